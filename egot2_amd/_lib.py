@@ -1,0 +1,113 @@
+"""ctypes binding of libegot2x.so (C ABI declared in include/egot2x.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load, every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libegot2x.so")
+
+EGX_ABI_VERSION = 1
+EGX_MAX_SEGMENTS = 8
+EGX_F32, EGX_BF16 = 0, 1
+EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED = 0, 1, 2
+
+_fp = C.c_void_p  # all device pointers travel as raw addresses
+
+
+class Segment(C.Structure):
+    _fields_ = [("feat", _fp), ("T", C.c_int), ("d_in", C.c_int), ("proj_w", _fp), ("proj_b", _fp),
+                ("add_vec", _fp), ("pos", _fp), ("pos_stride", C.c_int)]
+
+
+class SegmentGrads(C.Structure):
+    _fields_ = [("proj_w", _fp), ("proj_b", _fp), ("add_vec", _fp), ("pos", _fp), ("feat", _fp)]
+
+
+_LAYER_FIELDS = ["in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+                 "norm1_w", "norm1_b", "norm2_w", "norm2_b"]
+
+
+class Layer(C.Structure):
+    _fields_ = [(n, _fp) for n in _LAYER_FIELDS]
+
+
+class LayerGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in _LAYER_FIELDS]
+
+
+class Config(C.Structure):
+    _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int),
+                ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
+                ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float)]
+
+
+# symbol -> (restype, argtypes); every symbol include/egot2x.h declares
+SIGNATURES = {
+    "egx_abi_version": (C.c_int, []),
+    "egx_last_error": (C.c_char_p, []),
+    "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egx_encoder_fwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
+                                  _fp, _fp, _fp, C.c_int, C.c_uint64, _fp]),
+    "egx_encoder_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
+                                  _fp, _fp, _fp, C.POINTER(SegmentGrads), _fp, _fp, C.POINTER(LayerGrads),
+                                  C.c_int, C.c_uint64, _fp]),
+    "egx_pool_head_fwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int,
+                                    _fp, _fp, _fp]),
+    "egx_pool_head_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int,
+                                    _fp, _fp, _fp, _fp, _fp, _fp]),
+    "egx_linear_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "egx_linear_bwd_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "egx_linear_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "egx_gemm": (C.c_int, [C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp,
+                           C.c_size_t, _fp]),
+    "egx_layernorm_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "egx_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
+    "egx_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_attention_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_uint64, _fp]),
+}
+
+_lib = None
+
+
+class EgxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libegot2x.so (once). Raises loudly when the HIP extension is missing: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EgxError(
+            f"{LIB_PATH} is missing: build it with `python -m egot2_amd.build` (hipcc --offload-arch=gfx950). "
+            "egot2_amd has no CPU or PyTorch fallback for the translator.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.egx_abi_version()
+    if ver != EGX_ABI_VERSION:
+        raise EgxError(f"libegot2x ABI version {ver} != binding version {EGX_ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().egx_last_error()
+        raise EgxError("libegot2x: " + (msg.decode() if msg else f"error code {rc}"))
+
+
+def ptr(t) -> int | None:
+    """Device address of a contiguous fp32 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()

@@ -1,0 +1,81 @@
+"""Builds libegot2x.so (HIP, gfx950) in-tree with hipcc. No torch types cross this boundary."""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ_DIR = os.path.join(CSRC, "_obj")
+LIB_PATH = os.path.join(PKG_DIR, "libegot2x.so")
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "fused.hip", "encoder.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "egot2x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libegot2x.so cannot be built")
+    return exe
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 and link libegot2x.so. Returns the library path."""
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        stamp = obj + ".sha"
+        dg = _digest([src] + hdr_paths)
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+            continue
+        jobs.append((src, obj, stamp, dg))
+
+    def compile_one(job):
+        src, obj, stamp, dg = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        with open(stamp, "w") as f:
+            f.write(dg)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    if jobs or force or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,423 @@
+// C ABI + host orchestration of the translator (see include/egot2x.h for the reference call sites each
+// entry point replaces). Everything here only enqueues kernels on the caller's stream: no allocation,
+// no synchronisation, hipGraph-capturable.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/egot2x.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace egx {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- workspace plan ---------------------------------------------------------------------------
+struct LayerOff {
+    size_t x_in, qkv, lse, attn_o, res1, stats1, x1, hid, res2, stats2;
+};
+struct Plan {
+    int B = 0, S = 0, d = 0, H = 0, dff = 0, L = 0, nseg = 0;
+    size_t N = 0;
+    int seg_off[EGX_MAX_SEGMENTS];
+    size_t seg_pre[EGX_MAX_SEGMENTS], seg_stats[EGX_MAX_SEGMENTS];
+    LayerOff layer[64];
+    size_t saved_bytes = 0;
+    // scratch
+    size_t s_dA = 0, s_dB = 0, s_dqkv = 0, s_dhid = 0, s_slab = 0, slab_bytes = 0;
+    size_t scratch_bytes = 0;
+};
+
+static size_t take(size_t& cur, size_t bytes) {
+    size_t o = cur;
+    cur = align_up(cur + bytes, 256);
+    return o;
+}
+
+static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan& pl) {
+    EGX_CHECK(cfg && segs, "null config/segments");
+    EGX_CHECK(cfg->n_segments >= 1 && cfg->n_segments <= EGX_MAX_SEGMENTS, "n_segments=%d out of range", cfg->n_segments);
+    EGX_CHECK(cfg->n_layers >= 0 && cfg->n_layers <= 64, "n_layers=%d out of range", cfg->n_layers);
+    EGX_CHECK(cfg->d_model > 0 && cfg->d_model % 4 == 0 && cfg->d_model <= 1024, "d_model=%d unsupported (multiple of 4, <= 1024)", cfg->d_model);
+    EGX_CHECK(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0, "d_model=%d not divisible by n_heads=%d", cfg->d_model, cfg->n_heads);
+    EGX_CHECK(cfg->d_ff > 0 && cfg->d_ff % 4 == 0, "d_ff=%d must be a positive multiple of 4", cfg->d_ff);
+    EGX_CHECK(cfg->compute == EGX_F32 || cfg->compute == EGX_BF16, "compute=%d unknown", cfg->compute);
+    EGX_CHECK(B > 0, "empty batch (B=%d)", B);
+    pl.B = B; pl.d = cfg->d_model; pl.H = cfg->n_heads; pl.dff = cfg->d_ff; pl.L = cfg->n_layers; pl.nseg = cfg->n_segments;
+    int S = 0;
+    for (int i = 0; i < pl.nseg; ++i) {
+        EGX_CHECK(segs[i].T > 0, "segment %d has T=%d", i, segs[i].T);
+        EGX_CHECK(segs[i].d_in > 0, "segment %d has d_in=%d", i, segs[i].d_in);
+        EGX_CHECK(segs[i].proj_w || segs[i].d_in == pl.d, "segment %d: identity projection needs d_in == d_model", i);
+        pl.seg_off[i] = S;
+        S += segs[i].T;
+    }
+    pl.S = S;
+    pl.N = (size_t)B * S;
+    size_t d = pl.d, N = pl.N;
+    size_t cur = 0;
+    for (int i = 0; i < pl.nseg; ++i) {
+        size_t rows = (size_t)B * segs[i].T;
+        pl.seg_pre[i] = take(cur, rows * d * 4);
+        pl.seg_stats[i] = take(cur, rows * 2 * 4);
+    }
+    for (int l = 0; l < pl.L; ++l) {
+        LayerOff& o = pl.layer[l];
+        o.x_in = take(cur, N * d * 4);
+        o.qkv = take(cur, N * 3 * d * 4);
+        o.lse = take(cur, (size_t)B * pl.H * S * 4);
+        o.attn_o = take(cur, N * d * 4);
+        o.res1 = take(cur, N * d * 4);
+        o.stats1 = take(cur, N * 2 * 4);
+        o.x1 = take(cur, N * d * 4);
+        o.hid = take(cur, N * (size_t)pl.dff * 4);
+        o.res2 = take(cur, N * d * 4);
+        o.stats2 = take(cur, N * 2 * 4);
+    }
+    pl.saved_bytes = cur;
+
+    size_t sc = 0;
+    pl.s_dA = take(sc, N * d * 4);
+    pl.s_dB = take(sc, N * d * 4);
+    pl.s_dqkv = take(sc, N * 3 * d * 4);
+    pl.s_dhid = take(sc, N * (size_t)pl.dff * 4);
+    size_t slab = 0;
+    auto upd = [&](int M, int Nn, int K) { slab = max(slab, gemm_scratch_bytes(2, M, Nn, K)); };
+    upd(3 * pl.d, pl.d, (int)N);
+    upd(pl.d, pl.d, (int)N);
+    upd(pl.dff, pl.d, (int)N);
+    upd(pl.d, pl.dff, (int)N);
+    for (int i = 0; i < pl.nseg; ++i)
+        if (segs[i].proj_w) upd(pl.d, segs[i].d_in, B * segs[i].T);
+    pl.slab_bytes = slab;
+    pl.s_slab = take(sc, slab);
+    pl.scratch_bytes = sc;
+    return 0;
+}
+
+static inline float* fptr(void* base, size_t off) { return (float*)((char*)base + off); }
+static inline const float* cfptr(const void* base, size_t off) { return (const float*)((const char*)base + off); }
+
+struct Drop {
+    uint64_t key = 0;
+    uint32_t thresh = 0;
+    float inv_keep = 1.f;
+};
+static Drop make_drop(int training, float p, uint64_t seed, uint32_t layer, uint32_t site) {
+    Drop dr;
+    if (training && p > 0.f) {
+        dr.key = site_key(seed, layer, site);
+        dr.thresh = drop_threshold(p);
+        dr.inv_keep = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    }
+    return dr;
+}
+
+static int linear_nt(const float* x, const float* W, const float* bias, float* y, int M, int N, int K, int relu,
+                     const Drop& dr, const float* residual, int compute, hipStream_t st) {
+    GemmParams g;
+    g.A = x; g.B = W; g.C = y;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = K; g.ldb = K; g.ldc = N;
+    g.bias = bias;
+    g.relu = relu;
+    g.drop_key = dr.key; g.drop_thresh = dr.thresh; g.drop_inv_keep = dr.inv_keep;
+    g.residual = residual; g.ldr = N;
+    return gemm(0, g, compute, 0, nullptr, 0, st);
+}
+
+// dx[M,K] = dy[M,N] W[N,K]  (+ mask/scale, + residual)
+static int linear_dx(const float* dy, const float* W, float* dx, int M, int N, int K, const float* mask, float mask_scale,
+                     const float* residual, int compute, hipStream_t st) {
+    GemmParams g;
+    g.A = dy; g.B = W; g.C = dx;
+    g.M = M; g.N = K; g.K = N;
+    g.lda = N; g.ldb = K; g.ldc = K;
+    g.mask = mask; g.ldm = K; g.mask_scale = mask_scale;
+    g.residual = residual; g.ldr = K;
+    return gemm(1, g, compute, 0, nullptr, 0, st);
+}
+
+// dW[N,K] += dy[M,N]^T x[M,K]
+static int linear_dw(const float* dy, const float* x, float* dW, int M, int N, int K, int compute, void* slab,
+                     size_t slab_bytes, hipStream_t st) {
+    GemmParams g;
+    g.A = dy; g.B = x; g.C = dW;
+    g.M = N; g.N = K; g.K = M;
+    g.lda = N; g.ldb = K; g.ldc = K;
+    return gemm(2, g, compute, 1, slab, slab_bytes, st);
+}
+
+}  // namespace egx
+
+using namespace egx;
+
+extern "C" {
+
+int egx_abi_version(void) { return EGX_ABI_VERSION; }
+const char* egx_last_error(void) { return g_err; }
+
+int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return 1;
+    if (saved_bytes) *saved_bytes = pl.saved_bytes;
+    if (scratch_bytes) *scratch_bytes = pl.scratch_bytes;
+    return 0;
+}
+
+int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B, float* tokens_out, void* saved, void* scratch, int training,
+                    uint64_t seed, void* stream) {
+    (void)scratch;
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return 1;
+    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused implementation not available for this configuration");
+    EGX_CHECK(tokens_out && saved && ln_w && ln_b, "null pointer argument");
+    EGX_CHECK(pl.L == 0 || layers, "null layers");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = pl.d, S = pl.S, comp = cfg->compute;
+    const int N = (int)pl.N;
+
+    float* x0 = pl.L > 0 ? fptr(saved, pl.layer[0].x_in) : tokens_out;
+    for (int i = 0; i < pl.nseg; ++i) {
+        const egx_segment& sg = segs[i];
+        int rows = B * sg.T;
+        const float* pre = sg.feat;
+        if (sg.proj_w) {
+            float* po = fptr(saved, pl.seg_pre[i]);
+            Drop df = make_drop(training, cfg->p_feat, seed, (uint32_t)i, SITE_FEAT);
+            if (linear_nt(sg.feat, sg.proj_w, sg.proj_b, po, rows, d, sg.d_in, 0, df, nullptr, comp, st)) return 1;
+            pre = po;
+        }
+        LnFwdParams lp;
+        lp.x = pre; lp.w = ln_w; lp.b = ln_b; lp.eps = cfg->ln_eps;
+        lp.stats = fptr(saved, pl.seg_stats[i]);
+        lp.y = x0; lp.rows = rows; lp.d = d;
+        lp.T = sg.T; lp.S = S; lp.off = pl.seg_off[i];
+        lp.add_vec = sg.add_vec; lp.pos = sg.pos; lp.pos_stride = sg.pos_stride;
+        Drop dp = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
+        lp.drop_key = dp.key; lp.drop_thresh = dp.thresh; lp.drop_inv_keep = dp.inv_keep;
+        if (layernorm_fwd(lp, st)) return 1;
+    }
+
+    for (int l = 0; l < pl.L; ++l) {
+        const LayerOff& o = pl.layer[l];
+        const egx_layer& w = layers[l];
+        const float* x_in = cfptr(saved, o.x_in);
+        float* x_out = (l + 1 < pl.L) ? fptr(saved, pl.layer[l + 1].x_in) : tokens_out;
+        Drop none;
+        if (linear_nt(x_in, w.in_proj_w, w.in_proj_b, fptr(saved, o.qkv), N, 3 * d, d, 0, none, nullptr, comp, st)) return 1;
+        Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
+        if (attention_fwd(cfptr(saved, o.qkv), fptr(saved, o.attn_o), fptr(saved, o.lse), B, S, pl.H, d, da.key, da.thresh,
+                          da.inv_keep, st)) return 1;
+        Drop d1 = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES1);
+        if (linear_nt(cfptr(saved, o.attn_o), w.out_proj_w, w.out_proj_b, fptr(saved, o.res1), N, d, d, 0, d1, x_in, comp, st)) return 1;
+        LnFwdParams l1;
+        l1.x = cfptr(saved, o.res1); l1.w = w.norm1_w; l1.b = w.norm1_b; l1.eps = cfg->ln_eps;
+        l1.stats = fptr(saved, o.stats1); l1.y = fptr(saved, o.x1); l1.rows = N; l1.d = d;
+        if (layernorm_fwd(l1, st)) return 1;
+        Drop dh = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN);
+        if (linear_nt(cfptr(saved, o.x1), w.lin1_w, w.lin1_b, fptr(saved, o.hid), N, pl.dff, d, 1, dh, nullptr, comp, st)) return 1;
+        Drop d2 = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2);
+        if (linear_nt(cfptr(saved, o.hid), w.lin2_w, w.lin2_b, fptr(saved, o.res2), N, d, pl.dff, 0, d2, cfptr(saved, o.x1), comp, st)) return 1;
+        LnFwdParams l2;
+        l2.x = cfptr(saved, o.res2); l2.w = w.norm2_w; l2.b = w.norm2_b; l2.eps = cfg->ln_eps;
+        l2.stats = fptr(saved, o.stats2); l2.y = x_out; l2.rows = N; l2.d = d;
+        if (layernorm_fwd(l2, st)) return 1;
+    }
+    return 0;
+}
+
+int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B, float* d_tokens, const void* saved, void* scratch,
+                    const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
+                    const egx_layer_grads* layer_grads, int training, uint64_t seed, void* stream) {
+    (void)ln_b;
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return 1;
+    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused implementation not available for this configuration");
+    EGX_CHECK(d_tokens && saved && scratch && ln_w, "null pointer argument");
+    EGX_CHECK(pl.L == 0 || (layers && layer_grads), "null layers / layer_grads");
+    hipStream_t st = (hipStream_t)stream;
+    const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;
+    const int N = (int)pl.N;
+    float* dA = fptr(scratch, pl.s_dA);
+    float* dBm = fptr(scratch, pl.s_dB);
+    float* dqkv = fptr(scratch, pl.s_dqkv);
+    float* dhid = fptr(scratch, pl.s_dhid);
+    void* slab = (char*)scratch + pl.s_slab;
+    float* g = d_tokens;
+
+    for (int l = pl.L - 1; l >= 0; --l) {
+        const LayerOff& o = pl.layer[l];
+        const egx_layer& w = layers[l];
+        const egx_layer_grads& gw = layer_grads[l];
+        // LayerNorm2 backward: dA = d(res2)
+        LnBwdParams b2;
+        b2.dy = g; b2.pre = cfptr(saved, o.res2); b2.stats = cfptr(saved, o.stats2); b2.w = w.norm2_w;
+        b2.dx = dA; b2.dw = gw.norm2_w; b2.db = gw.norm2_b; b2.rows = N; b2.d = d;
+        if (layernorm_bwd(b2, st)) return 1;
+        // dropout2 on the FFN branch
+        const float* dbr = dA;
+        Drop d2 = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2);
+        if (d2.thresh) {
+            EGX_HIP(hipMemcpyAsync(dBm, dA, (size_t)N * d * 4, hipMemcpyDeviceToDevice, st));
+            if (apply_dropout_mask(dBm, N, d, d2.key, d2.thresh, d2.inv_keep, st)) return 1;
+            dbr = dBm;
+        }
+        if (gw.lin2_b && colsum_accum(dbr, N, d, d, gw.lin2_b, st)) return 1;
+        if (gw.lin2_w && linear_dw(dbr, cfptr(saved, o.hid), gw.lin2_w, N, d, dff, comp, slab, pl.slab_bytes, st)) return 1;
+        Drop dh = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN);
+        if (linear_dx(dbr, w.lin2_w, dhid, N, d, dff, cfptr(saved, o.hid), dh.inv_keep, nullptr, comp, st)) return 1;
+        if (gw.lin1_b && colsum_accum(dhid, N, dff, dff, gw.lin1_b, st)) return 1;
+        if (gw.lin1_w && linear_dw(dhid, cfptr(saved, o.x1), gw.lin1_w, N, dff, d, comp, slab, pl.slab_bytes, st)) return 1;
+        // dx1 = dhid W1 + d(res2)  -> g
+        if (linear_dx(dhid, w.lin1_w, g, N, dff, d, nullptr, 1.f, dA, comp, st)) return 1;
+        // LayerNorm1 backward: dA = d(res1)
+        LnBwdParams b1;
+        b1.dy = g; b1.pre = cfptr(saved, o.res1); b1.stats = cfptr(saved, o.stats1); b1.w = w.norm1_w;
+        b1.dx = dA; b1.dw = gw.norm1_w; b1.db = gw.norm1_b; b1.rows = N; b1.d = d;
+        if (layernorm_bwd(b1, st)) return 1;
+        dbr = dA;
+        Drop d1 = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES1);
+        if (d1.thresh) {
+            EGX_HIP(hipMemcpyAsync(dBm, dA, (size_t)N * d * 4, hipMemcpyDeviceToDevice, st));
+            if (apply_dropout_mask(dBm, N, d, d1.key, d1.thresh, d1.inv_keep, st)) return 1;
+            dbr = dBm;
+        }
+        if (gw.out_proj_b && colsum_accum(dbr, N, d, d, gw.out_proj_b, st)) return 1;
+        if (gw.out_proj_w && linear_dw(dbr, cfptr(saved, o.attn_o), gw.out_proj_w, N, d, d, comp, slab, pl.slab_bytes, st)) return 1;
+        // d(attn_o) -> g
+        if (linear_dx(dbr, w.out_proj_w, g, N, d, d, nullptr, 1.f, nullptr, comp, st)) return 1;
+        Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
+        if (attention_bwd(cfptr(saved, o.qkv), cfptr(saved, o.attn_o), cfptr(saved, o.lse), g, dqkv, B, S, pl.H, d, da.key,
+                          da.thresh, da.inv_keep, st)) return 1;
+        if (gw.in_proj_b && colsum_accum(dqkv, N, 3 * d, 3 * d, gw.in_proj_b, st)) return 1;
+        if (gw.in_proj_w && linear_dw(dqkv, cfptr(saved, o.x_in), gw.in_proj_w, N, 3 * d, d, comp, slab, pl.slab_bytes, st)) return 1;
+        // dx_in = dqkv Win + d(res1) -> g
+        if (linear_dx(dqkv, w.in_proj_w, g, N, 3 * d, d, nullptr, 1.f, dA, comp, st)) return 1;
+    }
+
+    // token preparation backward
+    Drop dp = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
+    for (int i = 0; i < pl.nseg; ++i) {
+        const egx_segment& sg = segs[i];
+        egx_segment_grads sgr;
+        memset(&sgr, 0, sizeof(sgr));
+        if (seg_grads) sgr = seg_grads[i];
+        int rows = B * sg.T;
+        if (sgr.pos && pos_grad_accum(g, B, S, pl.seg_off[i], sg.T, d, sgr.pos, sg.pos_stride, dp.key, dp.thresh, dp.inv_keep, st)) return 1;
+        bool need_dx = (sg.proj_w && (sgr.proj_w || sgr.proj_b || sgr.feat)) || (!sg.proj_w && sgr.feat);
+        bool need_any = need_dx || d_ln_w || d_ln_b || sgr.add_vec;
+        if (!need_any) continue;
+        float* dseg = (!sg.proj_w && sgr.feat) ? sgr.feat : dA;
+        LnBwdParams bp;
+        bp.dy = g;
+        bp.pre = sg.proj_w ? cfptr(saved, pl.seg_pre[i]) : sg.feat;
+        bp.stats = cfptr(saved, pl.seg_stats[i]);
+        bp.w = ln_w; bp.dx = dseg; bp.dw = d_ln_w; bp.db = d_ln_b; bp.dadd = sgr.add_vec;
+        bp.rows = rows; bp.d = d; bp.T = sg.T; bp.S = S; bp.off = pl.seg_off[i];
+        bp.drop_key = dp.key; bp.drop_thresh = dp.thresh; bp.drop_inv_keep = dp.inv_keep;
+        if (sg.proj_w) {
+            Drop df = make_drop(training, cfg->p_feat, seed, (uint32_t)i, SITE_FEAT);
+            bp.out_drop_key = df.key; bp.out_drop_thresh = df.thresh; bp.out_drop_inv_keep = df.inv_keep;
+        }
+        if (layernorm_bwd(bp, st)) return 1;
+        if (sg.proj_w) {
+            if (sgr.proj_b && colsum_accum(dseg, rows, d, d, sgr.proj_b, st)) return 1;
+            if (sgr.proj_w && linear_dw(dseg, sg.feat, sgr.proj_w, rows, d, sg.d_in, comp, slab, pl.slab_bytes, st)) return 1;
+            if (sgr.feat && linear_dx(dseg, sg.proj_w, sgr.feat, rows, d, sg.d_in, nullptr, 1.f, nullptr, comp, st)) return 1;
+        }
+    }
+    return 0;
+}
+
+int egx_pool_head_fwd(const float* tokens, int B, int S, int d, const float* ln_w, const float* ln_b, float ln_eps,
+                      const float* W, const float* b, int n_out, float* pooled_saved, float* out, void* stream) {
+    EGX_CHECK(tokens && pooled_saved && out, "null pointer argument");
+    return pool_head_fwd(tokens, B, S, d, ln_w, ln_b, ln_eps, W, b, n_out, pooled_saved, out, (hipStream_t)stream);
+}
+
+int egx_pool_head_bwd(const float* d_out, const float* pooled_saved, int B, int S, int d, const float* ln_w,
+                      const float* ln_b, float ln_eps, const float* W, int n_out, float* d_tokens, float* d_ln_w,
+                      float* d_ln_b, float* d_W, float* d_b, void* stream) {
+    EGX_CHECK(d_out && pooled_saved && d_tokens, "null pointer argument");
+    return pool_head_bwd(d_out, pooled_saved, B, S, d, ln_w, ln_b, ln_eps, W, n_out, d_tokens, d_ln_w, d_ln_b, d_W, d_b,
+                         (hipStream_t)stream);
+}
+
+int egx_linear_fwd(const float* x, const float* W, const float* b, float* y, int M, int N, int K, int relu, int compute,
+                   void* stream) {
+    EGX_CHECK(x && W && y, "null pointer argument");
+    Drop none;
+    return linear_nt(x, W, b, y, M, N, K, relu, none, nullptr, compute, (hipStream_t)stream);
+}
+
+size_t egx_linear_bwd_scratch(int M, int N, int K) { return gemm_scratch_bytes(2, N, K, M); }
+
+int egx_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
+                   int compute, void* scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    EGX_CHECK(dy, "null dy");
+    if (db && colsum_accum(dy, M, N, N, db, st)) return 1;
+    if (dW) {
+        EGX_CHECK(x && scratch, "linear_bwd: dW needs x and scratch");
+        if (linear_dw(dy, x, dW, M, N, K, compute, scratch, gemm_scratch_bytes(2, N, K, M), st)) return 1;
+    }
+    if (dx) {
+        EGX_CHECK(W, "linear_bwd: dx needs W");
+        if (linear_dx(dy, W, dx, M, N, K, nullptr, 1.f, nullptr, compute, st)) return 1;
+    }
+    return 0;
+}
+
+int egx_gemm(int layout, const float* A, const float* Bm, float* C, int M, int N, int K, const float* bias, int relu,
+             int compute, void* scratch, size_t scratch_bytes, void* stream) {
+    EGX_CHECK(A && Bm && C, "null pointer argument");
+    GemmParams g;
+    g.A = A; g.B = Bm; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.lda = (layout == 2) ? M : K;
+    g.ldb = (layout == 0) ? K : N;
+    g.ldc = N;
+    g.bias = bias; g.relu = relu;
+    return gemm(layout, g, compute, 0, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int egx_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps, float* pre,
+                      float* stats, float* y, int rows, int d, void* stream) {
+    EGX_CHECK(x && w && b && y, "null pointer argument");
+    LnFwdParams p;
+    p.x = x; p.res = res; p.w = w; p.b = b; p.eps = eps; p.pre = pre; p.stats = stats; p.y = y; p.rows = rows; p.d = d;
+    return layernorm_fwd(p, (hipStream_t)stream);
+}
+
+int egx_layernorm_bwd(const float* dy, const float* pre, const float* stats, const float* w, float* dx, float* dw,
+                      float* db, int rows, int d, void* stream) {
+    EGX_CHECK(dy && pre && stats && w && dx, "null pointer argument");
+    LnBwdParams p;
+    p.dy = dy; p.pre = pre; p.stats = stats; p.w = w; p.dx = dx; p.dw = dw; p.db = db; p.rows = rows; p.d = d;
+    return layernorm_bwd(p, (hipStream_t)stream);
+}
+
+int egx_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int d, float p_drop, uint64_t seed,
+                      void* stream) {
+    EGX_CHECK(qkv && out && lse, "null pointer argument");
+    Drop da = make_drop(p_drop > 0.f, p_drop, seed, 0, SITE_ATTN);
+    return attention_fwd(qkv, out, lse, B, S, H, d, da.key, da.thresh, da.inv_keep, (hipStream_t)stream);
+}
+
+int egx_attention_bwd(const float* qkv, const float* out, const float* lse, const float* d_out, float* d_qkv, int B,
+                      int S, int H, int d, float p_drop, uint64_t seed, void* stream) {
+    EGX_CHECK(qkv && out && lse && d_out && d_qkv, "null pointer argument");
+    Drop da = make_drop(p_drop > 0.f, p_drop, seed, 0, SITE_ATTN);
+    return attention_bwd(qkv, out, lse, d_out, d_qkv, B, S, H, d, da.key, da.thresh, da.inv_keep, (hipStream_t)stream);
+}
+
+}  // extern "C"

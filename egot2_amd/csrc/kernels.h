@@ -1,0 +1,93 @@
+// Internal launch interfaces shared by the translation units of libegot2x.
+#pragma once
+#include "common.h"
+
+namespace egx {
+
+struct GemmParams {
+    const float* A = nullptr;
+    const float* B = nullptr;
+    float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0;
+    const float* bias = nullptr;       // [N]
+    const float* residual = nullptr;   // [M, ldr], added last
+    int ldr = 0;
+    const float* mask = nullptr;       // [M, ldm]; C = mask > 0 ? C * mask_scale : 0   (ReLU / dropout backward)
+    int ldm = 0;
+    float mask_scale = 1.f;
+    int relu = 0;
+    uint64_t drop_key = 0;             // inverted dropout on (acc + bias [relu]) keyed by (row, col)
+    uint32_t drop_thresh = 0;
+    float drop_inv_keep = 1.f;
+    int k_chunk = 0;                   // set by gemm()
+    size_t slab_stride = 0;            // set by gemm()
+};
+
+// layout: 0 NT, 1 NN, 2 TN (see gemm.hip). compute: 0 fp32 MFMA, 1 bf16 MFMA.
+int gemm(int layout, GemmParams p, int compute, int accumulate, void* scratch, size_t scratch_bytes, hipStream_t st);
+size_t gemm_scratch_bytes(int layout, int M, int N, int K);
+
+// y[orow] = dropout(LN(x[row] (+ res[row])) * w + b) (+ add_vec) (+ pos[t]); row -> orow = (row / T) * S + off + row % T.
+struct LnFwdParams {
+    const float* x = nullptr;     // [rows, d]
+    const float* res = nullptr;   // [rows, d] or null
+    const float* w = nullptr;
+    const float* b = nullptr;
+    float eps = 1e-5f;
+    float* pre = nullptr;         // [rows, d] x + res written when non-null
+    float* stats = nullptr;       // [rows, 2] (mean, rstd) when non-null
+    float* y = nullptr;
+    int rows = 0, d = 0;
+    int T = 1, S = 1, off = 0;    // output row remap (T == S == 1... identity when T == S and off == 0)
+    const float* add_vec = nullptr;
+    const float* pos = nullptr;
+    int pos_stride = 0;
+    uint64_t drop_key = 0;
+    uint32_t drop_thresh = 0;
+    float drop_inv_keep = 1.f;
+};
+int layernorm_fwd(const LnFwdParams& p, hipStream_t st);
+
+// dx[row] = LN backward of dy[orow] (dropout mask re-applied to dy first); dw/db accumulated (+=).
+struct LnBwdParams {
+    const float* dy = nullptr;    // rows addressed through the remap
+    const float* pre = nullptr;   // [rows, d]
+    const float* stats = nullptr; // [rows, 2]
+    const float* w = nullptr;
+    float* dx = nullptr;          // [rows, d]
+    float* dw = nullptr;          // [d] +=
+    float* db = nullptr;          // [d] +=
+    float* dadd = nullptr;        // [d] += sum of (masked) dy rows (task-embedding gradient) or null
+    int rows = 0, d = 0;
+    int T = 1, S = 1, off = 0;
+    uint64_t drop_key = 0;        // mask on dy (dropout applied after LN in forward)
+    uint32_t drop_thresh = 0;
+    float drop_inv_keep = 1.f;
+    uint64_t out_drop_key = 0;    // mask on dx (dropout applied before LN in forward: HOI feature dropout)
+    uint32_t out_drop_thresh = 0;
+    float out_drop_inv_keep = 1.f;
+};
+int layernorm_bwd(const LnBwdParams& p, hipStream_t st);
+
+// out[c] += sum_r x[r * ld + c], r < rows, c < cols
+int colsum_accum(const float* x, int rows, int cols, int ld, float* out, hipStream_t st);
+// learned positional gradient: dpos[t * pos_stride + c] += sum_b dtok[(b * S + off + t) * d + c]  (dropout mask re-applied)
+int pos_grad_accum(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride,
+                   uint64_t drop_key, uint32_t drop_thresh, float drop_inv_keep, hipStream_t st);
+// x[i] *= dropmask(row, col) for a dense [rows, d] tensor
+int apply_dropout_mask(float* x, int rows, int d, uint64_t key, uint32_t thresh, float inv_keep, hipStream_t st);
+
+int attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int d,
+                  uint64_t drop_key, uint32_t drop_thresh, float drop_inv_keep, hipStream_t st);
+int attention_bwd(const float* qkv, const float* out, const float* lse, const float* d_out, float* d_qkv,
+                  int B, int S, int H, int d,
+                  uint64_t drop_key, uint32_t drop_thresh, float drop_inv_keep, hipStream_t st);
+
+int pool_head_fwd(const float* tokens, int B, int S, int d, const float* ln_w, const float* ln_b, float eps,
+                  const float* W, const float* b, int n_out, float* pooled, float* out, hipStream_t st);
+int pool_head_bwd(const float* d_out, const float* pooled, int B, int S, int d, const float* ln_w,
+                  const float* ln_b, float eps, const float* W, int n_out, float* d_tokens, float* d_ln_w,
+                  float* d_ln_b, float* d_W, float* d_b, hipStream_t st);
+
+}  // namespace egx

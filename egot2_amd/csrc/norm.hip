@@ -1,0 +1,385 @@
+// Row-wise kernels of the translator: LayerNorm forward/backward with fused residual, task-embedding,
+// positional encoding and dropout (token preparation), column sums for bias gradients, and the pooled
+// task head. HBM-bound: one 64-lane wave per token row, wavefront (DPP/shuffle) reductions, no LDS for
+// the row statistics.
+//
+// Reference math: HHI/models/ttm/model_taskspecific.py:222-226 (encode_prepare), :243-244 (mean + linear_head),
+// torch.nn.TransformerEncoderLayer post-LN residual blocks (norm1/norm2).
+#include "common.h"
+#include "kernels.h"
+
+namespace egx {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int remap_row(int row, int T, int S, int off) { return (row / T) * S + off + (row % T); }
+
+// ---- LayerNorm forward ------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int d = p.d;
+    const float inv_d = 1.f / (float)d;
+    for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+        const float* x = p.x + (size_t)row * d;
+        const float* rs = p.res ? p.res + (size_t)row * d : nullptr;
+        float v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = lane + 64 * i;
+            float t = 0.f;
+            if (c < d) {
+                t = x[c];
+                if (rs) t += rs[c];
+            }
+            v[i] = t;
+            s += t;
+        }
+        float mean = wave_sum(s) * inv_d;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = lane + 64 * i;
+            float t = (c < d) ? v[i] - mean : 0.f;
+            ss += t * t;
+        }
+        float var = wave_sum(ss) * inv_d;
+        float rstd = rsqrtf(var + p.eps);
+        if (p.stats && lane == 0) {
+            p.stats[2 * (size_t)row] = mean;
+            p.stats[2 * (size_t)row + 1] = rstd;
+        }
+        int t_in = row % p.T;
+        int orow = remap_row(row, p.T, p.S, p.off);
+        float* y = p.y + (size_t)orow * d;
+        float* pre = p.pre ? p.pre + (size_t)row * d : nullptr;
+        const float* pos = p.pos ? p.pos + (size_t)t_in * p.pos_stride : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = lane + 64 * i;
+            if (c < d) {
+                if (pre) pre[c] = v[i];
+                float o = (v[i] - mean) * rstd * p.w[c] + p.b[c];
+                if (p.add_vec) o += p.add_vec[c];
+                if (pos) o += pos[c];
+                if (p.drop_thresh) o *= drop_scale(p.drop_key, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv_keep);
+                y[c] = o;
+            }
+        }
+    }
+}
+
+int layernorm_fwd(const LnFwdParams& p, hipStream_t st) {
+    EGX_CHECK(p.d > 0 && p.d <= 1024, "layernorm: d=%d unsupported (max 1024)", p.d);
+    if (p.rows <= 0) return 0;
+    int nv = cdiv(p.d, 64);
+    int blocks = min(cdiv(p.rows, 4), 4096);
+    dim3 g(blocks), b(256);
+    if (nv <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, g, b, 0, st, p);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, g, b, 0, st, p);
+    else if (nv <= 8) hipLaunchKernelGGL(ln_fwd_kernel<8>, g, b, 0, st, p);
+    else if (nv <= 12) hipLaunchKernelGGL(ln_fwd_kernel<12>, g, b, 0, st, p);
+    else hipLaunchKernelGGL(ln_fwd_kernel<16>, g, b, 0, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- LayerNorm backward -----------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
+    __shared__ float red[3][4][64 * NV];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int d = p.d;
+    const float inv_d = 1.f / (float)d;
+    float aw[NV], ab[NV], aa[NV];
+    float wv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        aw[i] = 0.f; ab[i] = 0.f; aa[i] = 0.f;
+        int c = lane + 64 * i;
+        wv[i] = (c < d) ? p.w[c] : 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < p.rows; row += gridDim.x * 4) {
+        int orow = remap_row(row, p.T, p.S, p.off);
+        const float* dy = p.dy + (size_t)orow * d;
+        const float* pre = p.pre + (size_t)row * d;
+        float mean = p.stats[2 * (size_t)row];
+        float rstd = p.stats[2 * (size_t)row + 1];
+        float g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = lane + 64 * i;
+            float dyv = 0.f, x = 0.f;
+            if (c < d) {
+                dyv = dy[c];
+                if (p.drop_thresh) dyv *= drop_scale(p.drop_key, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv_keep);
+                x = (pre[c] - mean) * rstd;
+            }
+            xh[i] = x;
+            g[i] = dyv * wv[i];
+            s1 += g[i];
+            s2 += g[i] * x;
+            aw[i] += dyv * x;
+            ab[i] += dyv;
+        }
+        s1 = wave_sum(s1) * inv_d;
+        s2 = wave_sum(s2) * inv_d;
+        float* dx = p.dx + (size_t)row * d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = lane + 64 * i;
+            if (c < d) {
+                float o = rstd * (g[i] - s1 - xh[i] * s2);
+                if (p.out_drop_thresh) o *= drop_scale(p.out_drop_key, (uint32_t)row, (uint32_t)c, p.out_drop_thresh, p.out_drop_inv_keep);
+                dx[c] = o;
+            }
+        }
+    }
+    // block reduction of the parameter-gradient partials, one atomic per column per block
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        red[0][wave][lane + 64 * i] = aw[i];
+        red[1][wave][lane + 64 * i] = ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        if (p.dw) atomicAdd(p.dw + c, sw);
+        if (p.db) atomicAdd(p.db + c, sb);
+        if (p.dadd) atomicAdd(p.dadd + c, sb);
+    }
+    (void)aa;
+}
+
+int layernorm_bwd(const LnBwdParams& p, hipStream_t st) {
+    EGX_CHECK(p.d > 0 && p.d <= 1024, "layernorm_bwd: d=%d unsupported (max 1024)", p.d);
+    if (p.rows <= 0) return 0;
+    int nv = cdiv(p.d, 64);
+    int blocks = min(cdiv(p.rows, 4 * 8), 256);
+    if (blocks < 1) blocks = 1;
+    dim3 g(blocks), b(256);
+    if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, g, b, 0, st, p);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, g, b, 0, st, p);
+    else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, g, b, 0, st, p);
+    else if (nv <= 12) hipLaunchKernelGGL(ln_bwd_kernel<12>, g, b, 0, st, p);
+    else hipLaunchKernelGGL(ln_bwd_kernel<16>, g, b, 0, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- column sums (bias gradients) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+                                                      float* __restrict__ out, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int c = blockIdx.x * 64 + lane;
+    int r0 = blockIdx.y * rows_per_block;
+    int r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + wave; r < r1; r += 4) s += x[(size_t)r * ld + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+int colsum_accum(const float* x, int rows, int cols, int ld, float* out, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return 0;
+    int cb = cdiv(cols, 64);
+    int want = max(1, 1024 / cb);
+    int rpb = max(32, cdiv(rows, want));
+    dim3 g(cb, cdiv(rows, rpb));
+    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, x, rows, cols, ld, out, rpb);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- learned positional-embedding gradient -----------------------------------------------------
+__global__ void pos_grad_kernel(const float* __restrict__ dtok, int B, int S, int off, int T, int d,
+                                float* __restrict__ dpos, int pos_stride, uint64_t key, uint32_t thresh, float inv_keep) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * d) return;
+    int t = i / d, c = i % d;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        int orow = b * S + off + t;
+        float v = dtok[(size_t)orow * d + c];
+        if (thresh) v *= drop_scale(key, (uint32_t)orow, (uint32_t)c, thresh, inv_keep);
+        s += v;
+    }
+    dpos[(size_t)t * pos_stride + c] += s;
+}
+
+int pos_grad_accum(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride,
+                   uint64_t key, uint32_t thresh, float inv_keep, hipStream_t st) {
+    int n = T * d;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dtok, B, S, off, T, d, dpos, pos_stride,
+                       key, thresh, inv_keep);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ x, int rows, int d, uint64_t key, uint32_t thresh, float inv_keep) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t n = (size_t)rows * d;
+    if (i >= n) return;
+    uint32_t row = (uint32_t)(i / d), col = (uint32_t)(i % d);
+    x[i] *= drop_scale(key, row, col, thresh, inv_keep);
+}
+
+int apply_dropout_mask(float* x, int rows, int d, uint64_t key, uint32_t thresh, float inv_keep, hipStream_t st) {
+    size_t n = (size_t)rows * d;
+    if (!n || !thresh) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, d, key, thresh, inv_keep);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- pooled head: mean over tokens -> (LN) -> (Linear) ----------------------------------------
+constexpr int PH_MAXD = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void pool_head_fwd_kernel(const float* __restrict__ tokens, int S, int d,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                                                             const float* __restrict__ W, const float* __restrict__ bias, int n_out,
+                                                             float* __restrict__ pooled, float* __restrict__ out) {
+    __shared__ float y[PH_MAXD];
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* tk = tokens + (size_t)b * S * d;
+    float inv_s = 1.f / (float)S;
+    float loc = 0.f;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += tk[(size_t)t * d + c];
+        s *= inv_s;
+        y[c] = s;
+        pooled[(size_t)b * d + c] = s;
+        loc += s;
+    }
+    if (ln_w) {
+        float mean = block_sum(loc, red) / (float)d;
+        float v = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) { float t = y[c] - mean; v += t * t; }
+        float var = block_sum(v, red) / (float)d;
+        float rstd = rsqrtf(var + eps);
+        for (int c = threadIdx.x; c < d; c += 256) y[c] = (y[c] - mean) * rstd * ln_w[c] + ln_b[c];
+    }
+    __syncthreads();
+    if (W) {
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = wave; o < n_out; o += 4) {
+            float s = 0.f;
+            for (int c = lane; c < d; c += 64) s += y[c] * W[(size_t)o * d + c];
+            s = wave_sum(s);
+            if (lane == 0) out[(size_t)b * n_out + o] = s + (bias ? bias[o] : 0.f);
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) out[(size_t)b * d + c] = y[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_head_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ pooled,
+                                                             int S, int d, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                             float eps, const float* __restrict__ W, int n_out,
+                                                             float* __restrict__ d_tokens, float* __restrict__ d_ln_w,
+                                                             float* __restrict__ d_ln_b, float* __restrict__ d_W, float* __restrict__ d_b) {
+    __shared__ float xh[PH_MAXD];   // normalised pooled (or pooled when no LN)
+    __shared__ float dy[PH_MAXD];   // gradient w.r.t. head input y
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* pl = pooled + (size_t)b * d;
+    float mean = 0.f, rstd = 1.f;
+    if (ln_w) {
+        float loc = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) loc += pl[c];
+        mean = block_sum(loc, red) / (float)d;
+        float v = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) { float t = pl[c] - mean; v += t * t; }
+        float var = block_sum(v, red) / (float)d;
+        rstd = rsqrtf(var + eps);
+    }
+    const float* go = d_out + (size_t)b * (W ? n_out : d);
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float x = ln_w ? (pl[c] - mean) * rstd : pl[c];
+        xh[c] = x;
+        float g;
+        if (W) {
+            g = 0.f;
+            for (int o = 0; o < n_out; ++o) g += go[o] * W[(size_t)o * d + c];
+            float yv = ln_w ? x * ln_w[c] + ln_b[c] : x;
+            if (d_W)
+                for (int o = 0; o < n_out; ++o) atomicAdd(d_W + (size_t)o * d + c, go[o] * yv);
+        } else {
+            g = go[c];
+        }
+        dy[c] = g;
+    }
+    if (W && d_b && threadIdx.x < n_out) atomicAdd(d_b + threadIdx.x, go[threadIdx.x]);
+    __syncthreads();
+    float inv_s = 1.f / (float)S;
+    if (ln_w) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = threadIdx.x; c < d; c += 256) {
+            float g = dy[c] * ln_w[c];
+            s1 += g;
+            s2 += g * xh[c];
+            if (d_ln_w) atomicAdd(d_ln_w + c, dy[c] * xh[c]);
+            if (d_ln_b) atomicAdd(d_ln_b + c, dy[c]);
+        }
+        s1 = block_sum(s1, red) / (float)d;
+        s2 = block_sum(s2, red) / (float)d;
+        for (int c = threadIdx.x; c < d; c += 256) {
+            float g = dy[c] * ln_w[c];
+            dy[c] = rstd * (g - s1 - xh[c] * s2) * inv_s;
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) dy[c] *= inv_s;
+    }
+    __syncthreads();
+    float* dt = d_tokens + (size_t)b * S * d;
+    for (int i = threadIdx.x; i < S * d; i += 256) dt[i] = dy[i % d];
+}
+
+int pool_head_fwd(const float* tokens, int B, int S, int d, const float* ln_w, const float* ln_b, float eps,
+                  const float* W, const float* b, int n_out, float* pooled, float* out, hipStream_t st) {
+    EGX_CHECK(d <= PH_MAXD, "pool_head: d=%d exceeds %d", d, PH_MAXD);
+    EGX_CHECK(!W || (n_out >= 1 && n_out <= 64), "pool_head: n_out=%d out of range 1..64", n_out);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pool_head_fwd_kernel, dim3(B), dim3(256), 0, st, tokens, S, d, ln_w, ln_b, eps, W, b, n_out, pooled, out);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+int pool_head_bwd(const float* d_out, const float* pooled, int B, int S, int d, const float* ln_w,
+                  const float* ln_b, float eps, const float* W, int n_out, float* d_tokens, float* d_ln_w,
+                  float* d_ln_b, float* d_W, float* d_b, hipStream_t st) {
+    EGX_CHECK(d <= PH_MAXD, "pool_head: d=%d exceeds %d", d, PH_MAXD);
+    EGX_CHECK(!W || (n_out >= 1 && n_out <= 64), "pool_head: n_out=%d out of range 1..64", n_out);
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pool_head_bwd_kernel, dim3(B), dim3(256), 0, st, d_out, pooled, S, d, ln_w, ln_b, eps, W, n_out,
+                       d_tokens, d_ln_w, d_ln_b, d_W, d_b);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace egx

@@ -1,0 +1,354 @@
+"""torch.autograd bridges onto the C ABI of libegot2x.so.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); all arithmetic of the translator runs in the
+hand-written HIP kernels. There is no fallback: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (Config, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
+                   EGX_F32, EGX_BF16, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED)
+
+COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16}
+IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED}
+
+
+@dataclass
+class SegmentSpec:
+    T: int
+    d_in: int
+    has_proj: bool
+    add_row: Optional[int] = None      # row of the (1, K, d) task-embedding table, or None
+    pos_row0: Optional[int] = None     # first row of the positional table used by this segment, or None
+
+
+@dataclass
+class EncoderSpec:
+    d_model: int
+    n_heads: int
+    d_ff: int
+    n_layers: int
+    segments: List[SegmentSpec] = field(default_factory=list)
+    ln_eps: float = 1e-5
+    compute: str = "f32"
+    impl: str = "auto"
+    p_drop: float = 0.0
+    p_pos: float = 0.0
+    p_feat: float = 0.0
+    training: bool = False
+    seed: int = 0
+
+    def config(self) -> Config:
+        return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
+                      COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat))
+
+
+_scratch_cache = {}
+
+
+def _workspace(tag: str, device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only byte buffer per (tag, device). Safe because every call is ordered on the current stream."""
+    key = (tag, device.index)
+    buf = _scratch_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.EgxError(f"{name} is on {t.device}: the translator runs only on the GPU through libegot2x.so "
+                            "(no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.EgxError(f"{name} has dtype {t.dtype}; libegot2x stores activations and weights in fp32")
+    return t.contiguous()
+
+
+def _elem_ptr(t: torch.Tensor, row: int, row_elems: int) -> int:
+    return t.data_ptr() + 4 * row * row_elems
+
+
+class _GradPacker:
+    """Allocates every requested gradient as a 16-byte-aligned view of one zero-filled flat buffer."""
+
+    def __init__(self):
+        self.shapes = []
+        self.total = 0
+
+    def add(self, t: Optional[torch.Tensor], want: bool) -> int:
+        if t is None or not want:
+            self.shapes.append(None)
+            return -1
+        off = self.total
+        self.shapes.append((off, t.shape))
+        self.total += (t.numel() + 3) // 4 * 4
+        return len(self.shapes) - 1
+
+    def materialise(self, device) -> List[Optional[torch.Tensor]]:
+        flat = torch.zeros(max(self.total, 4), dtype=torch.float32, device=device)
+        out = []
+        for s in self.shapes:
+            if s is None:
+                out.append(None)
+            else:
+                off, shape = s
+                n = 1
+                for k in shape:
+                    n *= k
+                out.append(flat[off:off + n].view(shape))
+        return out
+
+
+class EncoderFn(torch.autograd.Function):
+    """tokens(B,S,d) = encoder(token_prep(feats)). Argument order:
+    spec, task_embed|None, pos_table|None, ln_w, ln_b, feats[n_seg], (proj_w, proj_b) per projecting segment,
+    12 tensors per layer in _LAYER_FIELDS order."""
+
+    @staticmethod
+    def forward(ctx, spec: EncoderSpec, task_embed, pos_table, ln_w, ln_b, *rest):
+        lib = _lib.load()
+        nseg = len(spec.segments)
+        feats = [_dev_f32(t, f"feats[{i}]") for i, t in enumerate(rest[:nseg])]
+        nproj = sum(1 for s in spec.segments if s.has_proj)
+        proj = [_dev_f32(t, "projection weight") for t in rest[nseg:nseg + 2 * nproj]]
+        layer_t = [_dev_f32(t, "layer weight") for t in rest[nseg + 2 * nproj:]]
+        assert len(layer_t) == 12 * spec.n_layers, "layer parameter count mismatch"
+        ln_w = _dev_f32(ln_w, "ln.weight")
+        ln_b = _dev_f32(ln_b, "ln.bias")
+        if task_embed is not None:
+            task_embed = _dev_f32(task_embed, "task_embed")
+        if pos_table is not None:
+            pos_table = _dev_f32(pos_table, "positional table")
+        d = spec.d_model
+        B = feats[0].shape[0]
+        device = feats[0].device
+
+        segs = (Segment * nseg)()
+        pi = 0
+        for i, (ss, f) in enumerate(zip(spec.segments, feats)):
+            if f.dim() != 3 or f.shape[0] != B or f.shape[1] != ss.T or f.shape[2] != ss.d_in:
+                raise _lib.EgxError(f"feats[{i}] has shape {tuple(f.shape)}, expected ({B}, {ss.T}, {ss.d_in})")
+            segs[i].feat = ptr(f)
+            segs[i].T = ss.T
+            segs[i].d_in = ss.d_in
+            if ss.has_proj:
+                w, b = proj[2 * pi], proj[2 * pi + 1]
+                if tuple(w.shape) != (d, ss.d_in):
+                    raise _lib.EgxError(f"projection {i} weight shape {tuple(w.shape)} != ({d}, {ss.d_in})")
+                segs[i].proj_w, segs[i].proj_b = ptr(w), ptr(b)
+                pi += 1
+            if ss.add_row is not None:
+                segs[i].add_vec = _elem_ptr(task_embed, ss.add_row, d)
+            if ss.pos_row0 is not None:
+                segs[i].pos = _elem_ptr(pos_table, ss.pos_row0, d)
+                segs[i].pos_stride = d
+        layers = (Layer * max(spec.n_layers, 1))()
+        for l in range(spec.n_layers):
+            for k, name in enumerate(_LAYER_FIELDS):
+                setattr(layers[l], name, ptr(layer_t[12 * l + k]))
+
+        cfg = spec.config()
+        sv, sc = C.c_size_t(0), C.c_size_t(0)
+        check(lib.egx_encoder_workspace(C.byref(cfg), segs, B, C.byref(sv), C.byref(sc)))
+        S = sum(s.T for s in spec.segments)
+        tokens = torch.empty((B, S, d), dtype=torch.float32, device=device)
+        needs_grad = torch.is_grad_enabled() and any(
+            isinstance(t, torch.Tensor) and t.requires_grad for t in (task_embed, pos_table, ln_w, ln_b) + tuple(rest))
+        if needs_grad:
+            saved = torch.empty(max(sv.value, 256), dtype=torch.uint8, device=device)
+        else:
+            saved = _workspace("saved", device, sv.value)
+        scratch = _workspace("scratch", device, sc.value)
+        check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
+                                  ptr(scratch), int(spec.training), C.c_uint64(spec.seed & (2**64 - 1)), _stream()))
+        ctx.spec = spec
+        ctx.B = B
+        ctx.nseg, ctx.nproj = nseg, nproj
+        ctx.saved_buf = saved
+        ctx.scratch_bytes = sc.value
+        ctx.has_te = task_embed is not None
+        ctx.has_pos = pos_table is not None
+        ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t))
+        return tokens
+
+    @staticmethod
+    def backward(ctx, d_tokens):
+        lib = _lib.load()
+        spec: EncoderSpec = ctx.spec
+        sv = list(ctx.saved_tensors)
+        task_embed = sv.pop(0) if ctx.has_te else None
+        pos_table = sv.pop(0) if ctx.has_pos else None
+        ln_w, ln_b = sv[0], sv[1]
+        nseg, nproj = ctx.nseg, ctx.nproj
+        feats = sv[2:2 + nseg]
+        proj = sv[2 + nseg:2 + nseg + 2 * nproj]
+        layer_t = sv[2 + nseg + 2 * nproj:]
+        d = spec.d_model
+        B = ctx.B
+        device = d_tokens.device
+        need = ctx.needs_input_grad  # (spec, task_embed, pos_table, ln_w, ln_b, *rest)
+
+        pk = _GradPacker()
+        i_te = pk.add(task_embed, need[1])
+        i_pos = pk.add(pos_table, need[2])
+        i_lnw = pk.add(ln_w, need[3])
+        i_lnb = pk.add(ln_b, need[4])
+        i_feat = [pk.add(f, need[5 + i]) for i, f in enumerate(feats)]
+        i_proj = [pk.add(t, need[5 + nseg + i]) for i, t in enumerate(proj)]
+        i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i]) for i, t in enumerate(layer_t)]
+        grads = pk.materialise(device)
+
+        def g(i):
+            return grads[i] if i >= 0 else None
+
+        segs = (Segment * nseg)()
+        sgr = (SegmentGrads * nseg)()
+        pi = 0
+        for i, (ss, f) in enumerate(zip(spec.segments, feats)):
+            segs[i].feat = ptr(f)
+            segs[i].T = ss.T
+            segs[i].d_in = ss.d_in
+            sgr[i].feat = ptr(g(i_feat[i]))
+            if ss.has_proj:
+                segs[i].proj_w, segs[i].proj_b = ptr(proj[2 * pi]), ptr(proj[2 * pi + 1])
+                sgr[i].proj_w, sgr[i].proj_b = ptr(g(i_proj[2 * pi])), ptr(g(i_proj[2 * pi + 1]))
+                pi += 1
+            if ss.add_row is not None:
+                segs[i].add_vec = _elem_ptr(task_embed, ss.add_row, d)
+                if i_te >= 0:
+                    sgr[i].add_vec = _elem_ptr(grads[i_te], ss.add_row, d)
+            if ss.pos_row0 is not None:
+                segs[i].pos = _elem_ptr(pos_table, ss.pos_row0, d)
+                segs[i].pos_stride = d
+                if i_pos >= 0:
+                    sgr[i].pos = _elem_ptr(grads[i_pos], ss.pos_row0, d)
+        layers = (Layer * max(spec.n_layers, 1))()
+        lgr = (LayerGrads * max(spec.n_layers, 1))()
+        for l in range(spec.n_layers):
+            for k, name in enumerate(_LAYER_FIELDS):
+                setattr(layers[l], name, ptr(layer_t[12 * l + k]))
+                setattr(lgr[l], name, ptr(g(i_layer[12 * l + k])))
+
+        cfg = spec.config()
+        dtok = d_tokens.contiguous().clone() if d_tokens.dtype == torch.float32 else d_tokens.float().contiguous()
+        scratch = _workspace("scratch", device, ctx.scratch_bytes)
+        check(lib.egx_encoder_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(ctx.saved_buf),
+                                  ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr, int(spec.training),
+                                  C.c_uint64(spec.seed & (2**64 - 1)), _stream()))
+        out = [None, g(i_te), g(i_pos), g(i_lnw), g(i_lnb)]
+        out += [g(i) for i in i_feat] + [g(i) for i in i_proj] + [g(i) for i in i_layer]
+        return tuple(out)
+
+
+def encoder(spec: EncoderSpec, feats: Sequence[torch.Tensor], task_embed, pos_table, ln_w, ln_b,
+            proj: Sequence[torch.Tensor], layer_params: Sequence[torch.Tensor]) -> torch.Tensor:
+    return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params)
+
+
+class PoolHeadFn(torch.autograd.Function):
+    """out = [Linear]([LN](mean_s tokens)); ln / linear are optional (None)."""
+
+    @staticmethod
+    def forward(ctx, tokens, ln_w, ln_b, W, b, eps: float):
+        lib = _lib.load()
+        tokens = _dev_f32(tokens, "tokens")
+        B, S, d = tokens.shape
+        ln_w = _dev_f32(ln_w, "ln weight") if ln_w is not None else None
+        ln_b = _dev_f32(ln_b, "ln bias") if ln_b is not None else None
+        W = _dev_f32(W, "head weight") if W is not None else None
+        b = _dev_f32(b, "head bias") if b is not None else None
+        n_out = W.shape[0] if W is not None else d
+        pooled = torch.empty((B, d), dtype=torch.float32, device=tokens.device)
+        out = torch.empty((B, n_out), dtype=torch.float32, device=tokens.device)
+        check(lib.egx_pool_head_fwd(ptr(tokens), B, S, d, ptr(ln_w), ptr(ln_b), float(eps), ptr(W), ptr(b), n_out,
+                                    ptr(pooled), ptr(out), _stream()))
+        ctx.dims = (B, S, d, n_out, float(eps))
+        ctx.has = (ln_w is not None, W is not None, b is not None)
+        ctx.save_for_backward(*[t for t in (pooled, ln_w, ln_b, W) if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        B, S, d, n_out, eps = ctx.dims
+        has_ln, has_W, has_b = ctx.has
+        sv = list(ctx.saved_tensors)
+        pooled = sv.pop(0)
+        ln_w = sv.pop(0) if has_ln else None
+        ln_b = sv.pop(0) if has_ln else None
+        W = sv.pop(0) if has_W else None
+        d_out = d_out.contiguous().float()
+        dev = d_out.device
+        d_tokens = torch.empty((B, S, d), dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        pk = _GradPacker()
+        i_lw = pk.add(ln_w, has_ln and need[1])
+        i_lb = pk.add(ln_b, has_ln and need[2])
+        i_W = pk.add(W, has_W and need[3])
+        i_b = pk.add(torch.empty(n_out, device="meta") if has_b else None, has_b and need[4])
+        gr = pk.materialise(dev)
+
+        def g(i):
+            return gr[i] if i >= 0 else None
+
+        check(lib.egx_pool_head_bwd(ptr(d_out), ptr(pooled), B, S, d, ptr(ln_w), ptr(ln_b), eps, ptr(W), n_out,
+                                    ptr(d_tokens), ptr(g(i_lw)), ptr(g(i_lb)), ptr(g(i_W)), ptr(g(i_b)), _stream()))
+        return (d_tokens if need[0] else None), g(i_lw), g(i_lb), g(i_W), g(i_b), None
+
+
+def pool_head(tokens, ln_w=None, ln_b=None, W=None, b=None, eps: float = 1e-5):
+    return PoolHeadFn.apply(tokens, ln_w, ln_b, W, b, eps)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b for a 2-D x, through the MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, compute: str):
+        lib = _lib.load()
+        x = _dev_f32(x, "x")
+        W = _dev_f32(W, "W")
+        b = _dev_f32(b, "b") if b is not None else None
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.egx_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, N, K, 0, COMPUTE[compute], _stream()))
+        ctx.compute = compute
+        ctx.has_b = b is not None
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        M, K = x.shape
+        N = W.shape[0]
+        need = ctx.needs_input_grad
+        dev = dy.device
+        dx = torch.empty_like(x) if need[0] else None
+        dW = torch.zeros_like(W) if need[1] else None
+        db = torch.zeros(N, dtype=torch.float32, device=dev) if (ctx.has_b and need[2]) else None
+        nbytes = lib.egx_linear_bwd_scratch(M, N, K)
+        scratch = _workspace("linear", dev, nbytes)
+        check(lib.egx_linear_bwd(ptr(dy), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K, COMPUTE[ctx.compute],
+                                 ptr(scratch), _stream()))
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, compute: str = "f32"):
+    shp = x.shape
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), W, b, compute)
+    return y.view(*shp[:-1], W.shape[0])

@@ -1,0 +1,87 @@
+"""Host-side core shared by every translator class: packs nn.Parameters into the C-ABI call of
+libegot2x.so. The nn.TransformerEncoder / nn.LayerNorm / nn.Linear submodules are kept only as PARAMETER
+CONTAINERS so that state_dict keys, shapes and default initialisation are byte-compatible with the reference
+(SURVEY.md §8b); their forward() is never called on the product path.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_egx
+from .functional import EncoderSpec, SegmentSpec
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoidal table with the reference's buffer name and shape (max_len, 1, d)
+    (HHI/models/ttm/model_taskspecific.py:131-151). The translator kernels read rows of `pe` directly; this
+    module's forward is only used by the (torch) EgoT2-g sequence decoder."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=1000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        pe = pe.unsqueeze(0).transpose(0, 1)  # (max_len, 1, d_model)
+        self.register_buffer('pe', pe)
+
+    def forward(self, x):
+        x = x + self.pe[:x.size(0), :]
+        return self.dropout(x)
+
+
+def encoder_layer_tensors(encoder: nn.TransformerEncoder) -> List[torch.Tensor]:
+    """Flatten nn.TransformerEncoder parameters in the order of egx_layer's fields."""
+    out = []
+    for layer in encoder.layers:
+        if getattr(layer, "norm_first", False):
+            raise ValueError("libegot2x implements the post-LN encoder layer only (norm_first=False)")
+        sa = layer.self_attn
+        if sa.in_proj_weight is None:
+            raise ValueError("separate q/k/v projection weights are not supported")
+        out += [sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias]
+    return out
+
+
+class TranslatorMixin:
+    """Adds the HIP encoder call to an nn.Module. `egx_compute` in {"f32", "bf16"}; `egx_impl` in
+    {"auto", "generic", "fused"}."""
+
+    egx_compute: str = "f32"
+    egx_impl: str = "auto"
+    _egx_step: int = 0
+
+    def set_compute(self, compute: str = "f32", impl: str = "auto"):
+        assert compute in F_egx.COMPUTE and impl in F_egx.IMPL
+        self.egx_compute, self.egx_impl = compute, impl
+        return self
+
+    def _egx_seed(self) -> int:
+        # counter-based: one fresh dropout key per forward, no device sync
+        self._egx_step += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._egx_step * 0xD1B54A32D192ED03) & (2**63 - 1)
+
+    def _egx_encode(self, feats: Sequence[torch.Tensor], segments: List[SegmentSpec], *, encoder: nn.TransformerEncoder,
+                    ln: nn.LayerNorm, projs: Sequence[Optional[nn.Linear]], task_embed: Optional[torch.Tensor],
+                    pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0) -> torch.Tensor:
+        layer0 = encoder.layers[0]
+        d = ln.normalized_shape[0]
+        spec = EncoderSpec(d_model=d, n_heads=layer0.self_attn.num_heads, d_ff=layer0.linear1.out_features,
+                           n_layers=len(encoder.layers), segments=segments, ln_eps=ln.eps,
+                           compute=self.egx_compute, impl=self.egx_impl,
+                           p_drop=p_drop, p_pos=p_pos, p_feat=p_feat,
+                           training=bool(self.training), seed=self._egx_seed() if self.training else 0)
+        proj_t = []
+        for s, p in zip(segments, projs):
+            if s.has_proj:
+                proj_t += [p.weight, p.bias]
+        return F_egx.encoder(spec, list(feats), task_embed, pos_table, ln.weight, ln.bias, proj_t,
+                             encoder_layer_tensors(encoder))

@@ -1,0 +1,187 @@
+/*
+ * egot2x.h — C ABI of libegot2x.so, the MI355X (gfx950) native task-translation
+ * transformer ("translator") for EgoT2's Stage-II fusion path.
+ *
+ * The reference has no native code: its translator is a chain of torch.nn calls.
+ * Each entry point below replaces the torch.nn call sites named next to it
+ * (paths relative to the reference checkout):
+ *
+ *   egx_encoder_fwd / egx_encoder_bwd
+ *       HHI/models/ttm/model_taskspecific.py:222-226,238-242 (proj_* -> encode_prepare -> cat
+ *       -> nn.TransformerEncoder), HHI/models/asd/model_taskspecific.py:133-155,
+ *       HHI/models/multitask/task_prompt_model.py:224-250,
+ *       HOI/models/lta/lta_models_lta_transfer.py:355-361 (proj_* -> cat -> ln + pe -> transformer),
+ *       HOI/models/pnr/video_model_transfer_3task.py:249-255,
+ *       HOI/models/multitask/video_model_builder.py:331-346; and their autograd backward.
+ *   egx_pool_head_fwd / egx_pool_head_bwd
+ *       HHI/models/ttm/model_taskspecific.py:243-244 (mean over tokens -> linear_head = LN + Linear),
+ *       HOI/models/pnr/video_model_transfer_3task.py:256-257; HOI LTA mean-pool
+ *       (lta_models_lta_transfer.py:362) with ln == NULL and W == NULL.
+ *   egx_linear_fwd / egx_linear_bwd
+ *       any nn.Linear on the path that is not inside the encoder (HOI MultiTaskHead projections,
+ *       HOI/models/lta/head_helper.py:245-248,281-283).
+ *   egx_gemm / egx_layernorm_* / egx_attention_*
+ *       the individual ATen ops (addmm, layer_norm, multi_head_attention_forward core) for unit parity tests.
+ *
+ * Conventions
+ *   - All tensors are dense fp32, row-major, device memory owned by the caller (PyTorch's caching
+ *     allocator). The library never allocates device memory; `saved` and `scratch` are caller-provided
+ *     workspaces sized by egx_encoder_workspace().
+ *   - Token layout is batch-first packed (B, S, d): one clip's S*d block is contiguous.
+ *   - Weights are torch-style [out, in] row-major.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host sync and
+ *     is hipGraph-capturable.
+ *   - Return value 0 = success; non-zero = error, message via egx_last_error() (thread-local).
+ *   - `compute`: EGX_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), EGX_BF16 = bf16 MFMA operands with
+ *     fp32 accumulation, fp32 LayerNorm/softmax statistics, fp32 storage.
+ */
+#ifndef EGOT2X_H
+#define EGOT2X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGX_ABI_VERSION 1
+#define EGX_MAX_SEGMENTS 8
+
+enum { EGX_F32 = 0, EGX_BF16 = 1 };
+enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2 };
+
+/* One contiguous run of tokens of the packed sequence, produced from one frozen-backbone feature
+ * tensor: tokens[b, off + t, :] = LN(feat[b, t, :] @ proj_w^T + proj_b) + add_vec + pos[t * pos_stride + :]
+ * (LN is the encoder's shared `ln`; proj_w == NULL means the feature is already d_model wide). */
+typedef struct egx_segment {
+    const float* feat;    /* (B, T, d_in) */
+    int T;
+    int d_in;
+    const float* proj_w;  /* [d_model, d_in] or NULL */
+    const float* proj_b;  /* [d_model] or NULL */
+    const float* add_vec; /* [d_model] task-embedding row, or NULL */
+    const float* pos;     /* first positional row for this segment, or NULL */
+    int pos_stride;       /* floats between consecutive positional rows */
+} egx_segment;
+
+/* Gradient sinks matching egx_segment; any pointer may be NULL (gradient not wanted).
+ * All sinks are ACCUMULATED into (+=): the caller zero-fills them once per backward. */
+typedef struct egx_segment_grads {
+    float* proj_w;
+    float* proj_b;
+    float* add_vec;
+    float* pos;       /* [T, d_model] rows with stride pos_stride (learned pe), or NULL */
+    float* feat;      /* (B, T, d_in) gradient into the feature, or NULL (frozen backbones) */
+} egx_segment_grads;
+
+/* nn.TransformerEncoderLayer parameters (post-LN, ReLU). */
+typedef struct egx_layer {
+    const float* in_proj_w;  /* [3d, d] rows = [Wq; Wk; Wv] */
+    const float* in_proj_b;  /* [3d] */
+    const float* out_proj_w; /* [d, d] */
+    const float* out_proj_b; /* [d] */
+    const float* lin1_w;     /* [d_ff, d] */
+    const float* lin1_b;     /* [d_ff] */
+    const float* lin2_w;     /* [d, d_ff] */
+    const float* lin2_b;     /* [d] */
+    const float* norm1_w;
+    const float* norm1_b;
+    const float* norm2_w;
+    const float* norm2_b;
+} egx_layer;
+
+typedef struct egx_layer_grads {
+    float* in_proj_w;
+    float* in_proj_b;
+    float* out_proj_w;
+    float* out_proj_b;
+    float* lin1_w;
+    float* lin1_b;
+    float* lin2_w;
+    float* lin2_b;
+    float* norm1_w;
+    float* norm1_b;
+    float* norm2_w;
+    float* norm2_b;
+} egx_layer_grads;
+
+typedef struct egx_config {
+    int d_model;
+    int n_heads;
+    int d_ff;
+    int n_layers;
+    int n_segments;
+    float ln_eps;
+    int compute;      /* EGX_F32 | EGX_BF16 */
+    int impl;         /* EGX_IMPL_* */
+    float p_drop;     /* encoder-layer dropout (attention probs, dropout1, FFN hidden, dropout2) */
+    float p_pos;      /* dropout on the token-prep output (PositionalEncoding.dropout, fixed 0.1 in HHI) */
+    float p_feat;     /* dropout on projected features before LN (HOI `dp`) */
+} egx_config;
+
+int egx_abi_version(void);
+const char* egx_last_error(void);
+
+/* Workspace sizes in bytes for a batch of B clips of S tokens (S = sum of segment T). */
+int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
+                          size_t* saved_bytes, size_t* scratch_bytes);
+
+/* tokens_out: (B, S, d). `saved` is written in forward and read in backward.
+ * training != 0 applies dropout with masks derived from (seed, site, element). */
+int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs,
+                    const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B,
+                    float* tokens_out, void* saved, void* scratch,
+                    int training, uint64_t seed, void* stream);
+
+/* d_tokens: (B, S, d) gradient w.r.t. tokens_out; it is consumed (overwritten). */
+int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs,
+                    const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B,
+                    float* d_tokens, const void* saved, void* scratch,
+                    const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
+                    const egx_layer_grads* layer_grads,
+                    int training, uint64_t seed, void* stream);
+
+/* pooled = mean_s tokens[b, s, :]; y = ln_w ? LN(pooled) : pooled; out = W ? y W^T + b : y.
+ * `pooled_saved` (B, d) is kept for backward. n_out <= 64 when W != NULL. */
+int egx_pool_head_fwd(const float* tokens, int B, int S, int d,
+                      const float* ln_w, const float* ln_b, float ln_eps,
+                      const float* W, const float* b, int n_out,
+                      float* pooled_saved, float* out, void* stream);
+int egx_pool_head_bwd(const float* d_out, const float* pooled_saved, int B, int S, int d,
+                      const float* ln_w, const float* ln_b, float ln_eps,
+                      const float* W, int n_out,
+                      float* d_tokens, float* d_ln_w, float* d_ln_b, float* d_W, float* d_b,
+                      void* stream);
+
+/* y[M,N] = x[M,K] W[N,K]^T + b (+ReLU). */
+int egx_linear_fwd(const float* x, const float* W, const float* b, float* y,
+                   int M, int N, int K, int relu, int compute, void* stream);
+/* dx[M,K] = dy W ; dW[N,K] += dy^T x ; db[N] += colsum(dy). Any output may be NULL.
+ * scratch must hold egx_linear_bwd_scratch(M,N,K) bytes. */
+size_t egx_linear_bwd_scratch(int M, int N, int K);
+int egx_linear_bwd(const float* dy, const float* x, const float* W,
+                   float* dx, float* dW, float* db, int M, int N, int K,
+                   int compute, void* scratch, void* stream);
+
+/* --- single-op entry points (unit parity tests) --- */
+/* layout: 0 = NT (C = A[M,K] B[N,K]^T), 1 = NN (C = A[M,K] B[K,N]), 2 = TN (C = A[K,M]^T B[K,N]). */
+int egx_gemm(int layout, const float* A, const float* B, float* C, int M, int N, int K,
+             const float* bias, int relu, int compute, void* scratch, size_t scratch_bytes, void* stream);
+int egx_layernorm_fwd(const float* x, const float* res, const float* w, const float* b, float eps,
+                      float* pre, float* stats, float* y, int rows, int d, void* stream);
+int egx_layernorm_bwd(const float* dy, const float* pre, const float* stats, const float* w,
+                      float* dx, float* dw, float* db, int rows, int d, void* stream);
+/* qkv: (B, S, 3d) packed in-proj output; out: (B, S, d); lse: (B, H, S). */
+int egx_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int d,
+                      float p_drop, uint64_t seed, void* stream);
+int egx_attention_bwd(const float* qkv, const float* out, const float* lse, const float* d_out,
+                      float* d_qkv, int B, int S, int H, int d,
+                      float p_drop, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGOT2X_H */

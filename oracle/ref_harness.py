@@ -1,0 +1,163 @@
+"""ORACLE — test infrastructure only. Imports the REAL reference translator classes from /root/reference with
+import-time stubs for packages this image lacks (fvcore Registry, torchtext.vocab, torchaudio). No arithmetic is
+stubbed: the reference's own forward() runs, fed by pass-through "backbones" that hand the synthetic feature
+tensors straight to the translator.
+
+Only usable where /root/reference exists (this container); the GPU box never sees it. HHI and HOI share
+top-level package names (`models`, `utils`), so use one tree per process.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from argparse import Namespace
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = os.environ.get("EGOT2_REFERENCE", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "HHI", "models"))
+
+
+def _stub_module(name: str, **attrs):
+    m = sys.modules.get(name)
+    if m is None:
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+def _install_stubs():
+    class Registry:  # the 10-line dict registry of fvcore
+        def __init__(self, name):
+            self._name, self._obj_map = name, {}
+
+        def register(self, obj=None):
+            if obj is None:
+                def deco(o):
+                    self._obj_map[o.__name__] = o
+                    return o
+                return deco
+            self._obj_map[obj.__name__] = obj
+
+        def get(self, name):
+            return self._obj_map[name]
+
+    try:
+        import fvcore  # noqa: F401
+    except ImportError:
+        _stub_module("fvcore")
+        _stub_module("fvcore.common")
+        _stub_module("fvcore.common.registry", Registry=Registry)
+    try:
+        import torchtext  # noqa: F401
+    except ImportError:
+        _stub_module("torchtext")
+        _stub_module("torchtext.vocab", vocab=lambda *a, **k: None, build_vocab_from_iterator=lambda *a, **k: None)
+    try:
+        import torchaudio  # noqa: F401
+    except ImportError:
+        _stub_module("torchaudio")
+        _stub_module("torchaudio.transforms", MelSpectrogram=lambda *a, **k: nn.Identity())
+        sys.modules["torchaudio"].transforms = sys.modules["torchaudio.transforms"]
+
+
+def use_tree(tree: str):
+    """Put /root/reference/<tree> (HHI or HOI) first on sys.path."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found under {REFERENCE_ROOT}")
+    _install_stubs()
+    path = os.path.join(REFERENCE_ROOT, tree)
+    other = "HOI" if tree == "HHI" else "HHI"
+    if any(p.rstrip("/").endswith("/" + other) for p in sys.path):
+        raise RuntimeError("HHI and HOI reference trees cannot be mixed in one process")
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+
+# ---- pass-through backbones (feature tensors travel through the reference's own forward) ----------
+class _LamPass(nn.Module):
+    def forward(self, video, middle=False):
+        return video
+
+
+class _TtmPass(nn.Module):
+    def forward(self, video, audio, middle=False):
+        return audio
+
+
+class _AsdPass(nn.Module):
+    def forward_audio_frontend(self, x):
+        return x
+
+    def forward_visual_frontend(self, x):
+        return x
+
+    def forward_cross_attention(self, a, v):
+        return a, v
+
+    def forward_audio_visual_backend(self, a, v):
+        return a.reshape(-1, a.shape[-1])
+
+
+def hhi_args(hidden_dim=128, num_heads=4, dropout=0.0, num_layers=1, **kw) -> Namespace:
+    return Namespace(lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None, nofreeze=True,
+                     hidden_dim=hidden_dim, num_heads=num_heads, dropout=dropout, num_layers=num_layers,
+                     hidden_dim2=512, **kw)
+
+
+def attach_passthrough(model: nn.Module) -> nn.Module:
+    model.lam_model, model.ttm_model, model.asd_model = _LamPass(), _TtmPass(), _AsdPass()
+    return model
+
+
+def ref_ttm(n_tasks: int, args: Namespace) -> nn.Module:
+    """Real reference TaskFusionMFTransformer{2,3}Task (HHI/models/ttm/model_taskspecific.py:154,197)."""
+    use_tree("HHI")
+    from models.ttm.model_taskspecific import TaskFusionMFTransformer2Task, TaskFusionMFTransformer3Task
+    cls = TaskFusionMFTransformer2Task if n_tasks == 2 else TaskFusionMFTransformer3Task
+    return attach_passthrough(cls(args))
+
+
+def ref_ttm_forward(model: nn.Module, ttm_out, lam_out, asd_out=None):
+    """Calls the reference forward(): lam_model(video)->video, ttm_model(video, audio)->audio,
+    asd backend(audio_asd)->audio_asd; video_asd only provides (N, D, H, W) = (B, T, 1, 1)."""
+    if asd_out is None:
+        return model(lam_out, ttm_out)  # forward(video, audio)
+    B, T = asd_out.shape[:2]
+    return model(lam_out, torch.zeros(B, T, 1, 1), ttm_out, asd_out)
+
+
+def ref_asd(args: Namespace) -> nn.Module:
+    """Real reference HHI/models/asd/model_taskspecific.py:108 TaskFusionMFTransformer3Task."""
+    use_tree("HHI")
+    from models.asd.model_taskspecific import TaskFusionMFTransformer3Task
+    return attach_passthrough(TaskFusionMFTransformer3Task(args))
+
+
+def ref_hhi_g(args: Namespace, vocab=None) -> nn.Module:
+    """Real reference TaskTranslationPromptTransformer (HHI/models/multitask/task_prompt_model.py:174) with the
+    backbone constructors patched out and CustomDecoderLayer._mha_block adapted to torch>=2 (extra is_causal arg;
+    arithmetic unchanged)."""
+    use_tree("HHI")
+    import models.multitask.task_prompt_model as tpm
+    tpm.LAMBackbone = lambda ckpt: _LamPass()
+    tpm.TTMBackbone = lambda ckpt: _TtmPass()
+    tpm.talkNetModel = lambda: _AsdPass()
+    tpm.load_ckpt = lambda *a, **k: None
+    tpm.freeze_params = lambda m: None
+    orig = tpm.CustomDecoderLayer._mha_block
+
+    def _mha_block(self, x, mem, attn_mask, key_padding_mask, is_causal=False):
+        return orig(self, x, mem, attn_mask, key_padding_mask)
+
+    if getattr(orig, "__name__", "") == "_mha_block" and orig.__code__.co_argcount == 5:
+        tpm.CustomDecoderLayer._mha_block = _mha_block
+    vocab = vocab or {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+    return tpm.TaskTranslationPromptTransformer(args, vocab)

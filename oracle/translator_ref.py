@@ -1,0 +1,195 @@
+"""ORACLE — test infrastructure only. Never imported by egot2_amd (the product path).
+
+CPU restatement of the reference's Stage-II translator arithmetic, written out op by op in plain torch tensor
+math (no nn.Transformer*, no nn.MultiheadAttention, no F.layer_norm), batch-first, dtype-generic (fp32 to mirror
+the reference, fp64 as a tight yardstick). Gradients come from torch.autograd over this restatement.
+
+Parity status: PINNED by generated fixtures, not by reference tests (the reference has none).
+tests/golden/make_golden.py imports the real reference classes from /root/reference (import-time stubs only) and
+records inputs / logits / loss / gradient digests; tests/test_oracle_golden.py checks this file against them.
+
+Follows (paths relative to the reference checkout):
+  token preparation      HHI/models/ttm/model_taskspecific.py:131-151 (PositionalEncoding), :222-226 (encode_prepare)
+  token packing          :238-241 (order ttm, lam, asd); HHI/models/asd/model_taskspecific.py:151-154 (asd, ttm, lam)
+  encoder layer          torch.nn.TransformerEncoderLayer as constructed at :212-215 (post-LN, ReLU, d_ff=2048,
+                         eps=1e-5): x = LN1(x + MHA(x)); x = LN2(x + W2 relu(W1 x))
+  TTM head               :243-244 (mean over tokens, LayerNorm, Linear(d, 2))
+  ASD output             HHI/models/asd/model_taskspecific.py:155-157 (first T tokens of every clip)
+  EgoT2-g encoder        HHI/models/multitask/task_prompt_model.py:224-258
+  HOI translators        HOI/models/lta/lta_models_lta_transfer.py:355-363, HOI/models/pnr/video_model_transfer_3task.py:249-257
+  LTA head               HOI/models/lta/head_helper.py:261-290 (training branch: Linear per future action)
+  loss                   HHI/tasks/ttm/video_task_2loader.py:21-22,34 (CrossEntropyLoss(weight=[0.266, 0.734]))
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)  # biased, as F.layer_norm
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    y = x @ w.transpose(-1, -2)
+    return y if b is None else y + b
+
+
+def sinusoid_table(max_len: int, d: int, dtype=torch.float32) -> torch.Tensor:
+    """(max_len, d) — same values as the reference's `pe` buffer (computed in fp32 like the reference, then cast)."""
+    pe = torch.zeros(max_len, d)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.to(dtype)
+
+
+def self_attention(x: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int) -> torch.Tensor:
+    """x: (B, S, d). Packed in-projection rows = [Wq; Wk; Wv]; per-head softmax(QK^T / sqrt(d_h)) V; out-projection."""
+    B, S, d = x.shape
+    dh = d // n_heads
+    qkv = linear(x, in_w, in_b)  # (B, S, 3d)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+
+    def heads(t):
+        return t.reshape(B, S, n_heads, dh).permute(0, 2, 1, 3)  # (B, H, S, dh)
+
+    q, k, v = heads(q), heads(k), heads(v)
+    scores = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    scores = scores - scores.max(dim=-1, keepdim=True).values
+    p = torch.exp(scores)
+    p = p / p.sum(dim=-1, keepdim=True)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, S, d)
+    return linear(o, out_w, out_b)
+
+
+def encoder_layer(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_heads: int, eps: float = 1e-5) -> torch.Tensor:
+    g = lambda k: sd[prefix + k]  # noqa: E731
+    a = self_attention(x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"),
+                       g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_heads)
+    x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"), eps)
+    h = torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))
+    f = linear(h, g("linear2.weight"), g("linear2.bias"))
+    return layer_norm(x + f, g("norm2.weight"), g("norm2.bias"), eps)
+
+
+def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_layers: int, n_heads: int) -> torch.Tensor:
+    for i in range(n_layers):
+        x = encoder_layer(x, sd, f"{prefix}layers.{i}.", n_heads)
+    return x
+
+
+def n_layers_of(sd: Dict[str, torch.Tensor], prefix: str) -> int:
+    n = 0
+    while f"{prefix}layers.{n}.norm1.weight" in sd:
+        n += 1
+    return n
+
+
+def encode_prepare(feat: torch.Tensor, proj_w, proj_b, ln_w, ln_b, task_vec, pe_rows) -> torch.Tensor:
+    """(B, T, d_in) -> (B, T, d): LN_shared(proj(feat)) + task_embed[k] + pe[0:T] (position restarts per task)."""
+    x = feat if proj_w is None else linear(feat, proj_w, proj_b)
+    x = layer_norm(x, ln_w, ln_b)
+    if task_vec is not None:
+        x = x + task_vec
+    if pe_rows is not None:
+        x = x + pe_rows
+    return x
+
+
+# ---- HHI: TTM translators ------------------------------------------------------------------------
+def hhi_tokens(sd, feats: Sequence[torch.Tensor], names: Sequence[str], task_ids: Sequence[int]) -> torch.Tensor:
+    pe = sd["pos_embed.pe"][:, 0, :]
+    xs = []
+    for f, n, k in zip(feats, names, task_ids):
+        T = f.shape[1]
+        xs.append(encode_prepare(f, sd[f"proj_{n}.weight"], sd[f"proj_{n}.bias"], sd["ln.weight"], sd["ln.bias"],
+                                 sd["task_embed"][0, k], pe[:T]))
+    return torch.cat(xs, dim=1)
+
+
+def ttm_forward(sd, n_heads: int, ttm_out, lam_out, asd_out=None) -> torch.Tensor:
+    """TaskFusionMFTransformer{2,3}Task.forward on backbone features -> (B, 2) logits."""
+    feats, names, ids = [ttm_out, lam_out], ["ttm", "lam"], [0, 1]
+    if asd_out is not None:
+        feats.append(asd_out); names.append("asd"); ids.append(2)
+    x = hhi_tokens(sd, feats, names, ids)
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    pooled = x.mean(dim=1)
+    y = layer_norm(pooled, sd["linear_head.0.weight"], sd["linear_head.0.bias"])
+    return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])
+
+
+def asd_forward(sd, n_heads: int, ttm_out, lam_out, asd_out) -> torch.Tensor:
+    """HHI/models/asd TaskFusionMFTransformer3Task: token order asd, ttm, lam (task ids 2, 0, 1); returns the
+    encoded ASD block as (B*T, d)."""
+    x = hhi_tokens(sd, [asd_out, ttm_out, lam_out], ["asd", "ttm", "lam"], [2, 0, 1])
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    B, T = asd_out.shape[0], asd_out.shape[1]
+    return x[:, :T, :].reshape(B * T, -1)
+
+
+def hhi_g_encode(sd, n_heads: int, task: str, lam_feat, ttm_feat=None, asd_feat=None) -> torch.Tensor:
+    """TaskTranslationPromptTransformer.encode -> memory in the reference's (S, B, d) / (3, B*T, d) layout."""
+    if task == "lam":
+        x = hhi_tokens(sd, [lam_feat], ["lam"], [0])
+    else:
+        x = hhi_tokens(sd, [lam_feat, ttm_feat, asd_feat], ["lam", "ttm", "asd"], [0, 1, 2])
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    if task == "asd":
+        B, S, d = x.shape
+        T = S // 3
+        return torch.stack([x[:, 0:T].reshape(-1, d), x[:, T:2 * T].reshape(-1, d), x[:, 2 * T:3 * T].reshape(-1, d)], dim=0)
+    return x.permute(1, 0, 2)
+
+
+def weighted_ce(logits: torch.Tensor, target: torch.Tensor, weight: Sequence[float]) -> torch.Tensor:
+    """nn.CrossEntropyLoss(weight=w): sum_i w[y_i] * nll_i / sum_i w[y_i]."""
+    w = torch.tensor(list(weight), dtype=logits.dtype)
+    z = logits - logits.max(dim=-1, keepdim=True).values
+    logp = z - torch.log(torch.exp(z).sum(dim=-1, keepdim=True))
+    nll = -logp.gather(1, target[:, None])[:, 0]
+    wi = w[target]
+    return (wi * nll).sum() / wi.sum()
+
+
+# ---- HOI translators ----------------------------------------------------------------------------
+def hoi_tokens(sd, feats: Sequence[torch.Tensor], proj_names: Sequence[Optional[str]]) -> torch.Tensor:
+    """cat(proj_k(feat_k)) -> shared LN -> + learned pe (1, S, d)."""
+    xs = [f if n is None else linear(f, sd[f"{n}.weight"], sd[f"{n}.bias"]) for f, n in zip(feats, proj_names)]
+    x = torch.cat(xs, dim=1)
+    return layer_norm(x, sd["ln.weight"], sd["ln.bias"]) + sd["pe"]
+
+
+def lta4_forward(sd, n_heads: int, feat_pnr, feat_oscc, feat_action, feat_lta, num_classes: Sequence[int]):
+    """TaskFusionMFTransformerLTA4Task.forward (training-mode head, no activation) on features:
+    pnr/oscc (B, n, 8192), action (B, n, d), lta (B, n, 2048) -> [(B, Z, n_verbs), (B, Z, n_nouns)]."""
+    x = hoi_tokens(sd, [feat_pnr, feat_oscc, feat_action, feat_lta], ["proj_pnr", "proj_oscc", None, "proj_lta"])
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+    pooled = x.mean(dim=1)
+    z = 0
+    outs = []
+    while f"head.projections.{z}.weight" in sd:
+        outs.append(linear(pooled, sd[f"head.projections.{z}.weight"], sd[f"head.projections.{z}.bias"]))
+        z += 1
+    y = torch.stack(outs, dim=1)
+    return list(torch.split(y, list(num_classes), dim=-1))
+
+
+def pnr3_forward(sd, n_heads: int, pnr_feat, oscc_feat, slow_feat, fast_feat) -> torch.Tensor:
+    """TaskFusionMFTransformer3TaskDropout.forward on features (eval / p = 0): the shared `ln` is also the first
+    element of linear_head."""
+    x = hoi_tokens(sd, [pnr_feat, oscc_feat, slow_feat, fast_feat], ["proj1", "proj2", "proj3_slow", "proj3_fast"])
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+    pooled = x.mean(dim=1)
+    y = layer_norm(pooled, sd["ln.weight"], sd["ln.bias"])
+    return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])
+
+
+def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
+    return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

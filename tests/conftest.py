@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (this container only)")
+
+
+@pytest.fixture(scope="session")
+def egx_lib():
+    """Built + loaded libegot2x.so (build is a no-op when the .so is current)."""
+    from egot2_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,70 @@
+"""Model-level parity (-m gpu): the HIP translator classes against the oracle restatement (fp64) on identical
+seeded weights and features. Tolerances follow BASELINE.json:north_star: logits within 1e-3 (fp32) / 1e-2 (bf16);
+gradients within 1e-2 relative."""
+import pytest
+import torch
+
+from oracle import translator_ref as tr
+from tests.util import hhi_args, max_err, rel_err, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+
+CE_W = [0.266, 0.734]
+
+
+def _oracle_ttm(sd, n_heads, feats, target):
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    logits = tr.ttm_forward(sd64, n_heads, *[f.double() for f in feats])
+    loss = tr.weighted_ce(logits, target, CE_W)
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: v.grad for k, v in sd64.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-3), ("bf16", 1e-2, 3e-2)])
+@pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1)])
+def test_ttm_translator_vs_oracle(egx_lib, cuda, compute, tol_logit, tol_grad, n_tasks, B, T, L):
+    from egot2_amd import hhi_ttm
+    cls = hhi_ttm.TaskFusionMFTransformer3Task if n_tasks == 3 else hhi_ttm.TaskFusionMFTransformer2Task
+    model = cls(hhi_args(num_layers=L))
+    sd = seeded_state_dict(model, seed=100 + n_tasks + B)
+    model.load_state_dict(sd)
+    model = model.to(cuda).set_compute(compute, "generic")
+    model.train()
+    model.pos_embed.dropout.p = 0.0  # parity is asserted at p = 0 (dropout masks cannot match torch's RNG)
+    feats = seeded_feats(7 + B, [(B, T, 256)] * n_tasks)
+    target = torch.from_numpy((__import__("numpy").random.default_rng(B).integers(0, 2, B))).long()
+    logits = model.forward_features(*[f.to(cuda) for f in feats])
+    loss = torch.nn.functional.cross_entropy(logits, target.to(cuda), weight=torch.tensor(CE_W, device=cuda))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_logits, ref_loss, ref_grads = _oracle_ttm(sd, 4, feats, target)
+    assert max_err(logits, ref_logits) < tol_logit
+    assert abs(loss.item() - ref_loss.item()) < tol_logit
+    named = dict(model.named_parameters())
+    assert set(ref_grads) == set(k for k, p in named.items() if p.grad is not None)
+    for k, gr in ref_grads.items():
+        e = rel_err(named[k].grad, gr)
+        assert e < tol_grad, f"{k}: rel grad err {e}"
+
+
+def test_ttm_eval_matches_train_p0(egx_lib, cuda):
+    from egot2_amd import hhi_ttm
+    model = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5))
+    model.load_state_dict(seeded_state_dict(model, 5))
+    model = model.to(cuda).eval()
+    feats = [f.to(cuda) for f in seeded_feats(3, [(4, 15, 256)] * 3)]
+    with torch.no_grad():
+        a = model.forward_features(*feats)
+        b = model.forward_features(*feats)
+    assert torch.equal(a, b)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = tr.ttm_forward(tr.to_dtype(sd, torch.float64), 4, *[f.cpu().double() for f in feats])
+    assert max_err(a, ref) < 1e-3
+
+
+def test_cpu_tensor_raises(egx_lib, cuda):
+    from egot2_amd import hhi_ttm, _lib
+    model = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args())
+    feats = seeded_feats(3, [(2, 15, 256)] * 3)
+    with pytest.raises(_lib.EgxError):
+        model.forward_features(*feats)

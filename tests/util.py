@@ -1,0 +1,45 @@
+"""Shared helpers for the parity tests."""
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+
+def hhi_args(hidden_dim=128, num_heads=4, dropout=0.0, num_layers=1):
+    return Namespace(lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None, nofreeze=True,
+                     hidden_dim=hidden_dim, num_heads=num_heads, dropout=dropout, num_layers=num_layers, hidden_dim2=512)
+
+
+def seeded_feats(seed, shapes):
+    """Features from numpy's PCG64 (stable across platforms), fp32."""
+    rng = np.random.default_rng(seed)
+    return [torch.from_numpy(rng.standard_normal(s, dtype=np.float32)) for s in shapes]
+
+
+def seeded_state_dict(model, seed, scale=None):
+    """Deterministic weights independent of torch's RNG: every floating tensor of the state_dict except the
+    sinusoid buffer is redrawn from PCG64 with a fan-in style scale; LayerNorm weights around 1."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("pos_embed.pe") or not v.is_floating_point():
+            sd[k] = v.clone()
+            continue
+        a = rng.standard_normal(tuple(v.shape), dtype=np.float32)
+        if v.dim() >= 2 and "task_embed" not in k and k != "pe":
+            a *= (1.0 / np.sqrt(v.shape[-1]))
+        elif ("norm" in k or k.startswith("ln.") or k.endswith("linear_head.0.weight")) and k.endswith("weight"):
+            a = 1.0 + 0.1 * a
+        elif k.endswith("bias"):
+            a *= 0.1
+        sd[k] = torch.from_numpy(a.astype(np.float32))
+    return sd
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def max_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
