@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/s, forward+backward, 3-task TTM translator (B=256 per GPU, T=15, d=128, h=4, L=1,
+d_ff=2048) on synthetic backbone features — BASELINE.json configs[1].
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = token preparation + encoder + pooled head + weighted CE + full backward (+ one RCCL all-reduce of the
+flat gradient buffer when N > 1) over one batch of 256 clips per GPU (weak scaling). Inputs are resident in HBM
+before the timed region. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(B, K, T, d_in, d, h, L, d_ff, n_out=2):
+    """GEMM FLOPs (2mnk), softmax/LN/elementwise excluded — BASELINE.md §2."""
+    S = K * T
+    N = B * S
+    proj = K * 2 * B * T * d_in * d
+    layer = 2 * N * d * 3 * d + 4 * B * S * S * d + 2 * N * d * d + 4 * N * d * d_ff
+    head = 2 * B * d * n_out
+    fwd = proj + L * layer + head
+    bwd = 2 * fwd - proj  # no dX into the frozen features
+    return fwd, bwd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=15)
+    ap.add_argument("--layers", type=int, default=1)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--dropout", type=float, default=0.5, help="encoder dropout (reference recipe README.md:84 uses 0.5)")
+    ap.add_argument("--optimizer", action="store_true", help="also run Adam.step() inside the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the translator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from egot2_amd import ddp, hhi_ttm, _lib
+    from tests.util import hhi_args
+    lib = _lib.load()
+
+    B, T, K, d, h, L, dff = args.batch, args.frames, 3, 128, 4, args.layers, 2048
+    torch.manual_seed(0)
+    model = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(hidden_dim=d, num_heads=h, dropout=args.dropout, num_layers=L))
+    model = model.to(dev).set_compute(args.dtype, args.impl).train()
+    ddp.broadcast_parameters(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4) if args.optimizer else None
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    feats = [torch.randn(B, T, 256, generator=g).to(dev) for _ in range(K)]
+    target = torch.randint(0, 2, (B,), generator=g).to(dev)
+    ce_w = torch.tensor([0.266, 0.734], device=dev)
+
+    def step():
+        for p in params:
+            p.grad = None
+        logits = model.forward_features(*feats)
+        loss = torch.nn.functional.cross_entropy(logits, target, weight=ce_w)
+        loss.backward()
+        ddp.allreduce_gradients(params)
+        if opt is not None:
+            opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    fwd_f, bwd_f = algorithmic_flops(B, K, T, 256, d, h, L, dff)
+
+    out = {
+        "metric": "clips/sec fwd+bwd, 3-task TTM translator (B=256,T=15,d=128)",
+        "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"configs[1]: TTM 3-task translator (LAM+TTM+ASD), {L} layer d=128 h=4 d_ff=2048, "
+                               f"B={B}/GPU T={T} S={K * T}, synthetic N(0,1) features, random-init weights, "
+                               f"train mode dropout={args.dropout} (+0.1 on PE), weighted CE, fwd+bwd"
+                               + (" + Adam" if opt else "") + (" + RCCL grad all-reduce" if world > 1 else ""),
+                   "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl},
+        "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
+        "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype],
+    }
+
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = measure_roofline(torch, lib, dev, B * K * T, d, dff, args.dtype)
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle.stock_module import time_cpu_baseline
+        out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_roofline(torch, lib, dev, N, d, dff, dtype):
+    """Dominant kernel of the generic path: the FFN GEMMs (87 % of FLOPs). Times the FFN1 forward GEMM
+    [N x d] x [dff x d]^T launch with device events on the stream it is launched on."""
+    x = torch.randn(N, d, device=dev)
+    w = torch.randn(dff, d, device=dev) * 0.05
+    b = torch.zeros(dff, device=dev)
+    y = torch.empty(N, dff, device=dev)
+    comp = 0 if dtype == "f32" else 1
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        lib.egx_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, dff, d, 1, comp, st)
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.egx_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, dff, d, 1, comp, st)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    flops = 2.0 * N * d * dff
+    ach = flops / t / 1e12
+    return {"bound": "mfma", "kernel": "gemm_kernel<128,128,NT> (FFN linear1 forward)", "achieved": ach,
+            "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
+            "flops_per_launch": flops, "avg_launch_us": t * 1e6}
+
+
+if __name__ == "__main__":
+    main()

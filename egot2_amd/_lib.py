@@ -88,6 +88,9 @@ def load() -> C.CDLL:
         raise EgxError(
             f"{LIB_PATH} is missing: build it with `python -m egot2_amd.build` (hipcc --offload-arch=gfx950). "
             "egot2_amd has no CPU or PyTorch fallback for the translator.")
+    # PyTorch owns the in-process HIP runtime (its wheel bundles libamdhip64): import it first so that
+    # libegot2x.so binds to the SAME runtime instance; loading ours first splits the process across two runtimes.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -20,7 +20,7 @@ def _oracle_ttm(sd, n_heads, feats, target):
     return logits.detach(), loss.detach(), {k: v.grad for k, v in sd64.items() if v.grad is not None}
 
 
-@pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-3), ("bf16", 1e-2, 3e-2)])
+@pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-3), ("bf16", 1e-2, 8e-2)])
 @pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1)])
 def test_ttm_translator_vs_oracle(egx_lib, cuda, compute, tol_logit, tol_grad, n_tasks, B, T, L):
     from egot2_amd import hhi_ttm
