@@ -14,7 +14,8 @@ OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(PKG_DIR, "libegot2x.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "fused.hip", "encoder.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "egot2x.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+EXTRA = os.environ.get("EGX_CXXFLAGS", "").split()
+FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:

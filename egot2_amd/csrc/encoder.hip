@@ -7,6 +7,7 @@
 #include "../../include/egot2x.h"
 #include "common.h"
 #include "kernels.h"
+#include "fused.h"
 
 namespace egx {
 
@@ -102,6 +103,38 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
     return 0;
 }
 
+// ---- fused per-clip path (fused.hip) ---------------------------------------------------------------
+static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    if (pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1) return false;
+    if (cfg->p_feat > 0.f) return false;
+    int d_in[EGX_MAX_SEGMENTS], T[EGX_MAX_SEGMENTS];
+    bool hp[EGX_MAX_SEGMENTS];
+    for (int i = 0; i < pl.nseg; ++i) { d_in[i] = segs[i].d_in; T[i] = segs[i].T; hp[i] = segs[i].proj_w != nullptr; }
+    return fused_supported(pl.d, pl.H, pl.dff, pl.S, pl.nseg, d_in, T, hp);
+}
+static size_t fused_act_bytes(const Plan& pl) { return align_up((size_t)(1 + 2 * pl.L) * pl.N * pl.d * 4, 256); }
+static size_t fused_pack_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    size_t b = 0;
+    int bf = cfg->compute == EGX_BF16;
+    for (int i = 0; i < pl.nseg; ++i) b += align_up(packed_bytes(pl.d, segs[i].d_in, bf), 256);
+    b += (size_t)pl.L * (align_up(packed_bytes(3 * pl.d, pl.d, bf), 256) + align_up(packed_bytes(pl.d, pl.d, bf), 256) +
+                         2 * align_up(packed_bytes(pl.dff, pl.d, bf), 256));
+    return b;
+}
+static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return fused_act_bytes(pl) + fused_pack_bytes(cfg, segs, pl);
+}
+
+static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan& pl, bool* err) {
+    *err = false;
+    bool ok = fused_ok(cfg, segs, pl);
+    if (cfg->impl == EGX_IMPL_FUSED) {
+        if (!ok) { set_error("fused implementation does not support this configuration (needs d=128, h=4, S<=48, d_ff%%128==0, projected segments, <=4 layers)"); *err = true; }
+        return ok;
+    }
+    return false;   // EGX_IMPL_AUTO keeps the generic path until the fused backward lands
+}
+
 static inline float* fptr(void* base, size_t off) { return (float*)((char*)base + off); }
 static inline const float* cfptr(const void* base, size_t off) { return (const float*)((const char*)base + off); }
 
@@ -162,12 +195,13 @@ using namespace egx;
 extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
+int egx_debug_stamps(unsigned long long* out, int n) { return debug_read_stamps(out, n); }
 const char* egx_last_error(void) { return g_err; }
 
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    if (saved_bytes) *saved_bytes = pl.saved_bytes;
+    if (saved_bytes) *saved_bytes = max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
     if (scratch_bytes) *scratch_bytes = pl.scratch_bytes;
     return 0;
 }
@@ -178,12 +212,58 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
     (void)scratch;
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused implementation not available for this configuration");
     EGX_CHECK(tokens_out && saved && ln_w && ln_b, "null pointer argument");
     EGX_CHECK(pl.L == 0 || layers, "null layers");
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute;
     const int N = (int)pl.N;
+    bool ferr;
+    if (use_fused(cfg, segs, pl, &ferr)) {
+        FusedFwdParams fp;
+        memset(&fp, 0, sizeof(fp));
+        // rewrite the weights into MFMA-fragment order (once per forward; they live behind the saved activations)
+        PackParams pk;
+        memset(&pk, 0, sizeof(pk));
+        pk.bf16 = comp == EGX_BF16;
+        char* pcur = (char*)saved + fused_act_bytes(pl);
+        auto add_pack = [&](const float* src, int R, int K) -> const void* {
+            PackDesc& dsc = pk.d[pk.n++];
+            dsc.src = src; dsc.dst = pcur; dsc.R = R; dsc.K = K; dsc.ld = K; dsc.transpose = 0;
+            pcur += align_up(packed_bytes(R, K, pk.bf16), 256);
+            return dsc.dst;
+        };
+        for (int i = 0; i < pl.nseg; ++i) {
+            FusedSeg& fs = fp.seg[i];
+            fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, d, segs[i].d_in); fs.proj_b = segs[i].proj_b;
+            fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos;
+            fs.T = segs[i].T; fs.d_in = segs[i].d_in; fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
+        }
+        for (int l = 0; l < pl.L; ++l) {
+            FusedLayer& fl = fp.layer[l];
+            const egx_layer& w = layers[l];
+            fl.in_proj_wp = add_pack(w.in_proj_w, 3 * d, d); fl.in_proj_b = w.in_proj_b;
+            fl.out_proj_wp = add_pack(w.out_proj_w, d, d); fl.out_proj_b = w.out_proj_b;
+            fl.lin1_wp = add_pack(w.lin1_w, pl.dff, d); fl.lin1_b = w.lin1_b;
+            fl.lin2_wp = add_pack(w.lin2_w, d, pl.dff); fl.lin2_b = w.lin2_b;
+            fl.norm1_w = w.norm1_w; fl.norm1_b = w.norm1_b; fl.norm2_w = w.norm2_w; fl.norm2_b = w.norm2_b;
+            Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
+            fl.attn_key = da.key; fl.attn_thresh = da.thresh; fl.drop_inv = da.inv_keep;
+            fl.res_thresh = da.thresh; fl.ffn_thresh = da.thresh;
+            fl.res1_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES1).key;
+            fl.ffn_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN).key;
+            fl.res2_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2).key;
+        }
+        fp.ln_w = ln_w; fp.ln_b = ln_b; fp.eps = cfg->ln_eps;
+        fp.nseg = pl.nseg; fp.n_layers = pl.L; fp.B = B; fp.S = S; fp.d_ff = pl.dff;
+        fp.tokens_out = tokens_out;
+        fp.saved_pre = (float*)saved;
+        fp.saved_res = (float*)saved + (size_t)N * d;
+        Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
+        fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
+        if (pack_weights(pk, st)) return 1;
+        return fused_forward(fp, comp, st);
+    }
+    if (ferr) return 1;
 
     float* x0 = pl.L > 0 ? fptr(saved, pl.layer[0].x_in) : tokens_out;
     for (int i = 0; i < pl.nseg; ++i) {
@@ -242,7 +322,7 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
     (void)ln_b;
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused implementation not available for this configuration");
+    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused backward not available yet");
     EGX_CHECK(d_tokens && saved && scratch && ln_w, "null pointer argument");
     EGX_CHECK(pl.L == 0 || (layers && layer_grads), "null layers / layer_grads");
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,786 @@
+// Fused per-clip translator kernels for the small-d regime (d_model = 128, 4 heads of 32, S <= 64 tokens).
+//
+// One 256-thread workgroup (4 waves, one per SIMD, one workgroup per CU) owns ONE clip and carries its packed
+// (S, d) token block through token preparation, the encoder layers and back entirely on chip: activations
+// live in LDS (135 KB of the CU's 160 KB) and in MFMA accumulators, weights stream from L2 exactly once per
+// clip straight into MFMA A-operand registers, and nothing but the saved pre-LayerNorm residuals touches HBM.
+// B = 256 clips fill the 256 CUs of an MI355X with a single wave of workgroups.
+//
+// Everything is computed FEATURE-MAJOR (Y^T = W X^T): the 16x16 MFMA C tile then has the token on the lane
+// column and four consecutive output features in the lane's 4 registers, which is exactly the B-operand layout
+// of the next GEMM whose K dimension is that feature axis. GEMM chains (W1 -> ReLU -> W2, QK^T -> softmax ->
+// PV) therefore run accumulator -> operand with no LDS round trip and no shuffles. One operand convention serves
+// fp32 (v_mfma_f32_16x16x4_f32, exact) and bf16 (v_mfma_f32_16x16x32_bf16, fp32 accumulate):
+//   a K-block is 32 wide; lane group q = lane >> 4 holds k in {4q..4q+3} U {16+4q..16+4q+3} of the block.
+//
+// Reference math: HHI/models/ttm/model_taskspecific.py:222-226,238-242 + torch.nn.TransformerEncoderLayer.
+#include "common.h"
+#include "kernels.h"
+#include "fused.h"
+
+namespace egx {
+
+constexpr int FD = 128;        // d_model
+constexpr int FH = 4;          // heads
+constexpr int FDH = 32;        // head dim
+constexpr int LDX = FD + 4;    // token-major LDS row stride (floats)
+constexpr int LDV = 64 + 4;    // V^T row stride: keys padded to 64
+
+// ---- operand fragments --------------------------------------------------------------------------
+template <bool BF16> struct Frag { float v[8]; };
+template <> struct Frag<true> { bf16x8 v; };
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> make_frag(float4 a, float4 b) {
+    Frag<BF16> f;
+    if constexpr (BF16) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 u = {pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w)};
+        f.v = __builtin_bit_cast(bf16x8, u);
+    } else {
+        f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+        f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    }
+    return f;
+}
+
+// fragment of one row/column for the K-block that starts at p (fp32 memory, 16-byte aligned)
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> load_frag(const float* p, int q) {
+    float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
+    float4 b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
+    return make_frag<BF16>(a, b);
+}
+
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> zero_frag() {
+    return make_frag<BF16>(make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));
+}
+
+// raw (unconverted) fragment data: issued early so that many loads are in flight at once
+struct Raw { float4 a, b; };
+__device__ __forceinline__ Raw load_raw(const float* p, int q) {
+    Raw x;
+    x.a = *reinterpret_cast<const float4*>(p + 4 * q);
+    x.b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
+    return x;
+}
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> to_frag(const Raw& x) { return make_frag<BF16>(x.a, x.b); }
+// Pins a prefetched fragment at this program point: the loads that produce it must have been issued above (hipcc
+// otherwise sinks every load down to its convert/MFMA and waits on each one individually), and the single
+// s_waitcnt for the whole batch lands here.
+__device__ __forceinline__ void pin(Raw& x) {
+    asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
+}
+
+// ---- packed weights ---------------------------------------------------------------------------------
+// A row-major weight read in MFMA-fragment shape makes every lane of a 16-lane group touch a different cache
+// line (16 rows x 64 B per instruction): the texture addresser then delivers ~16 B/clk/CU and the whole kernel
+// runs at that rate. pack_weights_kernel therefore rewrites each weight ONCE per step into fragment order:
+//   block (tile t of 16 rows, K-block kb of 32) holds the 64 lanes' operands contiguously, so a fragment load is
+//   one (bf16: uint4) or two (fp32: float4 planes) perfectly coalesced 1 KiB wave accesses.
+//   fp32: float4 plane[half][lane] = W[t*16 + r][kb*32 + half*16 + 4q .. +3]
+//   bf16: uint4  [lane]            = bf16 of the same 8 values (half 0 first)
+template <bool BF16> struct WRaw { float4 a, b; };
+template <> struct WRaw<true> { uint4 v; };
+
+template <bool BF16>
+__device__ __forceinline__ WRaw<BF16> load_w(const void* packed, int tile, int nkb, int kb, int lane) {
+    WRaw<BF16> x;
+    size_t blk = (size_t)tile * nkb + kb;
+    if constexpr (BF16) {
+        x.v = reinterpret_cast<const uint4*>(packed)[blk * 64 + lane];
+    } else {
+        const float4* pl = reinterpret_cast<const float4*>(packed) + blk * 128;
+        x.a = pl[lane];
+        x.b = pl[64 + lane];
+    }
+    return x;
+}
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> w_frag(const WRaw<BF16>& x) {
+    if constexpr (BF16) {
+        Frag<true> f;
+        f.v = __builtin_bit_cast(bf16x8, x.v);
+        return f;
+    } else {
+        return make_frag<false>(x.a, x.b);
+    }
+}
+__device__ __forceinline__ void pin(WRaw<false>& x) {
+    asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
+}
+__device__ __forceinline__ void pin(WRaw<true>& x) {
+    asm volatile("" : "+v"(x.v.x), "+v"(x.v.y), "+v"(x.v.z), "+v"(x.v.w));
+}
+template <class T, int N>
+__device__ __forceinline__ void pin_all(T (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) pin(x[i]);
+}
+template <class T, int N, int M>
+__device__ __forceinline__ void pin_all(T (&x)[N][M]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) pin(x[i][j]);
+}
+
+__global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
+    int blk = blockIdx.x;
+    int di = 0;
+    while (di + 1 < pp.n && blk >= pp.d[di + 1].first_block) ++di;
+    const PackDesc& d = pp.d[di];
+    int local = blk - d.first_block;
+    int nkb = d.K / 32;
+    int t = local / nkb, kb = local % nkb;
+    int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int row = t * 16 + r, k = kb * 32 + half * 16 + 4 * q + j;
+            v[half * 4 + j] = d.transpose ? d.src[(size_t)k * d.ld + row] : d.src[(size_t)row * d.ld + k];
+        }
+    if (pp.bf16) {
+        uint4 o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        reinterpret_cast<uint4*>(d.dst)[(size_t)local * 64 + lane] = o;
+    } else {
+        float4* pl = reinterpret_cast<float4*>(d.dst) + (size_t)local * 128;
+        pl[lane] = make_float4(v[0], v[1], v[2], v[3]);
+        pl[64 + lane] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+int pack_weights(PackParams& pp, hipStream_t st) {
+    int blocks = 0;
+    for (int i = 0; i < pp.n; ++i) {
+        EGX_CHECK(pp.d[i].R % 16 == 0 && pp.d[i].K % 32 == 0, "pack: matrix %d is %dx%d (needs R%%16==0, K%%32==0)", i, pp.d[i].R, pp.d[i].K);
+        pp.d[i].first_block = blocks;
+        blocks += (pp.d[i].R / 16) * (pp.d[i].K / 32);
+    }
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(64), 0, st, pp);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// two consecutive 16-row C tiles of a feature-major result -> B operand of the next GEMM (K = those 32 rows)
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> chain_frag(const f32x4& t0, const f32x4& t1) {
+    return make_frag<BF16>(make_float4(t0[0], t0[1], t0[2], t0[3]), make_float4(t1[0], t1[1], t1[2], t1[3]));
+}
+
+template <bool BF16>
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<BF16>& a, const Frag<BF16>& b) {
+    if constexpr (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LayerNorm of rows [r0, r1) of a token-major LDS block, one wave per row, lane owns features 2*lane, 2*lane+1.
+// Writes y = LN(x)*w + b (+ add) (+ pos row) back in place and, if gdst != null, to global (row stride FD).
+struct LnRowArgs {
+    const float* w; const float* b; float eps;
+};
+
+// Row-parallel LayerNorm over a token-major LDS block: 4 adjacent lanes own one row (32 features each), so up
+// to 64 rows are normalised in one pass with quad (DPP) reductions. `fn(row, c0, x[32] pre-LN, y[32] post-LN)`
+// consumes the result (global saves, embeddings, dropout, write-back).
+__device__ __forceinline__ float quad_sum4(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+}
+template <class Fn>
+__device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __restrict__ w, const float* __restrict__ b,
+                                        float eps, Fn&& fn) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    if (row < S) {
+        const int c0 = part * 32;
+        float x[32], y[32];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(buf + row * LDX + c0 + 4 * j);
+            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        float mean = quad_sum4(s) * (1.f / FD);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { float t = x[j] - mean; ss += t * t; }
+        float rstd = rsqrtf(quad_sum4(ss) * (1.f / FD) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 wv = *reinterpret_cast<const float4*>(w + c0 + 4 * j);
+            float4 bv = *reinterpret_cast<const float4*>(b + c0 + 4 * j);
+            y[4 * j + 0] = (x[4 * j + 0] - mean) * rstd * wv.x + bv.x;
+            y[4 * j + 1] = (x[4 * j + 1] - mean) * rstd * wv.y + bv.y;
+            y[4 * j + 2] = (x[4 * j + 2] - mean) * rstd * wv.z + bv.z;
+            y[4 * j + 3] = (x[4 * j + 3] - mean) * rstd * wv.w + bv.w;
+        }
+        fn(row, c0, x, y);
+    } else {
+        // keep the quad shuffles convergent for partially filled waves
+        (void)quad_sum4(0.f);
+        (void)quad_sum4(0.f);
+    }
+}
+__device__ __forceinline__ void store32(float* dst, const float (&v)[32]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+// Development aid: phase timestamps of workgroup 0 / wave 0 (s_memtime), read back by egx_debug_stamps().
+__device__ unsigned long long g_stamps[32];
+#ifdef EGX_STAMPS
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+int debug_read_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 32 ? 32 : n)) == hipSuccess ? 0 : 1;
+}
+
+// ---- forward kernel -------------------------------------------------------------------------------
+template <bool BF16, int NT>
+__global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SP = NT * 16;                 // padded token count
+    float* Xs = lds;                            // [SP][LDX] layer input (later: FFN partial 0)
+    float* Qs = Xs + SP * LDX;                  // [SP][LDX] Q, later attention output O
+    float* Ks = Qs + SP * LDX;                  // [SP][LDX]
+    float* Vt = Ks + SP * LDX;                  // [FD][LDV] V^T, keys >= S zero
+    float* X1 = Vt + FD * LDV;                  // [SP][LDX] res1 / x1
+    float* Part = Qs;                           // FFN partials 1..3 alias Q/K/Vt (needs 3*SP*LDX <= 2*SP*LDX + FD*LDV)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int clip = blockIdx.x;
+    const int S = p.S;
+
+    STAMP(0);
+    // zero the padded rows once so that padded tokens stay finite everywhere
+    for (int i = tid; i < SP * LDX; i += 256) { Xs[i] = 0.f; X1[i] = 0.f; }
+    __syncthreads();
+
+    // ---- token preparation: proj GEMM (feature-major) -> LDS token-major -> LN + task embedding + position.
+    // Steps = (segment, 16-row tile, 128-wide K chunk); the loads of step i+1 are issued before the MFMAs of step i.
+    {
+        struct Step { int sgi, t0, k0; };
+        auto valid = [&](const Step& s) { return s.sgi < p.nseg; };
+        auto advance = [&](Step s) {
+            s.k0 += 128;
+            if (s.k0 >= p.seg[s.sgi].d_in) { s.k0 = 0; s.t0 += 16; if (s.t0 >= p.seg[s.sgi].T) { s.t0 = 0; ++s.sgi; } }
+            return s;
+        };
+        auto issue = [&](const Step& s, Raw (&rb)[4], WRaw<BF16> (&ra0)[4], WRaw<BF16> (&ra1)[4]) {
+            const FusedSeg& sg = p.seg[s.sgi];
+            int trow = s.t0 + r;
+            bool tv = trow < sg.T;
+            const float* frow = sg.feat + ((size_t)clip * sg.T + (tv ? trow : 0)) * sg.d_in;
+            const int nkb = sg.d_in / 32;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int k = s.k0 + 32 * j;       // d_in % 128 == 0; rows >= T read row 0 and are discarded at the store
+                rb[j] = load_raw(frow + k, q);
+                ra0[j] = load_w<BF16>(sg.proj_wp, wave * 2 + 0, nkb, k / 32, lane);
+                ra1[j] = load_w<BF16>(sg.proj_wp, wave * 2 + 1, nkb, k / 32, lane);
+            }
+        };
+        f32x4 acc[2];
+        auto compute = [&](const Step& s, Raw (&rb)[4], WRaw<BF16> (&ra0)[4], WRaw<BF16> (&ra1)[4]) {
+            const FusedSeg& sg = p.seg[s.sgi];
+            pin_all(rb); pin_all(ra0); pin_all(ra1);
+            if (s.k0 == 0) { acc[0] = f32x4{0, 0, 0, 0}; acc[1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Frag<BF16> b = to_frag<BF16>(rb[j]);
+                mma<BF16>(acc[0], w_frag<BF16>(ra0[j]), b);
+                mma<BF16>(acc[1], w_frag<BF16>(ra1[j]), b);
+            }
+            if (s.k0 + 128 >= sg.d_in) {
+                int trow = s.t0 + r;
+                if (trow < sg.T) {
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) {
+                        int f0 = (wave * 2 + ft) * 16 + 4 * q;
+                        float4 bb = *reinterpret_cast<const float4*>(sg.proj_b + f0);
+                        float4 o = make_float4(acc[ft][0] + bb.x, acc[ft][1] + bb.y, acc[ft][2] + bb.z, acc[ft][3] + bb.w);
+                        *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0) = o;
+                    }
+                }
+            }
+        };
+        Raw rbA[4], rbB[4];
+        WRaw<BF16> ra0A[4], ra1A[4], ra0B[4], ra1B[4];
+        Step cur{0, 0, 0};
+        issue(cur, rbA, ra0A, ra1A);
+        while (valid(cur)) {
+            Step nx = advance(cur);
+            if (valid(nx)) issue(nx, rbB, ra0B, ra1B);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur, rbA, ra0A, ra1A);
+            cur = nx;
+            if (!valid(cur)) break;
+            nx = advance(cur);
+            if (valid(nx)) issue(nx, rbA, ra0A, ra1A);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur, rbB, ra0B, ra1B);
+            cur = nx;
+        }
+    }
+    __syncthreads();
+    STAMP(1);
+    // save pre-LN projections (token order) and apply the shared LN + embeddings
+    ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+        int sgi = 0;
+        while (sgi + 1 < p.nseg && row >= p.seg[sgi + 1].off) ++sgi;
+        const FusedSeg& sg = p.seg[sgi];
+        int t = row - sg.off;
+        store32(p.saved_pre + ((size_t)clip * S + row) * FD + c0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (sg.add_vec) {
+                float4 a = *reinterpret_cast<const float4*>(sg.add_vec + c0 + 4 * j);
+                y[4 * j] += a.x; y[4 * j + 1] += a.y; y[4 * j + 2] += a.z; y[4 * j + 3] += a.w;
+            }
+            if (sg.pos) {
+                float4 a = *reinterpret_cast<const float4*>(sg.pos + (size_t)t * sg.pos_stride + c0 + 4 * j);
+                y[4 * j] += a.x; y[4 * j + 1] += a.y; y[4 * j + 2] += a.z; y[4 * j + 3] += a.w;
+            }
+        }
+        if (p.pos_thresh) {
+            uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) y[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+        }
+        store32(Xs + row * LDX + c0, y);
+    });
+    __syncthreads();
+
+    for (int l = 0; l < p.n_layers; ++l) {
+        const FusedLayer& w = p.layer[l];
+        float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
+        float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
+
+        STAMP(2);
+        // ---- QKV projection: 24 feature tiles, 6 per wave, K = 128
+        {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 acc[3][NT];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+                WRaw<BF16> wa[3][FD / 32];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int kb = 0; kb < FD / 32; ++kb)
+                        wa[i][kb] = load_w<BF16>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(wa);
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb) {
+                    Frag<BF16> b[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(Xs + (t * 16 + r) * LDX + kb * 32, q);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        Frag<BF16> a = w_frag<BF16>(wa[i][kb]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    int f0 = (wave * 6 + half * 3 + i) * 16 + 4 * q;      // 0..383
+                    float4 bb = *reinterpret_cast<const float4*>(w.in_proj_b + f0);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        int tok = t * 16 + r;
+                        float4 o = make_float4(acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w);
+                        if (f0 < FD) {
+                            *reinterpret_cast<float4*>(Qs + tok * LDX + f0) = o;
+                        } else if (f0 < 2 * FD) {
+                            *reinterpret_cast<float4*>(Ks + tok * LDX + (f0 - FD)) = o;
+                        } else {
+                            int c = f0 - 2 * FD;
+                            bool kv = tok < S;
+                            Vt[(c + 0) * LDV + tok] = kv ? o.x : 0.f;
+                            Vt[(c + 1) * LDV + tok] = kv ? o.y : 0.f;
+                            Vt[(c + 2) * LDV + tok] = kv ? o.z : 0.f;
+                            Vt[(c + 3) * LDV + tok] = kv ? o.w : 0.f;
+                        }
+                    }
+                }
+            }
+            if (NT < 4) {   // zero the key padding columns SP..63 of V^T
+                for (int i = tid; i < FD * (64 - SP); i += 256) {
+                    int c = i / (64 - SP), k = SP + i % (64 - SP);
+                    Vt[c * LDV + k] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+
+        STAMP(3);
+        // ---- attention: wave = head. S^T = K Q^T (key rows, query columns), softmax over rows, O^T = V^T P^T
+        {
+            const int h = wave;
+            const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+            f32x4 sc[NT][NT];                            // [key tile][query tile]
+            Frag<BF16> kq[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) kq[t] = load_frag<BF16>(Qs + (t * 16 + r) * LDX + h * FDH, q);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) {
+                Frag<BF16> a = load_frag<BF16>(Ks + (kt * 16 + r) * LDX + h * FDH, q);
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    sc[kt][qt] = f32x4{0, 0, 0, 0};
+                    mma<BF16>(sc[kt][qt], a, kq[qt]);
+                }
+            }
+            // softmax over keys for every query column; this lane holds keys kt*16 + 4q + e
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int key = kt * 16 + 4 * q + e;
+                        float s = (key < S) ? sc[kt][qt][e] * scale : -INFINITY;
+                        sc[kt][qt][e] = s;
+                        m = fmaxf(m, s);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pv = __expf(sc[kt][qt][e] - m);
+                        sc[kt][qt][e] = pv;
+                        sum += pv;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                float inv = 1.f / sum;
+                int query = qt * 16 + r;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pv = sc[kt][qt][e] * inv;
+                        if (w.attn_thresh) {
+                            int key = kt * 16 + 4 * q + e;
+                            pv *= drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
+                        }
+                        sc[kt][qt][e] = pv;
+                    }
+            }
+            // O^T[c][query] = sum_key V^T[c][key] P^T[key][query]; keys in K-blocks of 32 = key-tile pairs
+            f32x4 oc[2][NT];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) oc[ct][qt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < (NT + 1) / 2; ++kb) {
+                Frag<BF16> a[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) a[ct] = load_frag<BF16>(Vt + (h * FDH + ct * 16 + r) * LDV + kb * 32, q);
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    f32x4 z = f32x4{0, 0, 0, 0};
+                    Frag<BF16> b = chain_frag<BF16>(sc[2 * kb][qt], (2 * kb + 1 < NT) ? sc[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) mma<BF16>(oc[ct][qt], a[ct], b);
+                }
+            }
+            // write O token-major over this head's Q columns (only this wave reads/writes them)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    int tok = qt * 16 + r;
+                    *reinterpret_cast<float4*>(Qs + tok * LDX + h * FDH + ct * 16 + 4 * q) =
+                        make_float4(oc[ct][qt][0], oc[ct][qt][1], oc[ct][qt][2], oc[ct][qt][3]);
+                }
+        }
+        __syncthreads();
+
+        STAMP(4);
+        // ---- out-projection + residual -> res1 (X1 region), 2 feature tiles per wave
+        {
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+            WRaw<BF16> wo[2][FD / 32];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb)
+                    wo[i][kb] = load_w<BF16>(w.out_proj_wp, wave * 2 + i, FD / 32, kb, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            pin_all(wo);
+#pragma unroll
+            for (int kb = 0; kb < FD / 32; ++kb) {
+                Frag<BF16> b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(Qs + (t * 16 + r) * LDX + kb * 32, q);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Frag<BF16> a = w_frag<BF16>(wo[i][kb]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int f0 = (wave * 2 + i) * 16 + 4 * q;
+                float4 bb = *reinterpret_cast<const float4*>(w.out_proj_b + f0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int tok = t * 16 + r;
+                    if (tok < S) {
+                        float o[4] = {acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w};
+                        float4 xr = *reinterpret_cast<const float4*>(Xs + tok * LDX + f0);
+                        if (w.res_thresh) {
+                            uint32_t orow = (uint32_t)(clip * S + tok);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] *= drop_scale(w.res1_key, orow, (uint32_t)(f0 + e), w.res_thresh, w.drop_inv);
+                        }
+                        *reinterpret_cast<float4*>(X1 + tok * LDX + f0) = make_float4(o[0] + xr.x, o[1] + xr.y, o[2] + xr.z, o[3] + xr.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(5);
+        // ---- LayerNorm1 in place (res1 saved to HBM for the backward)
+        ln_rows(X1, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            store32(sv_res1 + (size_t)row * FD + c0, x);
+            store32(X1 + row * LDX + c0, y);
+        });
+        __syncthreads();
+
+        STAMP(6);
+        // ---- FFN: hidden blocks of 32 split across waves; H^T = relu(W1 x1^T + b1) chained into Y^T += W2 H^T
+        {
+            // x1 as B operand: resident in registers for bf16 (48 VGPRs); re-read from LDS per hidden block in fp32,
+            // where one block's MFMAs take 12k cycles and the 24 ds_read_b128 are free
+            constexpr bool XRES = BF16;
+            constexpr int XR = XRES ? FD / 32 : 1;
+            Frag<BF16> xb[XR][NT];
+            if constexpr (XRES) {
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xb[kb][t] = load_frag<BF16>(X1 + (t * 16 + r) * LDX + kb * 32, q);
+            }
+            f32x4 y[8][NT];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) y[i][t] = f32x4{0, 0, 0, 0};
+            const int nhb = p.d_ff / 32;
+            WRaw<BF16> w1r[2][FD / 32];   // W1 rows of the current hidden block (prefetched one phase ahead)
+            WRaw<BF16> w2r[8];            // W2 columns of the current hidden block
+            float4 b1r[2];
+            auto issue_w1 = [&](int hb) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int kb = 0; kb < FD / 32; ++kb)
+                        w1r[i][kb] = load_w<BF16>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
+                    b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb * 32 + i * 16 + 4 * q);
+                }
+            };
+            auto issue_w2 = [&](int hb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w2r[i] = load_w<BF16>(w.lin2_wp, i, nhb, hb, lane);
+            };
+            // Every CU walks the same weights: rotate the starting hidden block per clip so that the CUs of an XCD
+            // spread their L2 requests over all channels instead of hammering the same few lines in lockstep.
+            const int nit = nhb / 4;
+            const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
+            issue_w1(hb_of(0));
+            for (int it = 0; it < nit; ++it) {
+                const int hb = hb_of(it);
+                issue_w2(hb);                       // in flight while GEMM1 runs
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(w1r);
+                f32x4 hacc[2][NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) hacc[i][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb) {
+                    if constexpr (!XRES) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) xb[0][t] = load_frag<BF16>(X1 + (t * 16 + r) * LDX + kb * 32, q);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Frag<BF16> a = w_frag<BF16>(w1r[i][kb]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) mma<BF16>(hacc[i][t], a, xb[XRES ? kb : 0][t]);
+                    }
+                }
+                float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nit) issue_w1(hb_of(it + 1));  // in flight while GEMM2 runs
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(w2r);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hacc[i][t][e] = fmaxf(hacc[i][t][e] + bv[i][e], 0.f);
+                if (w.ffn_thresh) {     // one wave-uniform branch per hidden block
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        int h0 = hb * 32 + i * 16 + 4 * q;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                hacc[i][t][e] *= drop_scale(w.ffn_key, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
+                    }
+                }
+                Frag<BF16> hbq[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<BF16>(hacc[0][t], hacc[1][t]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    Frag<BF16> a = w_frag<BF16>(w2r[i]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mma<BF16>(y[i][t], a, hbq[t]);
+                }
+            }
+            STAMP(7);
+            // cross-wave reduction through LDS: wave 0 -> Xs region, waves 1..3 -> Part (aliases Q/K/V^T, now dead)
+            float* mine = (wave == 0) ? Xs : Part + (wave - 1) * SP * LDX;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<float4*>(mine + (t * 16 + r) * LDX + i * 16 + 4 * q) =
+                        make_float4(y[i][t][0], y[i][t][1], y[i][t][2], y[i][t][3]);
+        }
+        __syncthreads();
+        STAMP(8);
+        // ---- sum partials + bias + residual -> res2 (in X1), then LayerNorm2 -> next layer input / tokens_out
+        {
+            const int row = tid >> 2, c0 = (tid & 3) * 32;
+            if (row < S) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int o = row * LDX + c0 + 4 * j;
+                    float4 a0 = *reinterpret_cast<const float4*>(Xs + o);
+                    float4 a1 = *reinterpret_cast<const float4*>(Part + o);
+                    float4 a2 = *reinterpret_cast<const float4*>(Part + SP * LDX + o);
+                    float4 a3 = *reinterpret_cast<const float4*>(Part + 2 * SP * LDX + o);
+                    float4 x1 = *reinterpret_cast<const float4*>(X1 + o);
+                    float4 b2 = *reinterpret_cast<const float4*>(w.lin2_b + c0 + 4 * j);
+                    float f[4] = {a0.x + a1.x + a2.x + a3.x + b2.x, a0.y + a1.y + a2.y + a3.y + b2.y,
+                                  a0.z + a1.z + a2.z + a3.z + b2.z, a0.w + a1.w + a2.w + a3.w + b2.w};
+                    if (w.res_thresh) {
+                        uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] *= drop_scale(w.res2_key, orow, (uint32_t)(c0 + 4 * j + e), w.res_thresh, w.drop_inv);
+                    }
+                    *reinterpret_cast<float4*>(X1 + o) = make_float4(f[0] + x1.x, f[1] + x1.y, f[2] + x1.z, f[3] + x1.w);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            bool last = (l + 1 == p.n_layers);
+            ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+                store32(sv_res2 + (size_t)row * FD + c0, x);
+                if (last) store32(p.tokens_out + ((size_t)clip * S + row) * FD + c0, y);
+                else store32(Xs + row * LDX + c0, y);
+            });
+        }
+        __syncthreads();
+        STAMP(9);
+        if (l + 1 < p.n_layers) {
+            for (int i = tid; i < (SP - S) * LDX; i += 256) Xs[S * LDX + i] = 0.f;
+            __syncthreads();
+        }
+    }
+}
+
+size_t fused_lds_bytes(int NT) {
+    int SP = NT * 16;
+    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float);
+}
+
+bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {
+    if (d_model != FD || n_heads != FH) return false;
+    if (d_ff % 128 != 0 || d_ff < 128) return false;
+    if (S < 1 || S > 48) return false;   // NT = 4 would need 170 KB of LDS
+    for (int i = 0; i < nseg; ++i) {
+        if (!has_proj[i]) return false;
+        if (d_in[i] % 128 != 0) return false;
+        if (T[i] < 1) return false;
+    }
+    return true;
+}
+
+template <bool BF16>
+static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
+    // NT = 2 (S <= 32) is not instantiated: shorter sequences run the 48-row kernel with masked padding.
+    int NT = p.S <= 48 ? 3 : cdiv(p.S, 16);
+    size_t lds = fused_lds_bytes(NT);
+    dim3 grid(p.B), block(256);
+#define EGX_FWD_CASE(N)                                                                                          \
+    case N: {                                                                                                    \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<BF16, N>),               \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((fused_fwd_kernel<BF16, N>), grid, block, lds, st, p);                                \
+    } break;
+    switch (NT) {
+        EGX_FWD_CASE(3)
+        default: EGX_CHECK(false, "fused: S=%d unsupported", p.S);
+    }
+#undef EGX_FWD_CASE
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {
+    return compute == 1 ? launch_fwd<true>(p, st) : launch_fwd<false>(p, st);
+}
+
+}  // namespace egx

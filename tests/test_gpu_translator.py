@@ -68,3 +68,24 @@ def test_cpu_tensor_raises(egx_lib, cuda):
     feats = seeded_feats(3, [(2, 15, 256)] * 3)
     with pytest.raises(_lib.EgxError):
         model.forward_features(*feats)
+
+
+@pytest.mark.parametrize("compute,tol", [("f32", 1e-3), ("bf16", 1e-2)])
+@pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 16, 2), (3, 3, 7, 1), (3, 256, 15, 1)])
+def test_fused_forward_vs_oracle(egx_lib, cuda, compute, tol, n_tasks, B, T, L):
+    """Fused per-clip forward kernel (impl='fused'), eval mode, against the fp64 oracle and the generic path."""
+    from egot2_amd import hhi_ttm
+    cls = hhi_ttm.TaskFusionMFTransformer3Task if n_tasks == 3 else hhi_ttm.TaskFusionMFTransformer2Task
+    model = cls(hhi_args(num_layers=L))
+    sd = seeded_state_dict(model, seed=300 + n_tasks + B + T)
+    model.load_state_dict(sd)
+    model = model.to(cuda).eval()
+    feats = seeded_feats(17 + B, [(B, T, 256)] * n_tasks)
+    fd = [f.to(cuda) for f in feats]
+    with torch.no_grad():
+        fused = model.set_compute(compute, "fused").forward_features(*fd)
+        generic = model.set_compute(compute, "generic").forward_features(*fd)
+    ref = tr.ttm_forward(tr.to_dtype(sd, torch.float64), 4, *[f.double() for f in feats])
+    assert torch.isfinite(fused).all()
+    assert max_err(fused, ref) < tol, f"fused vs oracle {max_err(fused, ref)}"
+    assert max_err(fused, generic) < tol

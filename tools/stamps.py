@@ -1,0 +1,22 @@
+"""Phase breakdown of the fused forward kernel (needs a build with EGX_CXXFLAGS=-DEGX_STAMPS)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from egot2_amd import hhi_ttm, _lib
+from tests.util import hhi_args
+lib = _lib.load()
+dev = torch.device("cuda:0")
+m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args()).to(dev).eval()
+feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]
+names = ["zero", "proj", "ln0", "qkv", "attn", "outproj", "ln1", "ffn", "part-store", "ln2"]
+for comp in ("f32", "bf16"):
+    m.set_compute(comp, "fused")
+    with torch.no_grad():
+        for _ in range(3):
+            m.forward_features(*feats)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.egx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.egx_debug_stamps(buf, 32)
+    t = list(buf)[:10]
+    print(comp, "total ticks", t[9] - t[0], " ".join(f"{n}={t[i + 1] - t[i]}" for i, n in enumerate(names[:9])))
