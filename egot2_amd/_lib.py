@@ -68,6 +68,10 @@ SIGNATURES = {
     "egx_layernorm_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_debug_stamps": (C.c_int, [_fp, C.c_int]),
+    "egx_ffn_dw_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "egx_ffn_dw": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp, _fp, _fp,
+                             C.c_int, _fp, _fp]),
     "egx_attention_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_uint64, _fp]),
 }

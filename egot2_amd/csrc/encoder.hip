@@ -113,16 +113,65 @@ static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan&
     return fused_supported(pl.d, pl.H, pl.dff, pl.S, pl.nseg, d_in, T, hp);
 }
 static size_t fused_act_bytes(const Plan& pl) { return align_up((size_t)(1 + 2 * pl.L) * pl.N * pl.d * 4, 256); }
-static size_t fused_pack_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    size_t b = 0;
+// Fragment-packed weight copies kept behind the saved activations (written by the forward, reused by the
+// backward): per segment the projection, per layer each matrix in both orientations.
+struct FusedPackLayout {
+    void* proj[EGX_MAX_SEGMENTS];
+    struct { void* in_w; void* in_wt; void* out_w; void* out_wt; void* lin1_w; void* lin1_wt; void* lin2_w; void* lin2_wt; } layer[FUSED_MAX_LAYERS];
+    size_t bytes;
+};
+static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segment* segs, const Plan& pl, char* base) {
+    FusedPackLayout L;
+    memset(&L, 0, sizeof(L));
     int bf = cfg->compute == EGX_BF16;
-    for (int i = 0; i < pl.nseg; ++i) b += align_up(packed_bytes(pl.d, segs[i].d_in, bf), 256);
-    b += (size_t)pl.L * (align_up(packed_bytes(3 * pl.d, pl.d, bf), 256) + align_up(packed_bytes(pl.d, pl.d, bf), 256) +
-                         2 * align_up(packed_bytes(pl.dff, pl.d, bf), 256));
-    return b;
+    size_t cur = 0;
+    auto take_p = [&](int R, int K) -> void* { void* q = base ? base + cur : nullptr; cur += align_up(packed_bytes(R, K, bf), 256); return q; };
+    for (int i = 0; i < pl.nseg; ++i) L.proj[i] = take_p(pl.d, segs[i].d_in);
+    for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
+        L.layer[l].in_w = take_p(3 * pl.d, pl.d);
+        L.layer[l].in_wt = take_p(pl.d, 3 * pl.d);
+        L.layer[l].out_w = take_p(pl.d, pl.d);
+        L.layer[l].out_wt = take_p(pl.d, pl.d);
+        L.layer[l].lin1_w = take_p(pl.dff, pl.d);
+        L.layer[l].lin1_wt = take_p(pl.d, pl.dff);
+        L.layer[l].lin2_w = take_p(pl.d, pl.dff);
+        L.layer[l].lin2_wt = take_p(pl.dff, pl.d);
+    }
+    L.bytes = cur;
+    return L;
 }
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_act_bytes(pl) + fused_pack_bytes(cfg, segs, pl);
+    return fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes;
+}
+
+// scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
+// partial sums, and the slab area shared by ffn_dw and the split-K GEMMs.
+struct FusedBwdScratch {
+    size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], x_in[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
+    size_t dseg[EGX_MAX_SEGMENTS];
+    size_t partials, slabs, slab_bytes, bytes;
+    int P;
+};
+static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl) {
+    FusedBwdScratch s;
+    memset(&s, 0, sizeof(s));
+    size_t cur = 0;
+    size_t nd = pl.N * pl.d * 4;
+    for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
+        s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd); s.attn_o[l] = take(cur, nd);
+        s.g1[l] = take(cur, nd); s.x_in[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
+    }
+    for (int i = 0; i < pl.nseg; ++i) s.dseg[i] = take(cur, (size_t)pl.B * segs[i].T * pl.d * 4);
+    s.P = fused_partial_len(pl.L, pl.nseg);
+    s.partials = take(cur, (size_t)pl.B * s.P * 4);
+    size_t slab = ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr);
+    slab = max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
+    slab = max(slab, gemm_scratch_bytes(2, pl.d, pl.d, (int)pl.N));
+    for (int i = 0; i < pl.nseg; ++i) slab = max(slab, gemm_scratch_bytes(2, pl.d, segs[i].d_in, pl.B * segs[i].T));
+    s.slab_bytes = slab;
+    s.slabs = take(cur, slab);
+    s.bytes = cur;
+    return s;
 }
 
 static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan& pl, bool* err) {
@@ -132,7 +181,7 @@ static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan
         if (!ok) { set_error("fused implementation does not support this configuration (needs d=128, h=4, S<=48, d_ff%%128==0, projected segments, <=4 layers)"); *err = true; }
         return ok;
     }
-    return false;   // EGX_IMPL_AUTO keeps the generic path until the fused backward lands
+    return cfg->impl == EGX_IMPL_AUTO && ok;   // auto: fused per-clip kernels whenever the shape allows
 }
 
 static inline float* fptr(void* base, size_t off) { return (float*)((char*)base + off); }
@@ -196,13 +245,41 @@ extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 int egx_debug_stamps(unsigned long long* out, int n) { return debug_read_stamps(out, n); }
+
+// Unit-test hook for the fused FFN weight-gradient kernel. scratch: packed W1 + packed W2^T + slabs.
+size_t egx_ffn_dw_scratch(int N, int d_ff, int compute) {
+    int bf = compute == EGX_BF16;
+    return 2 * align_up(packed_bytes(d_ff, 128, bf), 256) + ffn_dw_scratch_bytes(N, d_ff, nullptr);
+}
+int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1, const float* W2, int N, int S, int d_ff,
+               float p_drop, uint64_t seed, float* dW1, float* db1, float* dW2, int compute, void* scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int bf = compute == EGX_BF16;
+    PackParams pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.bf16 = bf;
+    char* cur = (char*)scratch;
+    pk.d[0].src = W1; pk.d[0].dst = cur; pk.d[0].R = d_ff; pk.d[0].K = 128; pk.d[0].ld = 128; pk.d[0].transpose = 0;
+    cur += align_up(packed_bytes(d_ff, 128, bf), 256);
+    pk.d[1].src = W2; pk.d[1].dst = cur; pk.d[1].R = d_ff; pk.d[1].K = 128; pk.d[1].ld = d_ff; pk.d[1].transpose = 1;
+    cur += align_up(packed_bytes(d_ff, 128, bf), 256);
+    pk.n = 2;
+    if (pack_weights(pk, st)) return 1;
+    FfnDwParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.x1 = x1; fp.g = g; fp.w1p = pk.d[0].dst; fp.w2tp = pk.d[1].dst; fp.b1 = b1;
+    fp.N = N; fp.S = S; fp.d_ff = d_ff;
+    Drop dh = make_drop(p_drop > 0.f, p_drop, seed, 0, SITE_FFN);
+    fp.drop_key = dh.key; fp.drop_thresh = dh.thresh; fp.drop_inv = dh.inv_keep;
+    return ffn_dw(fp, compute, dW1, db1, dW2, cur, st);
+}
 const char* egx_last_error(void) { return g_err; }
 
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
     if (saved_bytes) *saved_bytes = max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = pl.scratch_bytes;
+    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(segs, pl).bytes : (size_t)0);
     return 0;
 }
 
@@ -225,26 +302,31 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
         PackParams pk;
         memset(&pk, 0, sizeof(pk));
         pk.bf16 = comp == EGX_BF16;
-        char* pcur = (char*)saved + fused_act_bytes(pl);
-        auto add_pack = [&](const float* src, int R, int K) -> const void* {
+        FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
+        auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose) -> const void* {
             PackDesc& dsc = pk.d[pk.n++];
-            dsc.src = src; dsc.dst = pcur; dsc.R = R; dsc.K = K; dsc.ld = K; dsc.transpose = 0;
-            pcur += align_up(packed_bytes(R, K, pk.bf16), 256);
-            return dsc.dst;
+            dsc.src = src; dsc.dst = dst; dsc.R = R; dsc.K = K; dsc.ld = ld; dsc.transpose = transpose;
+            return dst;
         };
         for (int i = 0; i < pl.nseg; ++i) {
             FusedSeg& fs = fp.seg[i];
-            fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, d, segs[i].d_in); fs.proj_b = segs[i].proj_b;
+            fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, PL.proj[i], d, segs[i].d_in, segs[i].d_in, 0); fs.proj_b = segs[i].proj_b;
             fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos;
             fs.T = segs[i].T; fs.d_in = segs[i].d_in; fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
         }
         for (int l = 0; l < pl.L; ++l) {
             FusedLayer& fl = fp.layer[l];
             const egx_layer& w = layers[l];
-            fl.in_proj_wp = add_pack(w.in_proj_w, 3 * d, d); fl.in_proj_b = w.in_proj_b;
-            fl.out_proj_wp = add_pack(w.out_proj_w, d, d); fl.out_proj_b = w.out_proj_b;
-            fl.lin1_wp = add_pack(w.lin1_w, pl.dff, d); fl.lin1_b = w.lin1_b;
-            fl.lin2_wp = add_pack(w.lin2_w, d, pl.dff); fl.lin2_b = w.lin2_b;
+            fl.in_proj_wp = add_pack(w.in_proj_w, PL.layer[l].in_w, 3 * d, d, d, 0); fl.in_proj_b = w.in_proj_b;
+            fl.out_proj_wp = add_pack(w.out_proj_w, PL.layer[l].out_w, d, d, d, 0); fl.out_proj_b = w.out_proj_b;
+            fl.lin1_wp = add_pack(w.lin1_w, PL.layer[l].lin1_w, pl.dff, d, d, 0); fl.lin1_b = w.lin1_b;
+            fl.lin2_wp = add_pack(w.lin2_w, PL.layer[l].lin2_w, d, pl.dff, pl.dff, 0); fl.lin2_b = w.lin2_b;
+            {   // transposed copies for the backward kernels
+                add_pack(w.in_proj_w, PL.layer[l].in_wt, d, 3 * d, d, 1);
+                add_pack(w.out_proj_w, PL.layer[l].out_wt, d, d, d, 1);
+                add_pack(w.lin1_w, PL.layer[l].lin1_wt, d, pl.dff, d, 1);
+                add_pack(w.lin2_w, PL.layer[l].lin2_wt, pl.dff, d, pl.dff, 1);
+            }
             fl.norm1_w = w.norm1_w; fl.norm1_b = w.norm1_b; fl.norm2_w = w.norm2_w; fl.norm2_b = w.norm2_b;
             Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
             fl.attn_key = da.key; fl.attn_thresh = da.thresh; fl.drop_inv = da.inv_keep;
@@ -322,8 +404,94 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
     (void)ln_b;
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    EGX_CHECK(cfg->impl != EGX_IMPL_FUSED, "fused backward not available yet");
     EGX_CHECK(d_tokens && saved && scratch && ln_w, "null pointer argument");
+    {
+        bool ferr;
+        if (use_fused(cfg, segs, pl, &ferr)) {
+            hipStream_t st = (hipStream_t)stream;
+            const int d = pl.d, S = pl.S, comp = cfg->compute;
+            const int N = (int)pl.N;
+            FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
+            FusedBwdScratch SC = fused_bwd_scratch(segs, pl);
+            FusedBwdParams bp;
+            memset(&bp, 0, sizeof(bp));
+            for (int i = 0; i < pl.nseg; ++i) {
+                FusedSeg& fs = bp.seg[i];
+                fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos; fs.T = segs[i].T; fs.d_in = segs[i].d_in;
+                fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
+                bp.dseg_out[i] = fptr(scratch, SC.dseg[i]);
+            }
+            for (int l = 0; l < pl.L; ++l) {
+                FusedBwdLayer& fl = bp.layer[l];
+                const egx_layer& w = layers[l];
+                fl.in_proj_wp = PL.layer[l].in_w; fl.in_proj_wtp = PL.layer[l].in_wt; fl.out_proj_wtp = PL.layer[l].out_wt;
+                fl.lin1_wp = PL.layer[l].lin1_w; fl.lin2_wtp = PL.layer[l].lin2_wt; fl.lin1_wtp = PL.layer[l].lin1_wt;
+                fl.in_proj_b = w.in_proj_b; fl.lin1_b = w.lin1_b;
+                fl.norm1_w = w.norm1_w; fl.norm1_b = w.norm1_b; fl.norm2_w = w.norm2_w; fl.norm2_b = w.norm2_b;
+                Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
+                fl.attn_key = da.key; fl.attn_thresh = da.thresh; fl.drop_inv = da.inv_keep;
+                fl.res_thresh = da.thresh; fl.ffn_thresh = da.thresh;
+                fl.res1_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES1).key;
+                fl.ffn_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN).key;
+                fl.res2_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2).key;
+                fl.x1_out = fptr(scratch, SC.x1[l]); fl.g2_out = fptr(scratch, SC.g2[l]); fl.attn_o_out = fptr(scratch, SC.attn_o[l]);
+                fl.g1_out = fptr(scratch, SC.g1[l]); fl.x_in_out = fptr(scratch, SC.x_in[l]); fl.dqkv_out = fptr(scratch, SC.dqkv[l]);
+            }
+            bp.ln_w = ln_w; bp.ln_b = ln_b; bp.eps = cfg->ln_eps;
+            bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = B; bp.S = S; bp.d_ff = pl.dff;
+            bp.d_tokens = d_tokens;
+            bp.saved_pre = (const float*)saved;
+            bp.saved_res = (const float*)saved + (size_t)N * d;
+            bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
+            Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
+            bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
+            if (fused_backward(bp, comp, st)) return 1;
+
+            // small parameter gradients: sum the per-clip partials
+            ReducePartialsParams rp;
+            memset(&rp, 0, sizeof(rp));
+            rp.B = B; rp.P = SC.P; rp.partials = bp.partials;
+            auto add_dst = [&](float* dst, int off, int len) { if (dst) { rp.d[rp.n].dst = dst; rp.d[rp.n].off = off; rp.d[rp.n].len = len; ++rp.n; } };
+            for (int l = 0; l < pl.L; ++l) {
+                const egx_layer_grads& gw = layer_grads[l];
+                int o = l * FUSED_P_LAYER;
+                add_dst(gw.norm2_w, o + 0, 128); add_dst(gw.norm2_b, o + 128, 128); add_dst(gw.lin2_b, o + 256, 128);
+                add_dst(gw.norm1_w, o + 384, 128); add_dst(gw.norm1_b, o + 512, 128); add_dst(gw.out_proj_b, o + 640, 128);
+                add_dst(gw.in_proj_b, o + 768, 384);
+            }
+            int og = pl.L * FUSED_P_LAYER;
+            add_dst(d_ln_w, og, 128); add_dst(d_ln_b, og + 128, 128);
+            for (int i = 0; i < pl.nseg; ++i) {
+                if (!seg_grads) break;
+                EGX_CHECK(!seg_grads[i].pos && !seg_grads[i].feat, "fused backward: positional / feature gradients are not supported (use impl=generic)");
+                add_dst(seg_grads[i].add_vec, og + 256 + i * 256, 128);
+                add_dst(seg_grads[i].proj_b, og + 256 + i * 256 + 128, 128);
+            }
+            if (reduce_partials(rp, st)) return 1;
+
+            void* slab = (char*)scratch + SC.slabs;
+            for (int l = 0; l < pl.L; ++l) {
+                const egx_layer& w = layers[l];
+                const egx_layer_grads& gw = layer_grads[l];
+                if (gw.lin1_w || gw.lin1_b || gw.lin2_w) {
+                    FfnDwParams fp;
+                    memset(&fp, 0, sizeof(fp));
+                    fp.x1 = bp.layer[l].x1_out; fp.g = bp.layer[l].g2_out;
+                    fp.w1p = PL.layer[l].lin1_w; fp.w2tp = PL.layer[l].lin2_wt; fp.b1 = w.lin1_b;
+                    fp.N = N; fp.S = S; fp.d_ff = pl.dff;
+                    fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
+                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st)) return 1;
+                }
+                if (gw.out_proj_w && linear_dw(bp.layer[l].g1_out, bp.layer[l].attn_o_out, gw.out_proj_w, N, d, d, comp, slab, SC.slab_bytes, st)) return 1;
+                if (gw.in_proj_w && linear_dw(bp.layer[l].dqkv_out, bp.layer[l].x_in_out, gw.in_proj_w, N, 3 * d, d, comp, slab, SC.slab_bytes, st)) return 1;
+            }
+            for (int i = 0; i < pl.nseg; ++i)
+                if (seg_grads && seg_grads[i].proj_w &&
+                    linear_dw(bp.dseg_out[i], segs[i].feat, seg_grads[i].proj_w, B * segs[i].T, d, segs[i].d_in, comp, slab, SC.slab_bytes, st)) return 1;
+            return 0;
+        }
+        if (ferr) return 1;
+    }
     EGX_CHECK(pl.L == 0 || (layers && layer_grads), "null layers / layer_grads");
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;

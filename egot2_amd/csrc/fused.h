@@ -53,6 +53,66 @@ struct PackParams {
 int pack_weights(PackParams& pp, hipStream_t st);
 static inline size_t packed_bytes(int R, int K, int bf16) { return (size_t)R * K * (bf16 ? 2 : 4); }
 
+struct FfnDwParams {
+    const float* x1;      // [N][128] FFN input (post-LN1)
+    const float* g;       // [N][128] gradient w.r.t. the FFN output (dropout2 mask already applied)
+    const void* w1p;      // packed W1   (R = d_ff, K = 128)
+    const void* w2tp;     // packed W2^T (R = d_ff, K = 128)
+    const float* b1;
+    int N, S, d_ff;
+    uint64_t drop_key; uint32_t drop_thresh; float drop_inv;   // FFN hidden dropout (same keying as the forward)
+    float* slab_w1; float* slab_w2t; float* slab_b1;           // set by ffn_dw()
+    int splits, kb_per_split;
+};
+size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
+int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st);
+
+struct FusedBwdLayer {
+    const void* in_proj_wp;    // packed W_in   (R = 384, K = 128): QKV recompute
+    const void* in_proj_wtp;   // packed W_in^T (R = 128, K = 384): input gradient
+    const void* out_proj_wtp;  // packed W_o^T  (R = 128, K = 128)
+    const void* lin1_wp;       // packed W1     (R = d_ff, K = 128): H recompute
+    const void* lin2_wtp;      // packed W2^T   (R = d_ff, K = 128): dH
+    const void* lin1_wtp;      // packed W1^T   (R = 128, K = d_ff): d x1
+    const float* in_proj_b; const float* lin1_b;
+    const float* norm1_w; const float* norm1_b; const float* norm2_w; const float* norm2_b;
+    uint64_t attn_key, res1_key, ffn_key, res2_key;
+    uint32_t attn_thresh, res_thresh, ffn_thresh;
+    float drop_inv;
+    // per-token tensors handed to the weight-gradient kernels, all (B*S, .) token-major fp32
+    float* x1_out; float* g2_out; float* attn_o_out; float* g1_out; float* x_in_out; float* dqkv_out;
+};
+
+// Per-clip partial sums of the small parameter gradients, laid out as `partials[clip][P]`:
+//   layer l at l * 1152: norm2_w, norm2_b, lin2_b, norm1_w, norm1_b, out_proj_b (128 each), in_proj_b (384)
+//   then ln_w, ln_b (128 each), then per segment: add_vec, proj_b (128 each)
+constexpr int FUSED_P_LAYER = 1152;
+static inline int fused_partial_len(int L, int nseg) { return L * FUSED_P_LAYER + 256 + nseg * 256; }
+
+struct FusedBwdParams {
+    FusedSeg seg[FUSED_MAX_SEG];
+    float* dseg_out[FUSED_MAX_SEG];   // (B, T_k, 128) gradient w.r.t. the projected (pre-LN) features of segment k
+    FusedBwdLayer layer[FUSED_MAX_LAYERS];
+    const float* ln_w; const float* ln_b;
+    float eps;
+    int nseg, n_layers, B, S, d_ff;
+    const float* d_tokens;     // (B, S, 128)
+    const float* saved_pre;    // from the forward
+    const float* saved_res;
+    float* partials; int P;
+    uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
+};
+int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
+
+struct PartialDst { float* dst; int off, len; };
+constexpr int PARTIAL_MAX_DST = 48;
+struct ReducePartialsParams {
+    PartialDst d[PARTIAL_MAX_DST];
+    int n, B, P;
+    const float* partials;
+};
+int reduce_partials(const ReducePartialsParams& rp, hipStream_t st);
+
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);
 size_t fused_lds_bytes(int NT);
 int debug_read_stamps(unsigned long long* out, int n);

@@ -17,117 +17,9 @@
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
+#include "fused_dev.h"
 
 namespace egx {
-
-constexpr int FD = 128;        // d_model
-constexpr int FH = 4;          // heads
-constexpr int FDH = 32;        // head dim
-constexpr int LDX = FD + 4;    // token-major LDS row stride (floats)
-constexpr int LDV = 64 + 4;    // V^T row stride: keys padded to 64
-
-// ---- operand fragments --------------------------------------------------------------------------
-template <bool BF16> struct Frag { float v[8]; };
-template <> struct Frag<true> { bf16x8 v; };
-
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
-
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> make_frag(float4 a, float4 b) {
-    Frag<BF16> f;
-    if constexpr (BF16) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 u = {pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w)};
-        f.v = __builtin_bit_cast(bf16x8, u);
-    } else {
-        f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
-        f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
-    }
-    return f;
-}
-
-// fragment of one row/column for the K-block that starts at p (fp32 memory, 16-byte aligned)
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> load_frag(const float* p, int q) {
-    float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
-    float4 b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
-    return make_frag<BF16>(a, b);
-}
-
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> zero_frag() {
-    return make_frag<BF16>(make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));
-}
-
-// raw (unconverted) fragment data: issued early so that many loads are in flight at once
-struct Raw { float4 a, b; };
-__device__ __forceinline__ Raw load_raw(const float* p, int q) {
-    Raw x;
-    x.a = *reinterpret_cast<const float4*>(p + 4 * q);
-    x.b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
-    return x;
-}
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> to_frag(const Raw& x) { return make_frag<BF16>(x.a, x.b); }
-// Pins a prefetched fragment at this program point: the loads that produce it must have been issued above (hipcc
-// otherwise sinks every load down to its convert/MFMA and waits on each one individually), and the single
-// s_waitcnt for the whole batch lands here.
-__device__ __forceinline__ void pin(Raw& x) {
-    asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
-}
-
-// ---- packed weights ---------------------------------------------------------------------------------
-// A row-major weight read in MFMA-fragment shape makes every lane of a 16-lane group touch a different cache
-// line (16 rows x 64 B per instruction): the texture addresser then delivers ~16 B/clk/CU and the whole kernel
-// runs at that rate. pack_weights_kernel therefore rewrites each weight ONCE per step into fragment order:
-//   block (tile t of 16 rows, K-block kb of 32) holds the 64 lanes' operands contiguously, so a fragment load is
-//   one (bf16: uint4) or two (fp32: float4 planes) perfectly coalesced 1 KiB wave accesses.
-//   fp32: float4 plane[half][lane] = W[t*16 + r][kb*32 + half*16 + 4q .. +3]
-//   bf16: uint4  [lane]            = bf16 of the same 8 values (half 0 first)
-template <bool BF16> struct WRaw { float4 a, b; };
-template <> struct WRaw<true> { uint4 v; };
-
-template <bool BF16>
-__device__ __forceinline__ WRaw<BF16> load_w(const void* packed, int tile, int nkb, int kb, int lane) {
-    WRaw<BF16> x;
-    size_t blk = (size_t)tile * nkb + kb;
-    if constexpr (BF16) {
-        x.v = reinterpret_cast<const uint4*>(packed)[blk * 64 + lane];
-    } else {
-        const float4* pl = reinterpret_cast<const float4*>(packed) + blk * 128;
-        x.a = pl[lane];
-        x.b = pl[64 + lane];
-    }
-    return x;
-}
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> w_frag(const WRaw<BF16>& x) {
-    if constexpr (BF16) {
-        Frag<true> f;
-        f.v = __builtin_bit_cast(bf16x8, x.v);
-        return f;
-    } else {
-        return make_frag<false>(x.a, x.b);
-    }
-}
-__device__ __forceinline__ void pin(WRaw<false>& x) {
-    asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
-}
-__device__ __forceinline__ void pin(WRaw<true>& x) {
-    asm volatile("" : "+v"(x.v.x), "+v"(x.v.y), "+v"(x.v.z), "+v"(x.v.w));
-}
-template <class T, int N>
-__device__ __forceinline__ void pin_all(T (&x)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) pin(x[i]);
-}
-template <class T, int N, int M>
-__device__ __forceinline__ void pin_all(T (&x)[N][M]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) pin(x[i][j]);
-}
 
 __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
     int blk = blockIdx.x;
@@ -167,82 +59,6 @@ int pack_weights(PackParams& pp, hipStream_t st) {
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(64), 0, st, pp);
     EGX_LAUNCH_CHECK();
     return 0;
-}
-
-// two consecutive 16-row C tiles of a feature-major result -> B operand of the next GEMM (K = those 32 rows)
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> chain_frag(const f32x4& t0, const f32x4& t1) {
-    return make_frag<BF16>(make_float4(t0[0], t0[1], t0[2], t0[3]), make_float4(t1[0], t1[1], t1[2], t1[3]));
-}
-
-template <bool BF16>
-__device__ __forceinline__ void mma(f32x4& acc, const Frag<BF16>& a, const Frag<BF16>& b) {
-    if constexpr (BF16) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
-    }
-}
-
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// LayerNorm of rows [r0, r1) of a token-major LDS block, one wave per row, lane owns features 2*lane, 2*lane+1.
-// Writes y = LN(x)*w + b (+ add) (+ pos row) back in place and, if gdst != null, to global (row stride FD).
-struct LnRowArgs {
-    const float* w; const float* b; float eps;
-};
-
-// Row-parallel LayerNorm over a token-major LDS block: 4 adjacent lanes own one row (32 features each), so up
-// to 64 rows are normalised in one pass with quad (DPP) reductions. `fn(row, c0, x[32] pre-LN, y[32] post-LN)`
-// consumes the result (global saves, embeddings, dropout, write-back).
-__device__ __forceinline__ float quad_sum4(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    return v;
-}
-template <class Fn>
-__device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __restrict__ w, const float* __restrict__ b,
-                                        float eps, Fn&& fn) {
-    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
-    if (row < S) {
-        const int c0 = part * 32;
-        float x[32], y[32];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float4 v = *reinterpret_cast<const float4*>(buf + row * LDX + c0 + 4 * j);
-            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-        float mean = quad_sum4(s) * (1.f / FD);
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) { float t = x[j] - mean; ss += t * t; }
-        float rstd = rsqrtf(quad_sum4(ss) * (1.f / FD) + eps);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float4 wv = *reinterpret_cast<const float4*>(w + c0 + 4 * j);
-            float4 bv = *reinterpret_cast<const float4*>(b + c0 + 4 * j);
-            y[4 * j + 0] = (x[4 * j + 0] - mean) * rstd * wv.x + bv.x;
-            y[4 * j + 1] = (x[4 * j + 1] - mean) * rstd * wv.y + bv.y;
-            y[4 * j + 2] = (x[4 * j + 2] - mean) * rstd * wv.z + bv.z;
-            y[4 * j + 3] = (x[4 * j + 3] - mean) * rstd * wv.w + bv.w;
-        }
-        fn(row, c0, x, y);
-    } else {
-        // keep the quad shuffles convergent for partially filled waves
-        (void)quad_sum4(0.f);
-        (void)quad_sum4(0.f);
-    }
-}
-__device__ __forceinline__ void store32(float* dst, const float (&v)[32]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
 }
 
 // Development aid: phase timestamps of workgroup 0 / wave 0 (s_memtime), read back by egx_debug_stamps().

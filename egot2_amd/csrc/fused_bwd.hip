@@ -1,0 +1,857 @@
+// Fused backward kernels of the d_model = 128 translator.
+//
+//   ffn_dw_kernel    (hidden-parallel)  weight gradients of the FFN: dW1, db1, dW2 from (x1, d_res2) with the hidden
+//                                       activation H and its gradient dH recomputed on chip — the (N, 2048) tensors
+//                                       never exist in HBM.
+//   fused_bwd_kernel (clip-parallel)    everything that is local to a clip: LayerNorm backward, FFN input
+//                                       gradient (again recomputing H), attention backward with recomputed
+//                                       probabilities, in/out projection input gradients, token-prep backward.
+//
+// Same operand convention as the forward (fused_dev.h). Reference math: autograd of
+// torch.nn.TransformerEncoderLayer as built at HHI/models/ttm/model_taskspecific.py:212-215.
+#include "common.h"
+#include "kernels.h"
+#include "fused.h"
+#include "fused_dev.h"
+
+namespace egx {
+
+// ---- FFN weight gradients -------------------------------------------------------------------------
+// grid = (d_ff / (64 * HT), splits). A block owns 64*HT hidden units (wave w: HT tiles of 16) and a contiguous
+// range of 32-token K-blocks. Per K-block the block stages x1 and g = d_res2 (32 x 128 fp32 each) in LDS with
+// coalesced loads (next K-block prefetched into registers), then every wave computes for its hidden tiles
+//     H  [tok][hid] = relu(x1 W1^T + b1)  (A = x1 rows,  B = packed W1 fragment)
+//     dH [tok][hid] = (g W2) .* mask      (A = g rows,   B = packed W2^T fragment)
+// whose C tiles (token rows on the registers, hidden unit on the lane) chain straight into the A operand of
+//     dW1 [hid][in]   += dH^T x1           (B gathered from the LDS tile, 8 ds_read_b32 per fragment)
+//     dW2T[hid][dout] += H^T  g
+// accumulated in registers over the whole token range and written once as fp32 slabs.
+template <bool BF16, int HT>
+__global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TILE = 32 * LDX;             // one tensor, 32 tokens
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int hg = blockIdx.x, split = blockIdx.y;
+    const int htile0 = (hg * 4 + wave) * HT;   // first 16-wide hidden tile of this wave
+    const int nkb_total = (p.N + 31) / 32;
+    const int kb_beg = split * p.kb_per_split;
+    const int kb_end = min(nkb_total, kb_beg + p.kb_per_split);
+
+    f32x4 accW1[HT][8], accW2[HT][8];
+#pragma unroll
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { accW1[h][j] = f32x4{0, 0, 0, 0}; accW2[h][j] = f32x4{0, 0, 0, 0}; }
+    float accB1[HT];
+    float b1v[HT];
+#pragma unroll
+    for (int h = 0; h < HT; ++h) { accB1[h] = 0.f; b1v[h] = p.b1[(htile0 + h) * 16 + r]; }
+
+    // packed weight fragments of this wave's hidden tiles (bf16: 64 VGPRs resident; fp32: re-read per K-block)
+    constexpr int WR = BF16 ? HT : 1;
+    WRaw<BF16> w1f[WR][4], w2f[WR][4];
+    if constexpr (BF16) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                w1f[h][k4] = load_w<BF16>(p.w1p, htile0 + h, 4, k4, lane);
+                w2f[h][k4] = load_w<BF16>(p.w2tp, htile0 + h, 4, k4, lane);
+            }
+    }
+
+    float4 pre[8];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int f = tid + i * 256;
+            int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
+            int n = kb * 32 + row;
+            const float* src = (tensor ? p.g : p.x1) + (size_t)n * FD + c4 * 4;
+            pre[i] = (n < p.N) ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int f = tid + i * 256;
+            int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
+            *reinterpret_cast<float4*>(buf + tensor * TILE + row * LDX + c4 * 4) = pre[i];
+        }
+    };
+
+    if (kb_beg < kb_end) gload(kb_beg);
+    int cur = 0;
+    for (int kb = kb_beg; kb < kb_end; ++kb) {
+        float* buf = lds + cur * 2 * TILE;
+        lstore(buf);
+        __syncthreads();
+        if (kb + 1 < kb_end) gload(kb + 1);
+        const float* Xs = buf;
+        const float* Gs = buf + TILE;
+
+        // token-major A fragments of both tensors: [token tile][K-block of features]
+        Frag<BF16> ax[2][4], ag[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                ax[tt][k4] = load_frag<BF16>(Xs + (tt * 16 + r) * LDX + k4 * 32, q);
+                ag[tt][k4] = load_frag<BF16>(Gs + (tt * 16 + r) * LDX + k4 * 32, q);
+            }
+        Frag<BF16> aH[HT], aD[HT];
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
+            if constexpr (!BF16) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    w1f[0][k4] = load_w<BF16>(p.w1p, htile0 + h, 4, k4, lane);
+                    w2f[0][k4] = load_w<BF16>(p.w2tp, htile0 + h, 4, k4, lane);
+                }
+            }
+            f32x4 hc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+            f32x4 dc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                Frag<BF16> b1f = w_frag<BF16>(w1f[BF16 ? h : 0][k4]);
+                Frag<BF16> b2f = w_frag<BF16>(w2f[BF16 ? h : 0][k4]);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    mma<BF16>(hc[tt], ax[tt][k4], b1f);
+                    mma<BF16>(dc[tt], ag[tt][k4], b2f);
+                }
+            }
+            float bsum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float hv = fmaxf(hc[tt][e] + b1v[h], 0.f);
+                    float scale = hv > 0.f ? 1.f : 0.f;
+                    if (p.drop_thresh) {
+                        int n = kb * 32 + tt * 16 + 4 * q + e;
+                        int clip = n / p.S, tok = n - clip * p.S;
+                        float ds = drop_scale(p.drop_key, (uint32_t)(clip * 64 + tok), (uint32_t)((htile0 + h) * 16 + r), p.drop_thresh, p.drop_inv);
+                        hv *= ds;
+                        scale *= ds;
+                    }
+                    hc[tt][e] = hv;
+                    float dv = dc[tt][e] * scale;
+                    dc[tt][e] = dv;
+                    bsum += dv;
+                }
+            accB1[h] += bsum;
+            aH[h] = chain_frag<BF16>(hc[0], hc[1]);
+            aD[h] = chain_frag<BF16>(dc[0], dc[1]);
+        }
+        // dW accumulation: B operands gathered transposed from the token-major tiles
+        const int t0 = 4 * q;
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            const float* xc = Xs + jt * 16 + r;
+            const float* gc = Gs + jt * 16 + r;
+            float4 xa = make_float4(xc[(t0 + 0) * LDX], xc[(t0 + 1) * LDX], xc[(t0 + 2) * LDX], xc[(t0 + 3) * LDX]);
+            float4 xb = make_float4(xc[(t0 + 16) * LDX], xc[(t0 + 17) * LDX], xc[(t0 + 18) * LDX], xc[(t0 + 19) * LDX]);
+            float4 ga = make_float4(gc[(t0 + 0) * LDX], gc[(t0 + 1) * LDX], gc[(t0 + 2) * LDX], gc[(t0 + 3) * LDX]);
+            float4 gb = make_float4(gc[(t0 + 16) * LDX], gc[(t0 + 17) * LDX], gc[(t0 + 18) * LDX], gc[(t0 + 19) * LDX]);
+            Frag<BF16> bx = make_frag<BF16>(xa, xb);
+            Frag<BF16> bg = make_frag<BF16>(ga, gb);
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                mma<BF16>(accW1[h][jt], aD[h], bx);
+                mma<BF16>(accW2[h][jt], aH[h], bg);
+            }
+        }
+        cur ^= 1;
+    }
+
+    // write the slabs. dW1: C rows = hidden (4q + e), cols = in (jt*16 + r). dW2 is stored already transposed
+    // ([dout][hid], the parameter's own layout): the lane's 4 consecutive hidden units are one 16-byte store.
+    float* sw1 = p.slab_w1 + (size_t)split * p.d_ff * FD;
+    float* sw2 = p.slab_w2t + (size_t)split * p.d_ff * FD;
+#pragma unroll
+    for (int h = 0; h < HT; ++h) {
+        int hrow = (htile0 + h) * 16 + 4 * q;
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[h][jt][e];
+            *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
+                make_float4(accW2[h][jt][0], accW2[h][jt][1], accW2[h][jt][2], accW2[h][jt][3]);
+        }
+        float bs = accB1[h];
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (q == 0) p.slab_b1[(size_t)split * p.d_ff + (htile0 + h) * 16 + r] = bs;
+    }
+}
+
+// out[i] += sum_z slabs[z * n + i], float4-vectorised (n % 4 == 0, 16-byte aligned pointers)
+__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(const float* __restrict__ slabs, int nslab, size_t n, float* __restrict__ out) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 s = *reinterpret_cast<const float4*>(out + i);
+    for (int z = 0; z < nslab; ++z) {
+        float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
+}
+
+size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
+    int nkb = (N + 31) / 32;
+    int splits = 16;
+    if (nkb < splits) splits = nkb;
+    if (splits_out) *splits_out = splits;
+    return (size_t)splits * ((size_t)2 * d_ff * FD + d_ff) * sizeof(float);
+}
+
+template <bool BF16>
+static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
+    constexpr int HT = 2;
+    size_t lds = (size_t)4 * 32 * LDX * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_kernel<BF16, HT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(p.d_ff / (64 * HT), p.splits);
+    hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H with H, dH recomputed. `slabs` holds ffn_dw_scratch_bytes().
+int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st) {
+    EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
+    int splits;
+    ffn_dw_scratch_bytes(p.N, p.d_ff, &splits);
+    int nkb = (p.N + 31) / 32;
+    p.splits = splits;
+    p.kb_per_split = cdiv(nkb, splits);
+    p.splits = cdiv(nkb, p.kb_per_split);
+    splits = p.splits;
+    p.slab_w1 = (float*)slabs;
+    p.slab_w2t = p.slab_w1 + (size_t)splits * p.d_ff * FD;
+    p.slab_b1 = p.slab_w2t + (size_t)splits * p.d_ff * FD;
+    int rc = compute == 1 ? launch_ffn_dw<true>(p, st) : launch_ffn_dw<false>(p, st);
+    if (rc) return rc;
+    size_t nw = (size_t)p.d_ff * FD;
+    auto red = [&](const float* slab, size_t n, float* out) -> int {
+        EGX_CHECK((((uintptr_t)out) & 15) == 0, "ffn_dw: gradient buffers must be 16-byte aligned");
+        hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slab, splits, n, out);
+        EGX_LAUNCH_CHECK();
+        return 0;
+    };
+    if (dW1 && red(p.slab_w1, nw, dW1)) return 1;
+    if (dW2 && red(p.slab_w2t, nw, dW2)) return 1;
+    if (db1 && red(p.slab_b1, (size_t)p.d_ff, db1)) return 1;
+    return 0;
+}
+
+// ---- per-clip backward --------------------------------------------------------------------------------
+// One workgroup per clip. Six token-major LDS blocks (48 x 132 fp32 each) are rotated through the roles noted at
+// each phase; small per-head softmax statistics live behind them. Everything that another kernel needs
+// (operands of the weight-gradient GEMMs) is written to HBM exactly once.
+template <bool BF16>
+__global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
+    constexpr int NT = 3;
+    constexpr int SP = NT * 16;
+    constexpr int BLK = SP * LDX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Gs = lds;                 // dY of the current layer (rotates with B2)
+    float* B1 = lds + 1 * BLK;
+    float* B2 = lds + 2 * BLK;
+    float* B3 = lds + 3 * BLK;
+    float* B4 = lds + 4 * BLK;
+    float* B5 = lds + 5 * BLK;
+    float* stat = lds + 6 * BLK;     // [FH][3][SP] softmax max / 1/sum / delta per query
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int clip = blockIdx.x;
+    const int S = p.S;
+    const size_t tok0 = (size_t)clip * S;
+    float* part = p.partials + (size_t)clip * p.P;
+
+    auto load_block = [&](float* dst, const float* src) {     // (S, 128) global -> token-major LDS, coalesced
+        for (int i = tid; i < S * (FD / 4); i += 256) {
+            int row = i >> 5, c = (i & 31) << 2;
+            *reinterpret_cast<float4*>(dst + row * LDX + c) = *reinterpret_cast<const float4*>(src + (size_t)row * FD + c);
+        }
+    };
+    for (int i = tid; i < 6 * BLK; i += 256) lds[i] = 0.f;
+    __syncthreads();
+    load_block(Gs, p.d_tokens + tok0 * FD);
+
+    for (int l = p.n_layers - 1; l >= 0; --l) {
+        const FusedBwdLayer& w = p.layer[l];
+        const float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
+        const float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
+        float* pl = part + l * FUSED_P_LAYER;
+
+        // P1: res2 -> B1
+        load_block(B1, sv_res2);
+        __syncthreads();
+        // P2: LayerNorm2 backward. B1 <- d_res2 (in place), B3 <- dY * xhat, B2 <- g2 = d_res2 .* dropout2 mask
+        ln_bwd_rows(S, w.norm2_w, p.eps,
+            [&](int row, int c0, float (&dy)[32], float (&x)[32]) { load32(Gs + row * LDX + c0, dy); load32(B1 + row * LDX + c0, x); },
+            [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
+                store32(B1 + row * LDX + c0, dx);
+                store32(B3 + row * LDX + c0, dyx);
+                if (w.res_thresh) {
+                    uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(w.res2_key, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
+                }
+                store32(B2 + row * LDX + c0, dx);
+                store32(w.g2_out + (tok0 + row) * FD + c0, dx);
+            });
+        __syncthreads();
+        // P3: column sums (norm2_w, norm2_b, lin2_b partials); res1 -> B4 and LayerNorm1 forward in place (x1)
+        if (tid < 128) {
+            pl[0 + tid] = colsum_lds(B3, 0, S, tid);
+            pl[256 + tid] = colsum_lds(B2, 0, S, tid);
+        } else {
+            pl[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
+        }
+        load_block(B4, sv_res1);
+        __syncthreads();
+        ln_rows(B4, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            store32(B4 + row * LDX + c0, y);
+            store32(w.x1_out + (tok0 + row) * FD + c0, y);
+        });
+        __syncthreads();
+
+        // P4: FFN input gradient. H^T = relu(W1 x1^T + b1); dH^T = (W2^T g2^T) .* mask; dX1^T += W1^T dH^T
+        {
+            constexpr bool XRES = BF16;
+            constexpr int XR = XRES ? FD / 32 : 1;
+            Frag<BF16> xb[XR][NT], gb[XR][NT];
+            if constexpr (XRES) {
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        xb[kb][t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + kb * 32, q);
+                        gb[kb][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
+                    }
+            }
+            f32x4 dxa[8][NT];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dxa[i][t] = f32x4{0, 0, 0, 0};
+            const int nhb = p.d_ff / 32;
+            const int nit = nhb / 4;
+            const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
+            WRaw<BF16> w1r[2][FD / 32], w2r[2][FD / 32], w3r[8];
+            float4 b1r[2];
+            auto issue_a = [&](int hb) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int kb = 0; kb < FD / 32; ++kb) {
+                        w1r[i][kb] = load_w<BF16>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
+                        w2r[i][kb] = load_w<BF16>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
+                    }
+                    b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb * 32 + i * 16 + 4 * q);
+                }
+            };
+            auto issue_b = [&](int hb) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w3r[i] = load_w<BF16>(w.lin1_wtp, i, nhb, hb, lane);
+            };
+            issue_a(hb_of(0));
+            for (int it = 0; it < nit; ++it) {
+                const int hb = hb_of(it);
+                issue_b(hb);
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(w1r); pin_all(w2r);
+                f32x4 hacc[2][NT], dacc[2][NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { hacc[i][t] = f32x4{0, 0, 0, 0}; dacc[i][t] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb) {
+                    if constexpr (!XRES) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            xb[0][t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + kb * 32, q);
+                            gb[0][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        Frag<BF16> a1 = w_frag<BF16>(w1r[i][kb]);
+                        Frag<BF16> a2 = w_frag<BF16>(w2r[i][kb]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            mma<BF16>(hacc[i][t], a1, xb[XRES ? kb : 0][t]);
+                            mma<BF16>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
+                        }
+                    }
+                }
+                float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < nit) issue_a(hb_of(it + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(w3r);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = (hacc[i][t][e] + bv[i][e] > 0.f) ? dacc[i][t][e] : 0.f;
+                if (w.ffn_thresh) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        int h0 = hb * 32 + i * 16 + 4 * q;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                dacc[i][t][e] *= drop_scale(w.ffn_key, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
+                    }
+                }
+                Frag<BF16> dq_[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<BF16>(dacc[0][t], dacc[1][t]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    Frag<BF16> a = w_frag<BF16>(w3r[i]);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) mma<BF16>(dxa[i][t], a, dq_[t]);
+                }
+            }
+            // deterministic cross-wave sum into Gs (dY is dead): wave 0 stores, waves 1..3 add in turn
+            for (int round = 0; round < 4; ++round) {
+                if (wave == round) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            float* d = Gs + (t * 16 + r) * LDX + i * 16 + 4 * q;
+                            float4 v = make_float4(dxa[i][t][0], dxa[i][t][1], dxa[i][t][2], dxa[i][t][3]);
+                            if (round) { float4 o = *reinterpret_cast<float4*>(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            *reinterpret_cast<float4*>(d) = v;
+                        }
+                }
+                __syncthreads();
+            }
+        }
+        // P5: res1 -> B3; LayerNorm1 backward with dy = dX1 (Gs) + d_res2 (B1).
+        load_block(B3, sv_res1);
+        __syncthreads();
+        ln_bwd_rows(S, w.norm1_w, p.eps,
+            [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
+                float t[32];
+                load32(Gs + row * LDX + c0, dy);
+                load32(B1 + row * LDX + c0, t);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) dy[j] += t[j];
+                load32(B3 + row * LDX + c0, x);
+            },
+            [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
+                store32(Gs + row * LDX + c0, dy);      // total dy, for d(norm1_b)
+                store32(B1 + row * LDX + c0, dx);      // d_res1 (residual path into the layer input)
+                store32(B4 + row * LDX + c0, dyx);
+                if (w.res_thresh) {
+                    uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(w.res1_key, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
+                }
+                store32(B2 + row * LDX + c0, dx);      // g1
+                store32(w.g1_out + (tok0 + row) * FD + c0, dx);
+            });
+        __syncthreads();
+        // P6: column sums (norm1_w, norm1_b, out_proj_b)
+        if (tid < 128) {
+            pl[384 + tid] = colsum_lds(B4, 0, S, tid);
+            pl[640 + tid] = colsum_lds(B2, 0, S, tid);
+        } else {
+            pl[512 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
+        }
+        // P7: out-projection input gradient dO^T = W_o^T g1^T -> B3 (token-major)
+        __syncthreads();
+        {
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.out_proj_wtp, wave * 2, 4, 0, B2, r, q, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<float4*>(B3 + (t * 16 + r) * LDX + (wave * 2 + i) * 16 + 4 * q) =
+                        make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
+        }
+        // P8: recompute the layer input x_in -> Gs
+        if (l == 0) {
+            load_block(Gs, p.saved_pre + tok0 * FD);
+            __syncthreads();
+            ln_rows(Gs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+                const float* addv = nullptr; const float* posr = nullptr;
+#pragma unroll
+                for (int si = 0; si < FUSED_MAX_SEG; ++si)
+                    if (si < p.nseg && row >= p.seg[si].off && row < p.seg[si].off + p.seg[si].T) {
+                        addv = p.seg[si].add_vec;
+                        posr = p.seg[si].pos ? p.seg[si].pos + (size_t)(row - p.seg[si].off) * p.seg[si].pos_stride : nullptr;
+                    }
+                if (addv) { float a[32]; load32(addv + c0, a);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) y[j] += a[j]; }
+                if (posr) { float a[32]; load32(posr + c0, a);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) y[j] += a[j]; }
+                if (p.pos_thresh) {
+                    uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) y[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+                }
+                store32(Gs + row * LDX + c0, y);
+                store32(w.x_in_out + (tok0 + row) * FD + c0, y);
+            });
+        } else {
+            const FusedBwdLayer& wp = p.layer[l - 1];
+            load_block(Gs, p.saved_res + ((size_t)(2 * (l - 1) + 1) * p.B + clip) * S * FD);
+            __syncthreads();
+            ln_rows(Gs, S, wp.norm2_w, wp.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+                store32(Gs + row * LDX + c0, y);
+                store32(w.x_in_out + (tok0 + row) * FD + c0, y);
+            });
+        }
+        __syncthreads();
+        // P9: QKV recompute: Q -> B4, K -> B5, V -> Gs (written after the barrier: Gs is this GEMM's B operand)
+        {
+            f32x4 acc[6][NT];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+            {
+                f32x4 (&a0)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[0]);
+                f32x4 (&a1)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[3]);
+                gemm_pack_lds<BF16, 3, NT, 4>(a0, w.in_proj_wp, wave * 6, 4, 0, Gs, r, q, lane);
+                gemm_pack_lds<BF16, 3, NT, 4>(a1, w.in_proj_wp, wave * 6 + 3, 4, 0, Gs, r, q, lane);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                int f0 = (wave * 6 + i) * 16 + 4 * q;
+                float4 bb = *reinterpret_cast<const float4*>(w.in_proj_b + f0);
+                float* dst = f0 < FD ? B4 + f0 : (f0 < 2 * FD ? B5 + (f0 - FD) : Gs + (f0 - 2 * FD));
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    *reinterpret_cast<float4*>(dst + (t * 16 + r) * LDX) =
+                        make_float4(acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w);
+            }
+        }
+        __syncthreads();
+        // P10: attention forward recompute + backward, wave = head. Q = B4, K = B5, V = Gs, dO = B3.
+        {
+            const int h = wave;
+            const int hc = h * FDH;
+            const float scale = 0.17677669529663687f;
+            float* st_m = stat + (h * 3 + 0) * SP;
+            float* st_i = stat + (h * 3 + 1) * SP;
+            float* st_d = stat + (h * 3 + 2) * SP;
+            Frag<BF16> fq[NT], fk[NT], fv[NT], fdo[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fq[t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + hc, q);
+                fk[t] = load_frag<BF16>(B5 + (t * 16 + r) * LDX + hc, q);
+                fv[t] = load_frag<BF16>(Gs + (t * 16 + r) * LDX + hc, q);
+                fdo[t] = load_frag<BF16>(B3 + (t * 16 + r) * LDX + hc, q);
+            }
+            // orientation T: rows = key, cols = query
+            f32x4 pt[NT][NT], dpt[NT][NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    pt[kt][qt] = f32x4{0, 0, 0, 0};
+                    dpt[kt][qt] = f32x4{0, 0, 0, 0};
+                    mma<BF16>(pt[kt][qt], fk[kt], fq[qt]);      // S^T = K Q^T
+                    mma<BF16>(dpt[kt][qt], fv[kt], fdo[qt]);    // dP^T = V dO^T
+                }
+            f32x4 mk[NT][NT];   // dropout keep-scale per element (1 when dropout is off)
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int key = kt * 16 + 4 * q + e;
+                        float sv = (key < S) ? pt[kt][qt][e] * scale : -INFINITY;
+                        pt[kt][qt][e] = sv;
+                        m = fmaxf(m, sv);
+                    }
+                m = fmaxf(m, __shfl_xor(m, 16, 64));
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float pv = __expf(pt[kt][qt][e] - m); pt[kt][qt][e] = pv; sum += pv; }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                float inv = 1.f / sum;
+                int query = qt * 16 + r;
+                float dl = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pv = pt[kt][qt][e] * inv;
+                        float ks = 1.f;
+                        if (w.attn_thresh) ks = drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)(kt * 16 + 4 * q + e), w.attn_thresh, w.drop_inv);
+                        mk[kt][qt][e] = ks;
+                        pt[kt][qt][e] = pv;
+                        dl += pv * ks * dpt[kt][qt][e];
+                    }
+                dl += __shfl_xor(dl, 16, 64);
+                dl += __shfl_xor(dl, 32, 64);
+                if (q == 0) { st_m[query] = m; st_i[query] = inv; st_d[query] = dl; }
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pv = pt[kt][qt][e];
+                        dpt[kt][qt][e] = pv * (mk[kt][qt][e] * dpt[kt][qt][e] - dl) * scale;   // dS^T (scaled)
+                        pt[kt][qt][e] = pv * mk[kt][qt][e];                                       // dropped P^T
+                    }
+            }
+            // O^T = V^T (P^T .* mask) -> attn_o (HBM);  dQ^T = K^T dS^T
+            f32x4 oq[2][NT], dqa[2][NT];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) { oq[ct][qt] = f32x4{0, 0, 0, 0}; dqa[ct][qt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Frag<BF16> av[2], ak[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    av[ct] = gather_frag<BF16>(Gs, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    ak[ct] = gather_frag<BF16>(B5, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                }
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    f32x4 z = f32x4{0, 0, 0, 0};
+                    Frag<BF16> bp = chain_frag<BF16>(pt[2 * kb][qt], (2 * kb + 1 < NT) ? pt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+                    Frag<BF16> bs = chain_frag<BF16>(dpt[2 * kb][qt], (2 * kb + 1 < NT) ? dpt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        mma<BF16>(oq[ct][qt], av[ct], bp);
+                        mma<BF16>(dqa[ct][qt], ak[ct], bs);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int qt = 0; qt < NT; ++qt) {
+                    int tok = qt * 16 + r;
+                    if (tok < S)
+                        *reinterpret_cast<float4*>(w.attn_o_out + (tok0 + tok) * FD + hc + ct * 16 + 4 * q) =
+                            make_float4(oq[ct][qt][0], oq[ct][qt][1], oq[ct][qt][2], oq[ct][qt][3]);
+                }
+            // orientation N: rows = query, cols = key. P and dS rebuilt from the per-query statistics.
+            f32x4 pn[NT][NT], dsn[NT][NT];
+#pragma unroll
+            for (int qt = 0; qt < NT; ++qt) {
+                float4 m4 = *reinterpret_cast<const float4*>(st_m + qt * 16 + 4 * q);
+                float4 i4 = *reinterpret_cast<const float4*>(st_i + qt * 16 + 4 * q);
+                float4 d4 = *reinterpret_cast<const float4*>(st_d + qt * 16 + 4 * q);
+                float mq[4] = {m4.x, m4.y, m4.z, m4.w}, iq[4] = {i4.x, i4.y, i4.z, i4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    f32x4 sN = f32x4{0, 0, 0, 0}, dN = f32x4{0, 0, 0, 0};
+                    mma<BF16>(sN, fq[qt], fk[kt]);      // S = Q K^T
+                    mma<BF16>(dN, fdo[qt], fv[kt]);     // dP = dO V^T
+                    int key = kt * 16 + r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int query = qt * 16 + 4 * q + e;
+                        bool ok = (key < S) && (query < S);
+                        float pv = ok ? __expf(sN[e] * scale - mq[e]) * iq[e] : 0.f;
+                        float ks = 1.f;
+                        if (w.attn_thresh) ks = drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
+                        pn[qt][kt][e] = pv * ks;
+                        dsn[qt][kt][e] = pv * (ks * dN[e] - dq4[e]) * scale;
+                    }
+                }
+            }
+            // dV^T = dO^T P ; dK^T = Q^T dS   (A gathered from token-major dO / Q; K dimension = query)
+            f32x4 dva[2][NT], dka[2][NT];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) { dva[ct][kt] = f32x4{0, 0, 0, 0}; dka[ct][kt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Frag<BF16> ad[2], aq[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    ad[ct] = gather_frag<BF16>(B3, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    aq[ct] = gather_frag<BF16>(B4, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                }
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt) {
+                    f32x4 z = f32x4{0, 0, 0, 0};
+                    Frag<BF16> bp = chain_frag<BF16>(pn[2 * kb][kt], (2 * kb + 1 < NT) ? pn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
+                    Frag<BF16> bs = chain_frag<BF16>(dsn[2 * kb][kt], (2 * kb + 1 < NT) ? dsn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        mma<BF16>(dva[ct][kt], ad[ct], bp);
+                        mma<BF16>(dka[ct][kt], aq[ct], bs);
+                    }
+                }
+            }
+            // all operands of this head are consumed: overwrite Q/K/V columns with dQ/dK/dV and emit dqkv
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int tok = t * 16 + r;
+                    int c = hc + ct * 16 + 4 * q;
+                    bool tv = tok < S;
+                    float4 vq = tv ? make_float4(dqa[ct][t][0], dqa[ct][t][1], dqa[ct][t][2], dqa[ct][t][3]) : make_float4(0, 0, 0, 0);
+                    float4 vk = tv ? make_float4(dka[ct][t][0], dka[ct][t][1], dka[ct][t][2], dka[ct][t][3]) : make_float4(0, 0, 0, 0);
+                    float4 vv = tv ? make_float4(dva[ct][t][0], dva[ct][t][1], dva[ct][t][2], dva[ct][t][3]) : make_float4(0, 0, 0, 0);
+                    *reinterpret_cast<float4*>(B4 + tok * LDX + c) = vq;
+                    *reinterpret_cast<float4*>(B5 + tok * LDX + c) = vk;
+                    *reinterpret_cast<float4*>(Gs + tok * LDX + c) = vv;
+                    if (tv) {
+                        float* o = w.dqkv_out + (tok0 + tok) * (3 * FD) + c;
+                        *reinterpret_cast<float4*>(o) = vq;
+                        *reinterpret_cast<float4*>(o + FD) = vk;
+                        *reinterpret_cast<float4*>(o + 2 * FD) = vv;
+                    }
+                }
+        }
+        __syncthreads();
+        // P11: in_proj_b partials
+        if (tid < 128) {
+            pl[768 + tid] = colsum_lds(B4, 0, S, tid);
+            pl[768 + 256 + tid] = colsum_lds(Gs, 0, S, tid);
+        } else {
+            pl[768 + 128 + (tid - 128)] = colsum_lds(B5, 0, S, tid - 128);
+        }
+        // P12: in-projection input gradient + residual d_res1 (B1) -> B2 (next layer's dY)
+        {
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 0, B4, r, q, lane);
+            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 4, B5, r, q, lane);
+            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 8, Gs, r, q, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int tok = t * 16 + r;
+                    int c = (wave * 2 + i) * 16 + 4 * q;
+                    float4 rs = *reinterpret_cast<const float4*>(B1 + tok * LDX + c);
+                    float4 o = make_float4(acc[i][t][0] + rs.x, acc[i][t][1] + rs.y, acc[i][t][2] + rs.z, acc[i][t][3] + rs.w);
+                    if (tok >= S) o = make_float4(0, 0, 0, 0);
+                    *reinterpret_cast<float4*>(B2 + tok * LDX + c) = o;
+                }
+        }
+        __syncthreads();
+        { float* t = Gs; Gs = B2; B2 = t; }
+    }
+
+    // ---- token preparation backward: Gs = d(x0)
+    {
+        float* pg = part + p.n_layers * FUSED_P_LAYER;
+        load_block(B1, p.saved_pre + tok0 * FD);
+        __syncthreads();
+        ln_bwd_rows(S, p.ln_w, p.eps,
+            [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
+                load32(Gs + row * LDX + c0, dy);
+                if (p.pos_thresh) {
+                    uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) dy[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+                }
+                load32(B1 + row * LDX + c0, x);
+            },
+            [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
+                store32(Gs + row * LDX + c0, dy);
+                store32(B1 + row * LDX + c0, dx);
+                store32(B3 + row * LDX + c0, dyx);
+#pragma unroll
+                for (int si = 0; si < FUSED_MAX_SEG; ++si)
+                    if (si < p.nseg && row >= p.seg[si].off && row < p.seg[si].off + p.seg[si].T)
+                        store32(p.dseg_out[si] + ((size_t)clip * p.seg[si].T + (row - p.seg[si].off)) * FD + c0, dx);
+            });
+        __syncthreads();
+        if (tid < 128) pg[tid] = colsum_lds(B3, 0, S, tid);
+        else pg[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
+        for (int si = 0; si < p.nseg; ++si) {
+            int r0 = p.seg[si].off, r1 = r0 + p.seg[si].T;
+            if (tid < 128) pg[256 + si * 256 + tid] = colsum_lds(Gs, r0, r1, tid);
+            else pg[256 + si * 256 + 128 + (tid - 128)] = colsum_lds(B1, r0, r1, tid - 128);
+        }
+    }
+}
+
+// grads[dst] += sum_clip partials[clip][off .. off+len): grid = (P / 64, clip chunks); 256 threads = 64 columns x 4
+// clip lanes, LDS tree, one atomic per column per block (<= 16 adders per address).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(ReducePartialsParams rp) {
+    __shared__ float red[4][64];
+    int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    int j = blockIdx.x * 64 + c;
+    int per = (rp.B + gridDim.y - 1) / gridDim.y;
+    int b0 = blockIdx.y * per, b1 = min(rp.B, b0 + per);
+    float s = 0.f;
+    if (j < rp.P)
+        for (int b = b0 + g; b < b1; b += 4) s += rp.partials[(size_t)b * rp.P + j];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < rp.P) {
+        float* dst = nullptr;
+        for (int i = 0; i < rp.n; ++i)
+            if (j >= rp.d[i].off && j < rp.d[i].off + rp.d[i].len) dst = rp.d[i].dst + (j - rp.d[i].off);
+        if (dst) atomicAdd(dst, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
+}
+
+int reduce_partials(const ReducePartialsParams& rp, hipStream_t st) {
+    int chunks = rp.B >= 64 ? 16 : (rp.B >= 8 ? 4 : 1);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(rp.P, 64), chunks), dim3(256), 0, st, rp);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool BF16>
+static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
+    size_t lds = (size_t)(6 * 48 * LDX + FH * 3 * 48) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<BF16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((fused_bwd_kernel<BF16>), dim3(p.B), dim3(256), lds, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st) {
+    EGX_CHECK(p.S <= 48, "fused backward: S=%d > 48", p.S);
+    return compute == 1 ? launch_bwd<true>(p, st) : launch_bwd<false>(p, st);
+}
+
+}  // namespace egx

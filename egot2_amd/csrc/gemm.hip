@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 if (p.drop_thresh) v *= drop_scale(p.drop_key, (uint32_t)row, (uint32_t)col, p.drop_thresh, p.drop_inv_keep);
                 if (p.mask) v = (p.mask[(size_t)row * p.ldm + col] > 0.f) ? v * p.mask_scale : 0.f;
                 if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
-                C[(size_t)row * p.ldc + col] = v;
+                if (p.atomic) atomicAdd(C + (size_t)row * p.ldc + col, v);
+                else C[(size_t)row * p.ldc + col] = v;
             }
         }
     }
@@ -318,7 +319,10 @@ int gemm(int layout, GemmParams p, int compute, int accumulate, void* scratch, s
     float* final_C = p.C;
     int final_ldc = p.ldc;
     bool use_slabs = false;
-    if (splits > 1 || accumulate) {
+    // small accumulate-into outputs (<= 256k floats): split-K blocks add straight into C, no slab round trip
+    if (accumulate && layout == 2 && (size_t)p.M * p.N <= 262144 && !p.bias && !p.residual && !p.mask && !p.relu && !p.drop_thresh) {
+        p.atomic = 1;
+    } else if (splits > 1 || accumulate) {
         size_t need = (size_t)splits * p.M * p.N * sizeof(float);
         EGX_CHECK(scratch && scratch_bytes >= need, "gemm: scratch too small (%zu < %zu)", scratch_bytes, need);
         EGX_CHECK(!p.bias && !p.residual && !p.mask && !p.relu && !p.drop_thresh, "gemm: epilogue unsupported with split-K");

@@ -20,6 +20,7 @@ struct GemmParams {
     uint64_t drop_key = 0;             // inverted dropout on (acc + bias [relu]) keyed by (row, col)
     uint32_t drop_thresh = 0;
     float drop_inv_keep = 1.f;
+    int atomic = 0;                    // split-K partials are atomically added into C (small weight gradients)
     int k_chunk = 0;                   // set by gemm()
     size_t slab_stride = 0;            // set by gemm()
 };

@@ -268,13 +268,33 @@ __global__ __launch_bounds__(256) void pool_head_fwd_kernel(const float* __restr
     const float* tk = tokens + (size_t)b * S * d;
     float inv_s = 1.f / (float)S;
     float loc = 0.f;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        float s = 0.f;
-        for (int t = 0; t < S; ++t) s += tk[(size_t)t * d + c];
-        s *= inv_s;
-        y[c] = s;
-        pooled[(size_t)b * d + c] = s;
-        loc += s;
+    if (d <= 128) {
+        // small d: split the token loop over the 256 threads (2 threads per column) and combine through LDS
+        __shared__ float ps[2][128];
+        int c = threadIdx.x & 127, g = threadIdx.x >> 7;
+        float s0 = 0.f, s1 = 0.f;
+        if (c < d) {
+            int t = g;
+            for (; t + 2 < S; t += 4) { s0 += tk[(size_t)t * d + c]; s1 += tk[(size_t)(t + 2) * d + c]; }
+            for (; t < S; t += 2) s0 += tk[(size_t)t * d + c];
+        }
+        ps[g][c] = s0 + s1;
+        __syncthreads();
+        if (threadIdx.x < d) {
+            float s = (ps[0][threadIdx.x] + ps[1][threadIdx.x]) * inv_s;
+            y[threadIdx.x] = s;
+            pooled[(size_t)b * d + threadIdx.x] = s;
+            loc = s;
+        }
+    } else {
+        for (int c = threadIdx.x; c < d; c += 256) {
+            float s = 0.f;
+            for (int t = 0; t < S; ++t) s += tk[(size_t)t * d + c];
+            s *= inv_s;
+            y[c] = s;
+            pooled[(size_t)b * d + c] = s;
+            loc += s;
+        }
     }
     if (ln_w) {
         float mean = block_sum(loc, red) / (float)d;

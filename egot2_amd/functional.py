@@ -158,6 +158,11 @@ class EncoderFn(torch.autograd.Function):
             for k, name in enumerate(_LAYER_FIELDS):
                 setattr(layers[l], name, ptr(layer_t[12 * l + k]))
 
+        if spec.impl == "auto" and torch.is_grad_enabled() and (
+                (pos_table is not None and pos_table.requires_grad) or any(f.requires_grad for f in rest[:nseg])):
+            # the fused backward emits no positional-table / feature gradients: keep the generic kernels
+            import dataclasses
+            spec = dataclasses.replace(spec, impl="generic")
         cfg = spec.config()
         sv, sc = C.c_size_t(0), C.c_size_t(0)
         check(lib.egx_encoder_workspace(C.byref(cfg), segs, B, C.byref(sv), C.byref(sc)))

@@ -181,6 +181,17 @@ int egx_attention_bwd(const float* qkv, const float* out, const float* lse, cons
                       float* d_qkv, int B, int S, int H, int d,
                       float p_drop, uint64_t seed, void* stream);
 
+/* Fused FFN weight gradients (d_model = 128): dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H where
+ * H = dropout(relu(x1 W1^T + b1)) and dH = (g W2) .* mask are recomputed on chip. x1, g: (N, 128); S = tokens per
+ * clip (dropout keying). scratch: egx_ffn_dw_scratch() bytes. Replaces the autograd of linear1/ReLU/linear2 weight
+ * gradients (torch.nn.TransformerEncoderLayer._ff_block). */
+size_t egx_ffn_dw_scratch(int N, int d_ff, int compute);
+int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1, const float* W2, int N, int S,
+               int d_ff, float p_drop, uint64_t seed, float* dW1, float* db1, float* dW2, int compute,
+               void* scratch, void* stream);
+/* development aid: phase timestamps of the fused forward (only meaningful in -DEGX_STAMPS builds) */
+int egx_debug_stamps(unsigned long long* out, int n);
+
 #ifdef __cplusplus
 }
 #endif

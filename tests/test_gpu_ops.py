@@ -99,3 +99,29 @@ def test_attention_fwd_bwd(egx_lib, cuda, B, S, H, d):
     torch.cuda.synchronize()
     assert (out.cpu().double() - ref.detach()).abs().max() < 2e-5
     assert (dq.cpu().double() - qr.grad).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("compute,tol", [(0, 2e-4), (1, 8e-2)])  # bf16: ReLU-mask sign flips dominate (sqrt of flipped fraction)
+@pytest.mark.parametrize("N,S,d_ff", [(45 * 8, 45, 2048), (45 * 256, 45, 2048), (100, 30, 256)])
+def test_fused_ffn_weight_grads(egx_lib, cuda, compute, tol, N, S, d_ff):
+    """ffn_dw_kernel (H and dH recomputed on chip) against autograd of the same two linears in fp64."""
+    g = torch.Generator().manual_seed(N + d_ff)
+    x1 = torch.randn(N, 128, generator=g)
+    gy = torch.randn(N, 128, generator=g) * 0.1
+    W1 = torch.randn(d_ff, 128, generator=g) / math.sqrt(128)
+    b1 = torch.randn(d_ff, generator=g) * 0.1
+    W2 = torch.randn(128, d_ff, generator=g) / math.sqrt(d_ff)
+    W1r, b1r, W2r = [t.double().requires_grad_(True) for t in (W1, b1, W2)]
+    y = torch.relu(x1.double() @ W1r.T + b1r) @ W2r.T
+    y.backward(gy.double())
+    d = [t.to(cuda) for t in (x1, gy, W1, b1, W2)]
+    dW1 = torch.zeros(d_ff, 128, device=cuda)
+    db1 = torch.zeros(d_ff, device=cuda)
+    dW2 = torch.zeros(128, d_ff, device=cuda)
+    scratch = torch.empty(egx_lib.egx_ffn_dw_scratch(N, d_ff, compute) + 256, dtype=torch.uint8, device=cuda)
+    _check(egx_lib, egx_lib.egx_ffn_dw(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]), _ptr(d[3]), _ptr(d[4]), N, S, d_ff, 0.0, 0,
+                                       _ptr(dW1), _ptr(db1), _ptr(dW2), compute, _ptr(scratch), _stream()))
+    torch.cuda.synchronize()
+    errs = {name: ((got.cpu().double() - ref).norm() / ref.norm()).item()
+            for got, ref, name in ((dW1, W1r.grad, "dW1"), (db1, b1r.grad, "db1"), (dW2, W2r.grad, "dW2"))}
+    assert all(e < tol for e in errs.values()), f"rel errs {errs}"
