@@ -161,3 +161,69 @@ def ref_hhi_g(args: Namespace, vocab=None) -> nn.Module:
         tpm.CustomDecoderLayer._mha_block = _mha_block
     vocab = vocab or {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
     return tpm.TaskTranslationPromptTransformer(args, vocab)
+
+
+# ---- HOI tree ------------------------------------------------------------------------------------------
+def _install_hoi_stubs():
+    _install_stubs()
+
+    class CfgNode(dict):
+        pass
+
+    try:
+        import fvcore.nn  # noqa: F401
+    except ImportError:
+        _stub_module("fvcore.nn")
+        _stub_module("fvcore.nn.weight_init", c2_msra_fill=lambda m: None, c2_xavier_fill=lambda m: None)
+        sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+        _stub_module("fvcore.common.config", CfgNode=CfgNode)
+    try:
+        import detectron2  # noqa: F401
+    except ImportError:
+        _stub_module("detectron2")
+        _stub_module("detectron2.layers", ROIAlign=lambda *a, **k: nn.Identity())
+
+
+class _FeatPass(nn.Module):
+    """Stands in for a frozen HOI backbone: returns the tensor it is called with, whatever the call protocol."""
+
+    def forward(self, x, *a, **k):
+        return x[0] if isinstance(x, (list, tuple)) else x
+
+
+def hoi_cfg(d=256, heads=8, layers=2, n_clips=4, num_classes=(5, 7), z=3, dropout=0.0):
+    from types import SimpleNamespace as NS
+    return NS(FORECASTING=NS(NUM_INPUT_CLIPS=n_clips, NUM_ACTIONS_TO_PREDICT=z),
+              MODEL=NS(TRANSLATION_HEADS=heads, TRANSLATION_LAYERS=layers, TRANSLATION_INPUT_FEATURES=d,
+                       TRANSLATION_DROPOUT=dropout, NUM_CLASSES=list(num_classes), DROPOUT_RATE=0.0, HEAD_ACT="softmax"),
+              TEST=NS(NO_ACT=False), PRETRAIN=NS(PNR_CFG=None, OSCC_CFG=None),
+              CHECKPOINT_FILE_PATH_AR=None, CHECKPOINT_FILE_PATH_LTA=None)
+
+
+def ref_lta4(cfg) -> nn.Module:
+    """Real reference TaskFusionMFTransformerLTA4Task (HOI/models/lta/lta_models_lta_transfer.py:257): constructors of
+    the four frozen backbones and their checkpoint loaders are patched out; __init__ / forward arithmetic is the
+    reference's. Feed features through forward_features-like call `ref_lta4_forward`."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.lta.lta_models_lta_transfer as m
+    from types import SimpleNamespace as NS
+    m.load_pnr_config = lambda path: NS(MISC=NS(CHECKPOINT_FILE_PATH=None), MODEL=NS(NO_TEMP_POOL=False))
+    m.KeyframeLocalizationResNet = lambda cfg: _FeatPass()
+    m.StateChangeClsResNet = lambda cfg: _FeatPass()
+    m.SlowFast = lambda cfg, with_head=True: _FeatPass()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _FeatPass()
+    m.load_ckpt = lambda *a, **k: None
+    m.load_lta_backbone = lambda *a, **k: None
+    m.freeze_params = lambda *a, **k: None
+    m.freeze_backbone_params = lambda *a, **k: None
+    return m.TaskFusionMFTransformerLTA4Task(cfg)
+
+
+def ref_lta4_forward(model, feat_pnr, feat_oscc, feat_action, feat_lta):
+    """The reference forward() after its backbone calls (lta_models_lta_transfer.py:355-363), on features:
+    pnr/oscc (B, n, 8192), action (B, n, d), lta (B, n, 2048)."""
+    f = torch.cat((model.proj_pnr(feat_pnr), model.proj_oscc(feat_oscc), feat_action, model.proj_lta(feat_lta)), dim=1)
+    f = model.ln(f) + model.pe
+    out = model.transformer(f).mean(dim=1)
+    return model.decode(out)

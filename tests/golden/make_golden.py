@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory by running the REAL reference translator classes
+(/root/reference, imported through oracle/ref_harness.py with import-time stubs only) on seeded weights and
+features. Only runnable where /root/reference exists; the fixtures (inputs are re-derived from seeds, outputs and
+gradient digests are stored) travel with the repo.
+
+    python tests/golden/make_golden.py            # regenerates every *.npz here
+
+Each fixture stores: the config (JSON), the weight/feature seeds, the reference outputs, a scalar loss, and for every
+trainable parameter the gradient's L2 norm, sum and first 64 entries (full gradient when it has <= 4096 entries).
+Weights: tests/util.seeded_state_dict(model, seed); features: tests/util.seeded_feats(seed, shapes).
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+CE_W = [0.266, 0.734]
+
+HHI_CASES = [
+    dict(name="ttm3_B4_T15_L1", kind="ttm", n_tasks=3, B=4, T=15, L=1, d=128, h=4, wseed=11, fseed=12),
+    dict(name="ttm2_B4_T15_L1", kind="ttm", n_tasks=2, B=4, T=15, L=1, d=128, h=4, wseed=21, fseed=22),
+    dict(name="ttm3_B3_T23_L2", kind="ttm", n_tasks=3, B=3, T=23, L=2, d=128, h=4, wseed=31, fseed=32),
+    dict(name="asd3_B3_T15_L2", kind="asd", n_tasks=3, B=3, T=15, L=2, d=128, h=4, wseed=41, fseed=42),
+    dict(name="hhig_B2_T15_L3_d256", kind="hhig", n_tasks=3, B=2, T=15, L=3, d=256, h=4, wseed=51, fseed=52),
+]
+HOI_CASES = [
+    dict(name="lta4_B3_n4_L2_d256", kind="lta4", B=3, n=4, L=2, d=256, h=8, classes=[5, 7], z=3, wseed=61, fseed=62),
+]
+
+
+def sd_keys(m):
+    return json.dumps({k: list(v.shape) for k, v in m.state_dict().items()})
+
+
+def digest(grads, out):
+    for k, g in grads.items():
+        g = g.detach().double().reshape(-1)
+        out[f"gnorm/{k}"] = g.norm().numpy()
+        out[f"gsum/{k}"] = g.sum().numpy()
+        out[f"ghead/{k}"] = (g if g.numel() <= 4096 else g[:64]).float().numpy()
+
+
+def run_hhi():
+    import numpy as np
+    import torch
+    from oracle import ref_harness as rh
+    from tests.util import seeded_feats, seeded_state_dict
+    for c in HHI_CASES:
+        args = rh.hhi_args(hidden_dim=c["d"], num_heads=c["h"], dropout=0.0, num_layers=c["L"])
+        if c["kind"] == "ttm":
+            m = rh.ref_ttm(c["n_tasks"], args)
+        elif c["kind"] == "asd":
+            m = rh.ref_asd(args)
+        else:
+            m = rh.ref_hhi_g(args)
+        m.load_state_dict(seeded_state_dict(m, c["wseed"]))
+        m.train()
+        m.pos_embed.dropout.p = 0.0
+        feats = seeded_feats(c["fseed"], [(c["B"], c["T"], 256)] * c["n_tasks"])  # order: ttm, lam[, asd]
+        out = {"config": np.array(json.dumps(c)), "sd_keys": np.array(sd_keys(m))}
+        if c["kind"] == "ttm":
+            logits = rh.ref_ttm_forward(m, *feats)
+            target = torch.from_numpy(np.random.default_rng(c["fseed"]).integers(0, 2, c["B"])).long()
+            loss = torch.nn.functional.cross_entropy(logits, target, weight=torch.tensor(CE_W))
+            out["out"] = logits.detach().numpy()
+            out["target"] = target.numpy()
+        elif c["kind"] == "asd":
+            B, T = c["B"], c["T"]
+            y = m(feats[1], torch.zeros(B, T, 1, 1), feats[0], feats[2])    # (B*T, d): video->lam, audio->ttm, audio_asd->asd
+            loss = (y * torch.linspace(-1, 1, y.numel()).view_as(y)).sum()
+            out["out"] = y.detach().numpy()
+        else:
+            B, T = c["B"], c["T"]
+            loss = 0
+            for task in ("lam", "ttm", "asd"):
+                lamf = feats[1][:, :7] if task == "lam" else feats[1]
+                enc = m.encode(lamf, torch.zeros(B, T, 1, 1), feats[0], feats[2], task)   # video->lam, audio->ttm, audio_asd->asd
+                out[f"out_{task}"] = enc.detach().numpy()
+                loss = loss + (enc * torch.linspace(-1, 1, enc.numel()).view_as(enc)).sum()
+        m.zero_grad()
+        loss.backward()
+        out["loss"] = loss.detach().numpy()
+        digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, out)
+        np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **out)
+        print("wrote", c["name"], "loss", float(loss))
+
+
+def run_hoi():
+    import numpy as np
+    import torch
+    from oracle import ref_harness as rh
+    from tests.util import seeded_feats, seeded_state_dict
+    for c in HOI_CASES:
+        cfg = rh.hoi_cfg(d=c["d"], heads=c["h"], layers=c["L"], n_clips=c["n"], num_classes=c["classes"], z=c["z"])
+        m = rh.ref_lta4(cfg)
+        m.load_state_dict(seeded_state_dict(m, c["wseed"]))
+        m.train()
+        B, n, d = c["B"], c["n"], c["d"]
+        feats = seeded_feats(c["fseed"], [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
+        outs = rh.ref_lta4_forward(m, *feats)
+        loss = sum((o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for o in outs)
+        m.zero_grad()
+        loss.backward()
+        out = {"config": np.array(json.dumps(c)), "sd_keys": np.array(sd_keys(m)), "loss": loss.detach().numpy(),
+               "out_verb": outs[0].detach().numpy(), "out_noun": outs[1].detach().numpy()}
+        digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, out)
+        np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **out)
+        print("wrote", c["name"], "loss", float(loss))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        {"hhi": run_hhi, "hoi": run_hoi}[sys.argv[1]]()
+    else:  # HHI and HOI share top-level package names -> one process per tree
+        for tree in ("hhi", "hoi"):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), tree])

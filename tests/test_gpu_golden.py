@@ -1,0 +1,51 @@
+"""-m gpu: the HIP translator classes against the golden fixtures generated from the REAL reference (outputs and
+gradient digests), through the C ABI of libegot2x.so. fp32: outputs within 1e-3, gradients within 1e-2 relative
+(BASELINE.json:north_star); bf16: 1e-2 / 1e-1."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_golden import (CE_W, FIXTURES, build_ours, check_against_fixture, fixture_feats, load_fixture)
+from tests.util import seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_run(c, model, feats):
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device).view_as(t)).sum()  # noqa: E731
+    if c["kind"] == "ttm":
+        out = model.forward_features(*feats)
+        target = torch.from_numpy(np.random.default_rng(c["fseed"]).integers(0, 2, c["B"])).long().to(out.device)
+        return {"out": out}, torch.nn.functional.cross_entropy(out, target, weight=torch.tensor(CE_W, device=out.device))
+    if c["kind"] == "asd":
+        out = model.forward_features(*feats)
+        return {"out": out}, lin(out)
+    if c["kind"] == "hhig":
+        outs, loss = {}, 0
+        for task in ("lam", "ttm", "asd"):
+            lamf = feats[1][:, :7].contiguous() if task == "lam" else feats[1]
+            enc = model.encode_features(task, lamf, feats[0], feats[2])
+            outs[f"out_{task}"] = enc
+            loss = loss + lin(enc)
+        return outs, loss
+    if c["kind"] == "lta4":
+        o = model.forward_features(*feats)
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
+    raise KeyError(c["kind"])
+
+
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 1e-1)])
+@pytest.mark.parametrize("name", FIXTURES)
+def test_hip_matches_reference_fixture(egx_lib, cuda, name, compute, tol_out, tol_grad):
+    c, z = load_fixture(name)
+    model = build_ours(c)
+    model.load_state_dict(seeded_state_dict(model, c["wseed"]))
+    model = model.to(cuda).set_compute(compute).train()
+    if hasattr(model, "pos_embed"):
+        model.pos_embed.dropout.p = 0.0
+    feats = [f.to(cuda) for f in fixture_feats(c)]
+    outs, loss = hip_run(c, model, feats)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    check_against_fixture(z, outs, loss, grads, tol_out, tol_grad)

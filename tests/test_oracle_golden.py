@@ -1,0 +1,147 @@
+"""CPU suite: the oracle restatement (oracle/translator_ref.py) and the stock-module CPU baseline against the golden
+fixtures generated from the REAL reference classes (tests/golden/make_golden.py), plus — when /root/reference is
+present — a live comparison against the imported reference."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import translator_ref as tr
+from tests.util import hhi_args, seeded_feats, seeded_state_dict
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CE_W = [0.266, 0.734]
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return json.loads(str(z["config"])), z
+
+
+def build_ours(c):
+    """Our (HIP-backed) module for a fixture config — used here only as the parameter container."""
+    from types import SimpleNamespace as NS
+    if c["kind"] == "ttm":
+        from egot2_amd import hhi_ttm
+        cls = hhi_ttm.TaskFusionMFTransformer3Task if c["n_tasks"] == 3 else hhi_ttm.TaskFusionMFTransformer2Task
+        return cls(hhi_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
+    if c["kind"] == "asd":
+        from egot2_amd import hhi_asd
+        return hhi_asd.TaskFusionMFTransformer3Task(hhi_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
+    if c["kind"] == "hhig":
+        from egot2_amd import hhi_multitask
+        vocab = {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+        return hhi_multitask.TaskTranslationPromptTransformer(hhi_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]), vocab)
+    if c["kind"] == "lta4":
+        from egot2_amd import hoi_lta
+        cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=c["n"], NUM_ACTIONS_TO_PREDICT=c["z"]),
+                 MODEL=NS(TRANSLATION_HEADS=c["h"], TRANSLATION_LAYERS=c["L"], TRANSLATION_INPUT_FEATURES=c["d"],
+                          TRANSLATION_DROPOUT=0.0, NUM_CLASSES=c["classes"], DROPOUT_RATE=0.0, HEAD_ACT="softmax"),
+                 TEST=NS(NO_ACT=False))
+        return hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+    raise KeyError(c["kind"])
+
+
+def fixture_feats(c):
+    if c["kind"] == "lta4":
+        B, n, d = c["B"], c["n"], c["d"]
+        return seeded_feats(c["fseed"], [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
+    return seeded_feats(c["fseed"], [(c["B"], c["T"], 256)] * c["n_tasks"])
+
+
+def oracle_run(c, sd, feats, dtype=torch.float64):
+    """Outputs dict + scalar loss (same loss definitions as make_golden.py) from the oracle restatement."""
+    sdd = {k: v.to(dtype).requires_grad_(v.is_floating_point() and not k.endswith("pos_embed.pe")) for k, v in sd.items()}
+    f = [t.to(dtype) for t in feats]
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel()).to(dtype).view_as(t)).sum()  # noqa: E731
+    if c["kind"] == "ttm":
+        out = tr.ttm_forward(sdd, c["h"], *f)
+        target = torch.from_numpy(np.random.default_rng(c["fseed"]).integers(0, 2, c["B"])).long()
+        return {"out": out}, tr.weighted_ce(out, target, CE_W), sdd
+    if c["kind"] == "asd":
+        out = tr.asd_forward(sdd, c["h"], f[0], f[1], f[2])
+        return {"out": out}, lin(out), sdd
+    if c["kind"] == "hhig":
+        outs, loss = {}, 0
+        for task in ("lam", "ttm", "asd"):
+            lamf = f[1][:, :7] if task == "lam" else f[1]
+            enc = tr.hhi_g_encode(sdd, c["h"], task, lamf, f[0], f[2])
+            outs[f"out_{task}"] = enc
+            loss = loss + lin(enc)
+        return outs, loss, sdd
+    if c["kind"] == "lta4":
+        o = tr.lta4_forward(sdd, c["h"], *f, c["classes"])
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
+    raise KeyError(c["kind"])
+
+
+FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def check_against_fixture(z, outs, loss, grads, tol_out, tol_grad):
+    for k, v in outs.items():
+        ref = torch.from_numpy(z[k]).double()
+        err = (v.detach().double().cpu() - ref).abs().max().item()
+        assert err < tol_out * max(1.0, ref.abs().max().item()), f"{k}: max err {err}"
+    ref_loss = float(z["loss"])
+    assert abs(float(loss) - ref_loss) < tol_out * max(1.0, abs(ref_loss)) * 10, f"loss {float(loss)} vs {ref_loss}"
+    gkeys = [k[len("gnorm/"):] for k in z.files if k.startswith("gnorm/")]
+    assert set(gkeys) == set(grads), f"gradient key mismatch: {set(gkeys) ^ set(grads)}"
+    for k in gkeys:
+        g = grads[k].detach().double().cpu().reshape(-1)
+        n_ref = float(z["gnorm/" + k])
+        head = torch.from_numpy(z["ghead/" + k]).double()
+        e_head = (g[:head.numel()] - head).norm().item() / (head.norm().item() + 1e-12 + 1e-6 * n_ref)
+        e_norm = abs(g.norm().item() - n_ref) / (n_ref + 1e-12)
+        assert e_norm < tol_grad and e_head < 3 * tol_grad, f"{k}: norm err {e_norm}, head err {e_head}"
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_matches_reference_fixture(name):
+    c, z = load_fixture(name)
+    model = build_ours(c)
+    ref_keys = json.loads(str(z["sd_keys"]))
+    ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert ours == ref_keys, "state_dict keys/shapes differ from the reference module"
+    sd = seeded_state_dict(model, c["wseed"])
+    outs, loss, sdd = oracle_run(c, sd, fixture_feats(c), torch.float64)
+    loss.backward()
+    grads = {k: v.grad for k, v in sdd.items() if v.grad is not None}
+    check_against_fixture(z, outs, loss, grads, tol_out=2e-5, tol_grad=2e-4)
+
+
+def test_stock_module_matches_fixture():
+    """The CPU-baseline module (oracle/stock_module.py) is the reference class minus backbones."""
+    from oracle.stock_module import StockTTMTranslator
+    c, z = load_fixture("ttm3_B4_T15_L1")
+    m = StockTTMTranslator(3, c["d"], c["h"], dropout=0.0, num_layers=c["L"])
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == json.loads(str(z["sd_keys"]))
+    m.load_state_dict(seeded_state_dict(m, c["wseed"]))
+    m.train()
+    m.pos_embed.dropout.p = 0.0
+    feats = fixture_feats(c)
+    logits = m(*feats)
+    target = torch.from_numpy(np.random.default_rng(c["fseed"]).integers(0, 2, c["B"])).long()
+    loss = torch.nn.functional.cross_entropy(logits, target, weight=torch.tensor(CE_W))
+    loss.backward()
+    check_against_fixture(z, {"out": logits}, loss, {k: p.grad for k, p in m.named_parameters()}, 2e-5, 2e-4)
+
+
+@pytest.mark.reference
+def test_oracle_matches_live_reference():
+    """Where /root/reference exists: import the real class and compare on fresh seeds (not only the stored ones)."""
+    from oracle import ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("/root/reference not present")
+    m = rh.ref_ttm(3, rh.hhi_args(num_layers=2))
+    m.load_state_dict(seeded_state_dict(m, 777))
+    m.eval()
+    feats = seeded_feats(778, [(5, 17, 256)] * 3)
+    with torch.no_grad():
+        ref = rh.ref_ttm_forward(m, *feats)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    out = tr.ttm_forward(sd, 4, *feats)
+    assert (out - ref).abs().max().item() < 1e-5

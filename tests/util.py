@@ -17,21 +17,24 @@ def seeded_feats(seed, shapes):
 
 
 def seeded_state_dict(model, seed, scale=None):
-    """Deterministic weights independent of torch's RNG: every floating tensor of the state_dict except the
-    sinusoid buffer is redrawn from PCG64 with a fan-in style scale; LayerNorm weights around 1."""
-    rng = np.random.default_rng(seed)
+    """Deterministic weights independent of torch's RNG and of state_dict ordering: every floating tensor except
+    the sinusoid buffer is drawn from PCG64 seeded by (seed, crc32(key)) with a fan-in style scale; LayerNorm
+    weights around 1."""
+    import zlib
     sd = {}
     for k, v in model.state_dict().items():
         if k.endswith("pos_embed.pe") or not v.is_floating_point():
             sd[k] = v.clone()
             continue
+        rng = np.random.default_rng([seed, zlib.crc32(k.encode())])
         a = rng.standard_normal(tuple(v.shape), dtype=np.float32)
-        if v.dim() >= 2 and "task_embed" not in k and k != "pe":
-            a *= (1.0 / np.sqrt(v.shape[-1]))
-        elif ("norm" in k or k.startswith("ln.") or k.endswith("linear_head.0.weight")) and k.endswith("weight"):
+        is_norm = ("norm" in k or k.startswith("ln.") or k.endswith("linear_head.0.weight") or k.endswith("linear_head.0.bias"))
+        if is_norm and k.endswith("weight"):
             a = 1.0 + 0.1 * a
         elif k.endswith("bias"):
             a *= 0.1
+        elif v.dim() >= 2 and "task_embed" not in k and k != "pe" and "embedding" not in k:
+            a *= (1.0 / np.sqrt(v.shape[-1]))
         sd[k] = torch.from_numpy(a.astype(np.float32))
     return sd
 
