@@ -158,8 +158,11 @@ class EncoderFn(torch.autograd.Function):
             for k, name in enumerate(_LAYER_FIELDS):
                 setattr(layers[l], name, ptr(layer_t[12 * l + k]))
 
-        if spec.impl == "auto" and torch.is_grad_enabled() and (
-                (pos_table is not None and pos_table.requires_grad) or any(f.requires_grad for f in rest[:nseg])):
+        # NB: grad mode is off inside Function.forward; ctx.needs_input_grad is the reliable signal.
+        # needs_input_grad order: (spec, task_embed, pos_table, ln_w, ln_b, *rest)
+        nig = ctx.needs_input_grad
+        needs_grad = any(nig)
+        if spec.impl == "auto" and (nig[2] or any(nig[5:5 + nseg])):
             # the fused backward emits no positional-table / feature gradients: keep the generic kernels
             import dataclasses
             spec = dataclasses.replace(spec, impl="generic")
@@ -168,8 +171,6 @@ class EncoderFn(torch.autograd.Function):
         check(lib.egx_encoder_workspace(C.byref(cfg), segs, B, C.byref(sv), C.byref(sc)))
         S = sum(s.T for s in spec.segments)
         tokens = torch.empty((B, S, d), dtype=torch.float32, device=device)
-        needs_grad = torch.is_grad_enabled() and any(
-            isinstance(t, torch.Tensor) and t.requires_grad for t in (task_embed, pos_table, ln_w, ln_b) + tuple(rest))
         if needs_grad:
             saved = torch.empty(max(sv.value, 256), dtype=torch.uint8, device=device)
         else:
