@@ -134,7 +134,7 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = measure_roofline(torch, lib, dev, B * K * T, d, dff, args.dtype)
+        out["roofline"] = measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, args.dtype)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle.stock_module import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)
@@ -145,30 +145,40 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(torch, lib, dev, N, d, dff, dtype):
-    """Dominant kernel of the generic path: the FFN GEMMs (87 % of FLOPs). Times the FFN1 forward GEMM
-    [N x d] x [dff x d]^T launch with device events on the stream it is launched on."""
-    x = torch.randn(N, d, device=dev)
-    w = torch.randn(dff, d, device=dev) * 0.05
-    b = torch.zeros(dff, device=dev)
-    y = torch.empty(N, dff, device=dev)
-    comp = 0 if dtype == "f32" else 1
-    st = torch.cuda.current_stream().cuda_stream
-    for _ in range(5):
-        lib.egx_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, dff, d, 1, comp, st)
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
+    """Dominant kernel = fused_bwd_kernel (the per-clip backward: LayerNorm/attention/projection input gradients and the
+    FFN input gradient with H recomputed). Its ALGORITHMIC FLOPs per launch are the dX-type GEMMs of the backward
+    (BASELINE.md §2 accounting, recompute NOT counted): L * (2N d 3d + 2N d^2 + 4N d d_ff + 8 B S^2 d).
+    Average launch duration is measured live with hipEvents recorded on the launch stream (egx_timing_*)."""
+    import ctypes as C
+    S = K * T
+    N = B * S
+    flops = {
+        "fused_bwd_kernel": L * (2.0 * N * d * 3 * d + 2.0 * N * d * d + 4.0 * N * d * dff + 8.0 * B * S * S * d),
+        "fused_fwd_kernel": K * 2.0 * B * T * 256 * d + L * (2.0 * N * d * 3 * d + 4.0 * B * S * S * d + 2.0 * N * d * d + 4.0 * N * d * dff),
+        "ffn_dw_kernel": L * 4.0 * N * d * dff,
+    }
+    lib.egx_timing_enable(1)
+    reps = 16
     for _ in range(reps):
-        lib.egx_linear_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), N, dff, d, 1, comp, st)
-    e1.record()
+        step()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / reps * 1e-3
-    flops = 2.0 * N * d * dff
-    ach = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "gemm_kernel<128,128,NT> (FFN linear1 forward)", "achieved": ach,
-            "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
-            "flops_per_launch": flops, "avg_launch_us": t * 1e6}
+    res = {}
+    for which, name in enumerate(("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel")):
+        tot, cnt = C.c_double(0), C.c_int(0)
+        if lib.egx_timing_read(which, C.byref(tot), C.byref(cnt)) == 0 and cnt.value:
+            res[name] = tot.value / cnt.value * 1e-3
+    lib.egx_timing_enable(0)
+    if "fused_bwd_kernel" not in res:   # generic path (shape outside the fused kernels)
+        return {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+                "frac": None, "traffic": None}
+    t = res["fused_bwd_kernel"]
+    ach = flops["fused_bwd_kernel"] / t / 1e12
+    return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": PEAK_TFLOPS[dtype],
+            "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
+            "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
+            "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
+                                  "frac": flops[k] / v / 1e12 / PEAK_TFLOPS[dtype]} for k, v in res.items() if k != "fused_bwd_kernel"}}
 
 
 if __name__ == "__main__":

@@ -69,6 +69,8 @@ SIGNATURES = {
     "egx_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
     "egx_debug_stamps": (C.c_int, [_fp, C.c_int]),
+    "egx_timing_enable": (None, [C.c_int]),
+    "egx_timing_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "egx_ffn_dw_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_ffn_dw": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp, _fp, _fp,
                              C.c_int, _fp, _fp]),

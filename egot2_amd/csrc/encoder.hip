@@ -244,7 +244,9 @@ using namespace egx;
 extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
-int egx_debug_stamps(unsigned long long* out, int n) { return debug_read_stamps(out, n); }
+int egx_debug_stamps(unsigned long long* out, int n) { return n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n); }
+void egx_timing_enable(int on) { timing_enable(on); }
+int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }
 
 // Unit-test hook for the fused FFN weight-gradient kernel. scratch: packed W1 + packed W2^T + slabs.
 size_t egx_ffn_dw_scratch(int N, int d_ff, int compute) {
@@ -482,12 +484,28 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
                     fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st)) return 1;
                 }
-                if (gw.out_proj_w && linear_dw(bp.layer[l].g1_out, bp.layer[l].attn_o_out, gw.out_proj_w, N, d, d, comp, slab, SC.slab_bytes, st)) return 1;
-                if (gw.in_proj_w && linear_dw(bp.layer[l].dqkv_out, bp.layer[l].x_in_out, gw.in_proj_w, N, 3 * d, d, comp, slab, SC.slab_bytes, st)) return 1;
             }
-            for (int i = 0; i < pl.nseg; ++i)
-                if (seg_grads && seg_grads[i].proj_w &&
-                    linear_dw(bp.dseg_out[i], segs[i].feat, seg_grads[i].proj_w, B * segs[i].T, d, segs[i].d_in, comp, slab, SC.slab_bytes, st)) return 1;
+            // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches
+            {
+                SmallDwParams sp;
+                memset(&sp, 0, sizeof(sp));
+                auto flush = [&]() -> int { int rc = sp.n ? small_dw(sp, comp, st) : 0; memset(&sp, 0, sizeof(sp)); return rc; };
+                auto add = [&](const float* G, int ldg, const float* X, int ldx, float* out, int R, int Cc, int K) -> int {
+                    if (!out) return 0;
+                    if (sp.n == SMALL_DW_MAX && flush()) return 1;
+                    SmallDwProblem& q = sp.pr[sp.n++];
+                    q.G = G; q.X = X; q.out = out; q.R = R; q.C = Cc; q.K = K; q.ldg = ldg; q.ldx = ldx;
+                    return 0;
+                };
+                for (int l = 0; l < pl.L; ++l) {
+                    const egx_layer_grads& gw = layer_grads[l];
+                    if (add(bp.layer[l].g1_out, d, bp.layer[l].attn_o_out, d, gw.out_proj_w, d, d, N)) return 1;
+                    if (add(bp.layer[l].dqkv_out, 3 * d, bp.layer[l].x_in_out, d, gw.in_proj_w, 3 * d, d, N)) return 1;
+                }
+                for (int i = 0; i < pl.nseg; ++i)
+                    if (seg_grads && add(bp.dseg_out[i], d, segs[i].feat, segs[i].d_in, seg_grads[i].proj_w, d, segs[i].d_in, B * segs[i].T)) return 1;
+                if (flush()) return 1;
+            }
             return 0;
         }
         if (ferr) return 1;

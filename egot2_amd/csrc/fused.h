@@ -104,6 +104,18 @@ struct FusedBwdParams {
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 
+// One "dW[R][C] += G^T X" problem of the grouped small-weight-gradient kernel: G (K, R) and X (K, C) token-major.
+struct SmallDwProblem {
+    const float* G; const float* X; float* out;
+    int R, C, K, ldg, ldx, first_item;
+};
+constexpr int SMALL_DW_MAX = 8;
+struct SmallDwParams {
+    SmallDwProblem pr[SMALL_DW_MAX];
+    int n, items, splits;
+};
+int small_dw(SmallDwParams& p, int compute, hipStream_t st);
+
 struct PartialDst { float* dst; int off, len; };
 constexpr int PARTIAL_MAX_DST = 48;
 struct ReducePartialsParams {
@@ -113,9 +125,17 @@ struct ReducePartialsParams {
 };
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st);
 
+// Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.
+enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_COUNT = 3 };
+void timing_enable(int on);
+void timing_begin(int which, hipStream_t st);
+void timing_end(int which, hipStream_t st);
+int timing_read(int which, double* total_ms, int* count);
+
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);
 size_t fused_lds_bytes(int NT);
 int debug_read_stamps(unsigned long long* out, int n);
+int debug_read_bstamps(unsigned long long* out, int n);
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st);
 
 }  // namespace egx

@@ -84,10 +84,18 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     float* X1 = Vt + FD * LDV;                  // [SP][LDX] res1 / x1
     float* Part = Qs;                           // FFN partials 1..3 alias Q/K/Vt (needs 3*SP*LDX <= 2*SP*LDX + FD*LDV)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int clip = blockIdx.x;
     const int S = p.S;
+    // keep lane-constant fragment addresses local to their phase (hipcc otherwise hoists them all to kernel entry
+    // and spills them around the phases)
+#define EGX_PHASE()                                              \
+    do {                                                         \
+        int t_ = threadIdx.x;                                    \
+        asm volatile("" : "+v"(t_));                             \
+        lane = t_ & 63; r = lane & 15; q = lane >> 4;            \
+    } while (0)
 
     STAMP(0);
     // zero the padded rows once so that padded tokens stay finite everywhere
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
 
         STAMP(2);
+        EGX_PHASE();
         // ---- QKV projection: 24 feature tiles, 6 per wave, K = 128
         {
 #pragma unroll
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
 
         STAMP(3);
+        EGX_PHASE();
         // ---- attention: wave = head. S^T = K Q^T (key rows, query columns), softmax over rows, O^T = V^T P^T
         {
             const int h = wave;
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
 
         STAMP(4);
+        EGX_PHASE();
         // ---- out-projection + residual -> res1 (X1 region), 2 feature tiles per wave
         {
             f32x4 acc[2][NT];
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
 
         STAMP(6);
+        EGX_PHASE();
         // ---- FFN: hidden blocks of 32 split across waves; H^T = relu(W1 x1^T + b1) chained into Y^T += W2 H^T
         {
             // x1 as B operand: resident in registers for bf16 (48 VGPRs); re-read from LDS per hidden block in fp32,
@@ -553,6 +565,41 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     }
 }
 
+// ---- optional device timing ----------------------------------------------------------------------------
+namespace {
+struct TimerSlot { hipEvent_t a[64], b[64]; int n = 0; bool made = false; };
+TimerSlot g_timers[TIMER_COUNT];
+int g_timing_on = 0;
+}
+void timing_enable(int on) {
+    g_timing_on = on;
+    for (int i = 0; i < TIMER_COUNT; ++i) g_timers[i].n = 0;
+}
+void timing_begin(int which, hipStream_t st) {
+    if (!g_timing_on) return;
+    TimerSlot& t = g_timers[which];
+    if (!t.made) { for (int i = 0; i < 64; ++i) { (void)hipEventCreate(&t.a[i]); (void)hipEventCreate(&t.b[i]); } t.made = true; }
+    if (t.n < 64) (void)hipEventRecord(t.a[t.n], st);
+}
+void timing_end(int which, hipStream_t st) {
+    if (!g_timing_on) return;
+    TimerSlot& t = g_timers[which];
+    if (t.n < 64) { (void)hipEventRecord(t.b[t.n], st); ++t.n; }
+}
+int timing_read(int which, double* total_ms, int* count) {
+    if (which < 0 || which >= TIMER_COUNT) return 1;
+    TimerSlot& t = g_timers[which];
+    double tot = 0;
+    for (int i = 0; i < t.n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.b[i]) != hipSuccess || hipEventElapsedTime(&ms, t.a[i], t.b[i]) != hipSuccess) return 1;
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (count) *count = t.n;
+    return 0;
+}
+
 size_t fused_lds_bytes(int NT) {
     int SP = NT * 16;
     return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float);
@@ -584,7 +631,9 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             attr_set = true;                                                                                     \
         }                                                                                                        \
+        timing_begin(TIMER_FUSED_FWD, st);                                                                       \
         hipLaunchKernelGGL((fused_fwd_kernel<BF16, N>), grid, block, lds, st, p);                                \
+        timing_end(TIMER_FUSED_FWD, st);                                                                         \
     } break;
     switch (NT) {
         EGX_FWD_CASE(3)

@@ -218,7 +218,9 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(p.d_ff / (64 * HT), p.splits);
+    timing_begin(TIMER_FFN_DW, st);
     hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
+    timing_end(TIMER_FFN_DW, st);
     EGX_LAUNCH_CHECK();
     return 0;
 }
@@ -251,6 +253,109 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     return 0;
 }
 
+// ---- grouped small weight gradients ------------------------------------------------------------------------
+// dW_in, dW_o and the K projection gradients are "G^T X" reductions over all tokens with tiny outputs; as five
+// separate split-K GEMMs they cost 15 us each in launch/prologue latency. One launch covers them all: a work item
+// is (problem, 64-row group, 128-column half); grid.y splits the tokens. Per 32-token K-block the block stages
+// G[32][64] and X[32][128] in LDS (coalesced, next block prefetched in registers); wave w owns rows 16w..16w+15 and
+// gathers its A fragment (and the 8 B fragments) transposed from the token-major tiles. Partials are atomically
+// added into the zero-initialised gradient buffers (<= `splits` adders per element).
+template <bool BF16>
+__global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
+    constexpr int LDG = 64 + 4, LDXS = 128 + 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LDG + 32 * LDXS)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    int pi = 0;
+    while (pi + 1 < p.n && (int)blockIdx.x >= p.pr[pi + 1].first_item) ++pi;
+    const SmallDwProblem& pr = p.pr[pi];
+    const int item = blockIdx.x - pr.first_item;
+    const int ncol = (pr.C + 127) / 128;
+    const int row0 = (item / ncol) * 64, col0 = (item % ncol) * 128;
+    const int nkb = (pr.K + 31) / 32;
+    const int per = (nkb + p.splits - 1) / p.splits;
+    const int kb_beg = blockIdx.y * per, kb_end = min(nkb, kb_beg + per);
+    if (kb_beg >= kb_end) return;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4{0, 0, 0, 0};
+    float4 pg[2], px[4];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int f = tid + i * 256, row = f >> 4, c4 = (f & 15) << 2;
+            int n = kb * 32 + row, c = row0 + c4;
+            pg[i] = (n < pr.K && c < pr.R) ? *reinterpret_cast<const float4*>(pr.G + (size_t)n * pr.ldg + c) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int f = tid + i * 256, row = f >> 5, c4 = (f & 31) << 2;
+            int n = kb * 32 + row, c = col0 + c4;
+            px[i] = (n < pr.K && c < pr.C) ? *reinterpret_cast<const float4*>(pr.X + (size_t)n * pr.ldx + c) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](float* gt, float* xt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { int f = tid + i * 256; *reinterpret_cast<float4*>(gt + (f >> 4) * LDG + ((f & 15) << 2)) = pg[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int f = tid + i * 256; *reinterpret_cast<float4*>(xt + (f >> 5) * LDXS + ((f & 31) << 2)) = px[i]; }
+    };
+    gload(kb_beg);
+    int cur = 0;
+    for (int kb = kb_beg; kb < kb_end; ++kb) {
+        float* gt = lds + cur * (32 * LDG + 32 * LDXS);
+        float* xt = gt + 32 * LDG;
+        lstore(gt, xt);
+        __syncthreads();
+        if (kb + 1 < kb_end) gload(kb + 1);
+        Frag<BF16> a = gather_frag<BF16>(gt, wave * 16 + r, 0, q, 31, LDG);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Frag<BF16> b = gather_frag<BF16>(xt, j * 16 + r, 0, q, 31, LDXS);
+            mma<BF16>(acc[j], a, b);
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int row = row0 + wave * 16 + 4 * q + e, col = col0 + j * 16 + r;
+            if (row < pr.R && col < pr.C) atomicAdd(pr.out + (size_t)row * pr.C + col, acc[j][e]);
+        }
+}
+
+int small_dw(SmallDwParams& p, int compute, hipStream_t st) {
+    int items = 0, maxk = 1;
+    for (int i = 0; i < p.n; ++i) {
+        EGX_CHECK(p.pr[i].R % 4 == 0 && p.pr[i].C % 4 == 0 && p.pr[i].ldg % 4 == 0 && p.pr[i].ldx % 4 == 0,
+                  "small_dw: problem %d needs 4-aligned dimensions", i);
+        p.pr[i].first_item = items;
+        items += cdiv(p.pr[i].R, 64) * cdiv(p.pr[i].C, 128);
+        maxk = max(maxk, p.pr[i].K);
+    }
+    if (!items) return 0;
+    p.items = items;
+    int nkb = cdiv(maxk, 32);
+    p.splits = max(1, min(nkb / 4, 512 / items));
+    dim3 grid(items, p.splits);
+    if (compute == 1) hipLaunchKernelGGL(small_dw_kernel<true>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(small_dw_kernel<false>, grid, dim3(256), 0, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ unsigned long long g_bstamps[32];
+#ifdef EGX_STAMPS
+#define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+int debug_read_bstamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamps), sizeof(unsigned long long) * (n > 32 ? 32 : n)) == hipSuccess ? 0 : 1;
+}
+
 // ---- per-clip backward --------------------------------------------------------------------------------
 // One workgroup per clip. Six token-major LDS blocks (48 x 132 fp32 each) are rotated through the roles noted at
 // each phase; small per-head softmax statistics live behind them. Everything that another kernel needs
@@ -269,12 +374,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     float* B5 = lds + 5 * BLK;
     float* stat = lds + 6 * BLK;     // [FH][3][SP] softmax max / 1/sum / delta per query
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int clip = blockIdx.x;
     const int S = p.S;
     const size_t tok0 = (size_t)clip * S;
     float* part = p.partials + (size_t)clip * p.P;
+    // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
+    // the phases (1 KB of scratch per lane). Re-deriving the lane indices behind an opaque asm at each phase start
+    // keeps address arithmetic local to the phase that needs it.
+#define EGX_PHASE()                                              \
+    do {                                                         \
+        int t_ = threadIdx.x;                                    \
+        asm volatile("" : "+v"(t_));                             \
+        lane = t_ & 63; r = lane & 15; q = lane >> 4;            \
+    } while (0)
 
     auto load_block = [&](float* dst, const float* src) {     // (S, 128) global -> token-major LDS, coalesced
         for (int i = tid; i < S * (FD / 4); i += 256) {
@@ -292,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
         float* pl = part + l * FUSED_P_LAYER;
 
+        BSTAMP(0);
         // P1: res2 -> B1
         load_block(B1, sv_res2);
         __syncthreads();
@@ -310,6 +425,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(w.g2_out + (tok0 + row) * FD + c0, dx);
             });
         __syncthreads();
+        BSTAMP(1);
         // P3: column sums (norm2_w, norm2_b, lin2_b partials); res1 -> B4 and LayerNorm1 forward in place (x1)
         if (tid < 128) {
             pl[0 + tid] = colsum_lds(B3, 0, S, tid);
@@ -325,6 +441,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         });
         __syncthreads();
 
+        BSTAMP(2);
+        EGX_PHASE();
         // P4: FFN input gradient. H^T = relu(W1 x1^T + b1); dH^T = (W2^T g2^T) .* mask; dX1^T += W1^T dH^T
         {
             constexpr bool XRES = BF16;
@@ -368,8 +486,6 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             issue_a(hb_of(0));
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
-                issue_b(hb);
-                __builtin_amdgcn_sched_barrier(0);
                 pin_all(w1r); pin_all(w2r);
                 f32x4 hacc[2][NT], dacc[2][NT];
 #pragma unroll
@@ -397,10 +513,11 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     }
                 }
                 float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
+                // W1 / W2^T fragments are dead now: fetch W1^T (its latency overlaps the mask/dropout VALU work below);
+                // holding all three weight sets at once overflowed the 256 arch VGPRs and spilled to scratch.
                 __builtin_amdgcn_sched_barrier(0);
-                if (it + 1 < nit) issue_a(hb_of(it + 1));
+                issue_b(hb);
                 __builtin_amdgcn_sched_barrier(0);
-                pin_all(w3r);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -421,6 +538,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 Frag<BF16> dq_[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<BF16>(dacc[0][t], dacc[1][t]);
+                __builtin_amdgcn_sched_barrier(0);
+                pin_all(w3r);
+                if (it + 1 < nit) issue_a(hb_of(it + 1));   // next block's W1 / W2^T stream in under the dX GEMM
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     Frag<BF16> a = w_frag<BF16>(w3r[i]);
@@ -428,6 +549,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int t = 0; t < NT; ++t) mma<BF16>(dxa[i][t], a, dq_[t]);
                 }
             }
+        BSTAMP(3);
             // deterministic cross-wave sum into Gs (dY is dead): wave 0 stores, waves 1..3 add in turn
             for (int round = 0; round < 4; ++round) {
                 if (wave == round) {
@@ -444,6 +566,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 __syncthreads();
             }
         }
+        BSTAMP(4);
         // P5: res1 -> B3; LayerNorm1 backward with dy = dX1 (Gs) + d_res2 (B1).
         load_block(B3, sv_res1);
         __syncthreads();
@@ -469,6 +592,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(w.g1_out + (tok0 + row) * FD + c0, dx);
             });
         __syncthreads();
+        BSTAMP(5);
         // P6: column sums (norm1_w, norm1_b, out_proj_b)
         if (tid < 128) {
             pl[384 + tid] = colsum_lds(B4, 0, S, tid);
@@ -476,6 +600,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         } else {
             pl[512 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
         }
+        EGX_PHASE();
         // P7: out-projection input gradient dO^T = W_o^T g1^T -> B3 (token-major)
         __syncthreads();
         {
@@ -492,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     *reinterpret_cast<float4*>(B3 + (t * 16 + r) * LDX + (wave * 2 + i) * 16 + 4 * q) =
                         make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
         }
+        BSTAMP(6);
         // P8: recompute the layer input x_in -> Gs
         if (l == 0) {
             load_block(Gs, p.saved_pre + tok0 * FD);
@@ -528,6 +654,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             });
         }
         __syncthreads();
+        BSTAMP(7);
+        EGX_PHASE();
         // P9: QKV recompute: Q -> B4, K -> B5, V -> Gs (written after the barrier: Gs is this GEMM's B operand)
         {
             f32x4 acc[6][NT];
@@ -554,6 +682,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             }
         }
         __syncthreads();
+        BSTAMP(8);
+        EGX_PHASE();
         // P10: attention forward recompute + backward, wave = head. Q = B4, K = B5, V = Gs, dO = B3.
         {
             const int h = wave;
@@ -562,26 +692,26 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             float* st_m = stat + (h * 3 + 0) * SP;
             float* st_i = stat + (h * 3 + 1) * SP;
             float* st_d = stat + (h * 3 + 2) * SP;
-            Frag<BF16> fq[NT], fk[NT], fv[NT], fdo[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                fq[t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + hc, q);
-                fk[t] = load_frag<BF16>(B5 + (t * 16 + r) * LDX + hc, q);
-                fv[t] = load_frag<BF16>(Gs + (t * 16 + r) * LDX + hc, q);
-                fdo[t] = load_frag<BF16>(B3 + (t * 16 + r) * LDX + hc, q);
-            }
+            auto ldq = [&](int t) { return load_frag<BF16>(B4 + (t * 16 + r) * LDX + hc, q); };
+            auto ldk = [&](int t) { return load_frag<BF16>(B5 + (t * 16 + r) * LDX + hc, q); };
+            auto ldv = [&](int t) { return load_frag<BF16>(Gs + (t * 16 + r) * LDX + hc, q); };
+            auto ldo = [&](int t) { return load_frag<BF16>(B3 + (t * 16 + r) * LDX + hc, q); };
             // orientation T: rows = key, cols = query
             f32x4 pt[NT][NT], dpt[NT][NT];
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
+            for (int qt = 0; qt < NT; ++qt) {
+                Frag<BF16> bq = ldq(qt), bdo = ldo(qt);
 #pragma unroll
-                for (int qt = 0; qt < NT; ++qt) {
+                for (int kt = 0; kt < NT; ++kt) {
                     pt[kt][qt] = f32x4{0, 0, 0, 0};
                     dpt[kt][qt] = f32x4{0, 0, 0, 0};
-                    mma<BF16>(pt[kt][qt], fk[kt], fq[qt]);      // S^T = K Q^T
-                    mma<BF16>(dpt[kt][qt], fv[kt], fdo[qt]);    // dP^T = V dO^T
+                    mma<BF16>(pt[kt][qt], ldk(kt), bq);      // S^T = K Q^T
+                    mma<BF16>(dpt[kt][qt], ldv(kt), bdo);    // dP^T = V dO^T
                 }
-            f32x4 mk[NT][NT];   // dropout keep-scale per element (1 when dropout is off)
+            }
+            auto keep = [&](int query, int key) -> float {   // attention-dropout keep-scale (regenerated, never stored)
+                return w.attn_thresh ? drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv) : 1.f;
+            };
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
                 float m = -INFINITY;
@@ -611,11 +741,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float pv = pt[kt][qt][e] * inv;
-                        float ks = 1.f;
-                        if (w.attn_thresh) ks = drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)(kt * 16 + 4 * q + e), w.attn_thresh, w.drop_inv);
-                        mk[kt][qt][e] = ks;
+                        float ks = keep(query, kt * 16 + 4 * q + e);
                         pt[kt][qt][e] = pv;
-                        dl += pv * ks * dpt[kt][qt][e];
+                        dpt[kt][qt][e] *= ks;          // mask .* dP^T
+                        dl += pv * dpt[kt][qt][e];
                     }
                 dl += __shfl_xor(dl, 16, 64);
                 dl += __shfl_xor(dl, 32, 64);
@@ -625,8 +754,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float pv = pt[kt][qt][e];
-                        dpt[kt][qt][e] = pv * (mk[kt][qt][e] * dpt[kt][qt][e] - dl) * scale;   // dS^T (scaled)
-                        pt[kt][qt][e] = pv * mk[kt][qt][e];                                       // dropped P^T
+                        dpt[kt][qt][e] = pv * (dpt[kt][qt][e] - dl) * scale;                      // dS^T (scaled)
+                        if (w.attn_thresh) pv *= keep(query, kt * 16 + 4 * q + e);
+                        pt[kt][qt][e] = pv;                                                        // dropped P^T
                     }
             }
             // O^T = V^T (P^T .* mask) -> attn_o (HBM);  dQ^T = K^T dS^T
@@ -675,16 +805,15 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     f32x4 sN = f32x4{0, 0, 0, 0}, dN = f32x4{0, 0, 0, 0};
-                    mma<BF16>(sN, fq[qt], fk[kt]);      // S = Q K^T
-                    mma<BF16>(dN, fdo[qt], fv[kt]);     // dP = dO V^T
+                    mma<BF16>(sN, ldq(qt), ldk(kt));    // S = Q K^T
+                    mma<BF16>(dN, ldo(qt), ldv(kt));    // dP = dO V^T
                     int key = kt * 16 + r;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         int query = qt * 16 + 4 * q + e;
                         bool ok = (key < S) && (query < S);
                         float pv = ok ? __expf(sN[e] * scale - mq[e]) * iq[e] : 0.f;
-                        float ks = 1.f;
-                        if (w.attn_thresh) ks = drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
+                        float ks = keep(query, key);
                         pn[qt][kt][e] = pv * ks;
                         dsn[qt][kt][e] = pv * (ks * dN[e] - dq4[e]) * scale;
                     }
@@ -739,6 +868,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
         }
         __syncthreads();
+        BSTAMP(9);
         // P11: in_proj_b partials
         if (tid < 128) {
             pl[768 + tid] = colsum_lds(B4, 0, S, tid);
@@ -746,6 +876,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         } else {
             pl[768 + 128 + (tid - 128)] = colsum_lds(B5, 0, S, tid - 128);
         }
+        EGX_PHASE();
         // P12: in-projection input gradient + residual d_res1 (B1) -> B2 (next layer's dY)
         {
             f32x4 acc[2][NT];
@@ -772,6 +903,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         { float* t = Gs; Gs = B2; B2 = t; }
     }
 
+        BSTAMP(10);
     // ---- token preparation backward: Gs = d(x0)
     {
         float* pg = part + p.n_layers * FUSED_P_LAYER;
@@ -805,6 +937,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             else pg[256 + si * 256 + 128 + (tid - 128)] = colsum_lds(B1, r0, r1, tid - 128);
         }
     }
+    BSTAMP(11);
 }
 
 // grads[dst] += sum_clip partials[clip][off .. off+len): grid = (P / 64, clip chunks); 256 threads = 64 columns x 4
@@ -844,7 +977,9 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    timing_begin(TIMER_FUSED_BWD, st);
     hipLaunchKernelGGL((fused_bwd_kernel<BF16>), dim3(p.B), dim3(256), lds, st, p);
+    timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
 }

@@ -240,11 +240,19 @@ __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, 
     }
 }
 
-// out[c] = sum_{row in [r0, r1)} buf[row][c] for c in [0, 128): called by 128 consecutive threads (t = 0..127)
+// Column sums of a token-major LDS block over rows [r0, r1): four independent accumulators so the LDS reads
+// pipeline instead of forming one dependent latency chain.
 __device__ __forceinline__ float colsum_lds(const float* buf, int r0, int r1, int c) {
-    float s = 0.f;
-    for (int row = r0; row < r1; ++row) s += buf[row * LDX + c];
-    return s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int row = r0;
+    for (; row + 3 < r1; row += 4) {
+        s0 += buf[(row + 0) * LDX + c];
+        s1 += buf[(row + 1) * LDX + c];
+        s2 += buf[(row + 2) * LDX + c];
+        s3 += buf[(row + 3) * LDX + c];
+    }
+    for (; row < r1; ++row) s0 += buf[row * LDX + c];
+    return (s0 + s1) + (s2 + s3);
 }
 
 // Feature-major GEMM against a token-major LDS operand: acc[i][t] += pack(tile0 + i, kb0 + kb) * B(rows t*16.., cols kb*32..).
@@ -275,13 +283,13 @@ __device__ __forceinline__ void gemm_pack_lds(f32x4 (&acc)[NTI][NT], const void*
 // A-operand fragment gathered from a token-major LDS block: element (i = column c0 + r, k = token row of the
 // K-block that starts at row k0): 8 ds_read_b32. Rows are clamped to rmax (callers zero the matching B rows).
 template <bool BF16>
-__device__ __forceinline__ Frag<BF16> gather_frag(const float* buf, int c, int k0, int q, int rmax) {
+__device__ __forceinline__ Frag<BF16> gather_frag(const float* buf, int c, int k0, int q, int rmax, int ld = LDX) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         int row = k0 + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
         row = row < rmax ? row : rmax;
-        v[j] = buf[row * LDX + c];
+        v[j] = buf[row * ld + c];
     }
     return make_frag<BF16>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
 }

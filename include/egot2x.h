@@ -189,6 +189,11 @@ size_t egx_ffn_dw_scratch(int N, int d_ff, int compute);
 int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1, const float* W2, int N, int S,
                int d_ff, float p_drop, uint64_t seed, float* dW1, float* db1, float* dW2, int compute,
                void* scratch, void* stream);
+/* Per-kernel device timing for bench.py's roofline block: hipEvents recorded on the launch stream around the
+ * fused kernels while enabled (which: 0 = fused forward, 1 = fused per-clip backward, 2 = FFN weight gradients).
+ * egx_timing_read synchronises on the recorded events; never call it inside a timed or captured region. */
+void egx_timing_enable(int on);
+int egx_timing_read(int which, double* total_ms, int* count);
 /* development aid: phase timestamps of the fused forward (only meaningful in -DEGX_STAMPS builds) */
 int egx_debug_stamps(unsigned long long* out, int n);
 
