@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--dropout", type=float, default=0.5, help="encoder dropout (reference recipe README.md:84 uses 0.5)")
     ap.add_argument("--optimizer", action="store_true", help="also run Adam.step() inside the timed step")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -84,16 +85,40 @@ def main():
     target = torch.randint(0, 2, (B,), generator=g).to(dev)
     ce_w = torch.tensor([0.266, 0.734], device=dev)
 
-    def step():
+    def step_eager():
         for p in params:
             p.grad = None
         logits = model.forward_features(*feats)
         loss = torch.nn.functional.cross_entropy(logits, target, weight=ce_w)
         loss.backward()
+        return loss
+
+    # One captured hipGraph per step (forward + weighted CE + backward): the library only enqueues kernels on the
+    # current stream and the dropout seed lives in device memory (advanced inside the graph), so replay is exact
+    # training work with fresh masks. The gradient all-reduce and the optimizer stay outside the graph.
+    graph = None
+    if not args.no_graph:
+        model.enable_device_seed()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step_eager()
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            step_eager()
         ddp.allreduce_gradients(params)
         if opt is not None:
             opt.step()
-        return loss
 
     for _ in range(args.warmup):
         step()
@@ -128,13 +153,14 @@ def main():
                                f"B={B}/GPU T={T} S={K * T}, synthetic N(0,1) features, random-init weights, "
                                f"train mode dropout={args.dropout} (+0.1 on PE), weighted CE, fwd+bwd"
                                + (" + Adam" if opt else "") + (" + RCCL grad all-reduce" if world > 1 else ""),
-                   "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl},
+                   "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
+                   "launch": "eager" if graph is None else "one hipGraph replay per step"},
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
         "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype],
     }
 
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, args.dtype)
+        out["roofline"] = measure_roofline(torch, lib, step_eager, B, K, T, d, h, L, dff, args.dtype)
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         from oracle.stock_module import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)

@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 1
+EGX_ABI_VERSION = 2
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16 = 0, 1
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED = 0, 1, 2
@@ -42,7 +42,7 @@ class LayerGrads(C.Structure):
 class Config(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int),
                 ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
-                ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float)]
+                ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float), ("seed_ptr", _fp)]
 
 
 # symbol -> (restype, argtypes); every symbol include/egot2x.h declares
@@ -69,6 +69,7 @@ SIGNATURES = {
     "egx_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
     "egx_debug_stamps": (C.c_int, [_fp, C.c_int]),
+    "egx_seed_advance": (C.c_int, [_fp, _fp]),
     "egx_timing_enable": (None, [C.c_int]),
     "egx_timing_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "egx_ffn_dw_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

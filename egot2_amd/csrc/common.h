@@ -72,7 +72,7 @@ static inline uint32_t drop_threshold(float p) {
     if (t >= 4294967295.0) return 0xFFFFFFFFu;
     return (uint32_t)t;
 }
-static inline uint64_t site_key(uint64_t seed, uint32_t layer, uint32_t site) {
+__host__ __device__ static inline uint64_t site_key(uint64_t seed, uint32_t layer, uint32_t site) {
     uint64_t k = seed * 0x9E3779B97F4A7C15ull + ((uint64_t)layer << 8 | site) * 0xD1B54A32D192ED03ull;
     k ^= k >> 29;
     return k | 1ull;

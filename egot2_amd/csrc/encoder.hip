@@ -245,6 +245,7 @@ extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 int egx_debug_stamps(unsigned long long* out, int n) { return n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n); }
+int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }
 int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }
 
@@ -344,10 +345,13 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
         fp.saved_res = (float*)saved + (size_t)N * d;
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
+        fp.seed_ptr = cfg->seed_ptr;
         if (pack_weights(pk, st)) return 1;
         return fused_forward(fp, comp, st);
     }
     if (ferr) return 1;
+    EGX_CHECK(!(cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)),
+              "device-resident dropout seed (seed_ptr) is only supported by the fused kernels");
 
     float* x0 = pl.L > 0 ? fptr(saved, pl.layer[0].x_in) : tokens_out;
     for (int i = 0; i < pl.nseg; ++i) {
@@ -447,6 +451,7 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
             bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
+            bp.seed_ptr = cfg->seed_ptr;
             if (fused_backward(bp, comp, st)) return 1;
 
             // small parameter gradients: sum the per-clip partials
@@ -482,6 +487,7 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
                     fp.w1p = PL.layer[l].lin1_w; fp.w2tp = PL.layer[l].lin2_wt; fp.b1 = w.lin1_b;
                     fp.N = N; fp.S = S; fp.d_ff = pl.dff;
                     fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
+                    fp.seed_ptr = cfg->seed_ptr; fp.layer = l;
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st)) return 1;
                 }
             }

@@ -38,6 +38,7 @@ struct FusedFwdParams {
     float* saved_pre;       // (B, S, 128)   projected features before the shared LN (token order)
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
+    const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };
 
 // one matrix to rewrite into MFMA-fragment order (A operand, rows = M dimension); transpose reads src[k][row]
@@ -61,6 +62,7 @@ struct FfnDwParams {
     const float* b1;
     int N, S, d_ff;
     uint64_t drop_key; uint32_t drop_thresh; float drop_inv;   // FFN hidden dropout (same keying as the forward)
+    const uint64_t* seed_ptr; int layer;                       // device-resident seed (see FusedFwdParams)
     float* slab_w1; float* slab_w2t; float* slab_b1;           // set by ffn_dw()
     int splits, kb_per_split;
 };
@@ -101,6 +103,7 @@ struct FusedBwdParams {
     const float* saved_res;
     float* partials; int P;
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
+    const uint64_t* seed_ptr;
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 
@@ -115,6 +118,7 @@ struct SmallDwParams {
     int n, items, splits;
 };
 int small_dw(SmallDwParams& p, int compute, hipStream_t st);
+int seed_advance(uint64_t* seed, hipStream_t st);
 
 struct PartialDst { float* dst; int off, len; };
 constexpr int PARTIAL_MAX_DST = 48;

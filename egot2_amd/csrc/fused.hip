@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     } while (0)
 
     STAMP(0);
+    const bool dev_seed = p.seed_ptr != nullptr;
+    const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
+    const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
     // zero the padded rows once so that padded tokens stay finite everywhere
     for (int i = tid; i < SP * LDX; i += 256) { Xs[i] = 0.f; X1[i] = 0.f; }
     __syncthreads();
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         if (p.pos_thresh) {
             uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) y[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+            for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
         }
         store32(Xs + row * LDX + c0, y);
     });
@@ -199,6 +202,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
     for (int l = 0; l < p.n_layers; ++l) {
         const FusedLayer& w = p.layer[l];
+        const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
+        const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
+        const uint64_t k_ffn = dev_seed ? site_key(seed_dev, l, SITE_FFN) : w.ffn_key;
+        const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
         float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
         float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
 
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         float pv = sc[kt][qt][e] * inv;
                         if (w.attn_thresh) {
                             int key = kt * 16 + 4 * q + e;
-                            pv *= drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
+                            pv *= drop_scale(k_attn, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
                         }
                         sc[kt][qt][e] = pv;
                     }
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         if (w.res_thresh) {
                             uint32_t orow = (uint32_t)(clip * S + tok);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] *= drop_scale(w.res1_key, orow, (uint32_t)(f0 + e), w.res_thresh, w.drop_inv);
+                            for (int e = 0; e < 4; ++e) o[e] *= drop_scale(k_res1, orow, (uint32_t)(f0 + e), w.res_thresh, w.drop_inv);
                         }
                         *reinterpret_cast<float4*>(X1 + tok * LDX + f0) = make_float4(o[0] + xr.x, o[1] + xr.y, o[2] + xr.z, o[3] + xr.w);
                     }
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                hacc[i][t][e] *= drop_scale(w.ffn_key, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
+                                hacc[i][t][e] *= drop_scale(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
                     }
                 }
                 Frag<BF16> hbq[NT];
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     if (w.res_thresh) {
                         uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] *= drop_scale(w.res2_key, orow, (uint32_t)(c0 + 4 * j + e), w.res_thresh, w.drop_inv);
+                        for (int e = 0; e < 4; ++e) f[e] *= drop_scale(k_res2, orow, (uint32_t)(c0 + 4 * j + e), w.res_thresh, w.drop_inv);
                     }
                     *reinterpret_cast<float4*>(X1 + o) = make_float4(f[0] + x1.x, f[1] + x1.y, f[2] + x1.z, f[3] + x1.w);
                 }

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
     const int nkb_total = (p.N + 31) / 32;
     const int kb_beg = split * p.kb_per_split;
     const int kb_end = min(nkb_total, kb_beg + p.kb_per_split);
+    const uint64_t drop_key = p.seed_ptr ? site_key(*p.seed_ptr, (uint32_t)p.layer, SITE_FFN) : p.drop_key;
 
     f32x4 accW1[HT][8], accW2[HT][8];
 #pragma unroll
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
                     if (p.drop_thresh) {
                         int n = kb * 32 + tt * 16 + 4 * q + e;
                         int clip = n / p.S, tok = n - clip * p.S;
-                        float ds = drop_scale(p.drop_key, (uint32_t)(clip * 64 + tok), (uint32_t)((htile0 + h) * 16 + r), p.drop_thresh, p.drop_inv);
+                        float ds = drop_scale(drop_key, (uint32_t)(clip * 64 + tok), (uint32_t)((htile0 + h) * 16 + r), p.drop_thresh, p.drop_inv);
                         hv *= ds;
                         scale *= ds;
                     }
@@ -250,6 +251,13 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     if (dW1 && red(p.slab_w1, nw, dW1)) return 1;
     if (dW2 && red(p.slab_w2t, nw, dW2)) return 1;
     if (db1 && red(p.slab_b1, (size_t)p.d_ff, db1)) return 1;
+    return 0;
+}
+
+__global__ void seed_advance_kernel(uint64_t* seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
+int seed_advance(uint64_t* seed, hipStream_t st) {
+    hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed);
+    EGX_LAUNCH_CHECK();
     return 0;
 }
 
@@ -396,12 +404,19 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             *reinterpret_cast<float4*>(dst + row * LDX + c) = *reinterpret_cast<const float4*>(src + (size_t)row * FD + c);
         }
     };
+    const bool dev_seed = p.seed_ptr != nullptr;
+    const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
+    const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
     for (int i = tid; i < 6 * BLK; i += 256) lds[i] = 0.f;
     __syncthreads();
     load_block(Gs, p.d_tokens + tok0 * FD);
 
     for (int l = p.n_layers - 1; l >= 0; --l) {
         const FusedBwdLayer& w = p.layer[l];
+        const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
+        const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
+        const uint64_t k_ffn = dev_seed ? site_key(seed_dev, l, SITE_FFN) : w.ffn_key;
+        const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
         const float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
         const float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
         float* pl = part + l * FUSED_P_LAYER;
@@ -419,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 if (w.res_thresh) {
                     uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(w.res2_key, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
+                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res2, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);
                 store32(w.g2_out + (tok0 + row) * FD + c0, dx);
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                         for (int t = 0; t < NT; ++t)
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                dacc[i][t][e] *= drop_scale(w.ffn_key, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
+                                dacc[i][t][e] *= drop_scale(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
                     }
                 }
                 Frag<BF16> dq_[NT];
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 if (w.res_thresh) {
                     uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(w.res1_key, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
+                    for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res1, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);      // g1
                 store32(w.g1_out + (tok0 + row) * FD + c0, dx);
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 if (p.pos_thresh) {
                     uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) y[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+                    for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
                 }
                 store32(Gs + row * LDX + c0, y);
                 store32(w.x_in_out + (tok0 + row) * FD + c0, y);
@@ -710,7 +725,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
             }
             auto keep = [&](int query, int key) -> float {   // attention-dropout keep-scale (regenerated, never stored)
-                return w.attn_thresh ? drop_scale(w.attn_key, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv) : 1.f;
+                return w.attn_thresh ? drop_scale(k_attn, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv) : 1.f;
             };
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
@@ -915,7 +930,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 if (p.pos_thresh) {
                     uint32_t orow = (uint32_t)(clip * S + row);
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) dy[j] *= drop_scale(p.pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+                    for (int j = 0; j < 32; ++j) dy[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
                 }
                 load32(B1 + row * LDX + c0, x);
             },

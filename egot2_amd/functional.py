@@ -43,10 +43,12 @@ class EncoderSpec:
     p_feat: float = 0.0
     training: bool = False
     seed: int = 0
+    seed_ptr: int = 0      # device address of a uint64 seed (hipGraph-replayable dropout), 0 = use `seed`
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
-                      COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat))
+                      COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
+                      self.seed_ptr or None)
 
 
 _scratch_cache = {}

@@ -64,6 +64,13 @@ class TranslatorMixin:
         self.egx_compute, self.egx_impl = compute, impl
         return self
 
+    def enable_device_seed(self, device=None):
+        """Keep the dropout seed in device memory and advance it on the stream every training forward, so that a
+        captured hipGraph (torch.cuda.graph around forward+backward) draws fresh masks on every replay."""
+        dev = device or next(self.parameters()).device
+        self._egx_seed_dev = torch.tensor([torch.initial_seed() & (2**62 - 1)], dtype=torch.int64, device=dev)
+        return self
+
     def _egx_seed(self) -> int:
         # counter-based: one fresh dropout key per forward, no device sync
         self._egx_step += 1
@@ -74,11 +81,16 @@ class TranslatorMixin:
                     pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0) -> torch.Tensor:
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
+        seed_dev = getattr(self, "_egx_seed_dev", None)
+        if seed_dev is not None and self.training:
+            from ._lib import load, check
+            check(load().egx_seed_advance(seed_dev.data_ptr(), torch.cuda.current_stream().cuda_stream))
         spec = EncoderSpec(d_model=d, n_heads=layer0.self_attn.num_heads, d_ff=layer0.linear1.out_features,
                            n_layers=len(encoder.layers), segments=segments, ln_eps=ln.eps,
                            compute=self.egx_compute, impl=self.egx_impl,
                            p_drop=p_drop, p_pos=p_pos, p_feat=p_feat,
-                           training=bool(self.training), seed=self._egx_seed() if self.training else 0)
+                           training=bool(self.training), seed=self._egx_seed() if self.training else 0,
+                           seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0)
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:

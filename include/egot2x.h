@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 1
+#define EGX_ABI_VERSION 2
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
@@ -118,6 +118,9 @@ typedef struct egx_config {
     float p_drop;     /* encoder-layer dropout (attention probs, dropout1, FFN hidden, dropout2) */
     float p_pos;      /* dropout on the token-prep output (PositionalEncoding.dropout, fixed 0.1 in HHI) */
     float p_feat;     /* dropout on projected features before LN (HOI `dp`) */
+    const uint64_t* seed_ptr; /* optional DEVICE pointer: when non-NULL the fused kernels derive their dropout keys
+                                 from *seed_ptr instead of the host `seed` argument, so a captured hipGraph draws fresh
+                                 masks on every replay (advance it with egx_seed_advance inside the graph). */
 } egx_config;
 
 int egx_abi_version(void);
@@ -189,6 +192,8 @@ size_t egx_ffn_dw_scratch(int N, int d_ff, int compute);
 int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1, const float* W2, int N, int S,
                int d_ff, float p_drop, uint64_t seed, float* dW1, float* db1, float* dW2, int compute,
                void* scratch, void* stream);
+/* *seed = lcg(*seed) on the stream (one tiny kernel): the per-step dropout seed of a replayed hipGraph. */
+int egx_seed_advance(uint64_t* seed, void* stream);
 /* Per-kernel device timing for bench.py's roofline block: hipEvents recorded on the launch stream around the
  * fused kernels while enabled (which: 0 = fused forward, 1 = fused per-clip backward, 2 = FFN weight gradients).
  * egx_timing_read synchronises on the recorded events; never call it inside a timed or captured region. */

@@ -1,0 +1,110 @@
+"""-m gpu: dropout consistency (same counter-based masks in forward and backward, fresh masks per step) and
+hipGraph replay of the whole training step with the device-resident seed."""
+import pytest
+import torch
+
+from tests.util import hhi_args, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+CE_W = [0.266, 0.734]
+
+
+def _model(cuda, compute="f32", impl="fused", p=0.5):
+    from egot2_amd import hhi_ttm
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=p))
+    m.load_state_dict(seeded_state_dict(m, 9))
+    return m.to(cuda).set_compute(compute, impl).train().enable_device_seed()
+
+
+def _loss(m, feats, target, seed_value):
+    m._egx_seed_dev.fill_(seed_value)      # the forward advances it once: same start -> same masks
+    logits = m.forward_features(*feats)
+    return torch.nn.functional.cross_entropy(logits, target, weight=torch.tensor(CE_W, device=logits.device))
+
+
+@pytest.mark.parametrize("impl", ["fused"])
+def test_dropout_masks_are_identical_in_forward_and_backward(egx_lib, cuda, impl):
+    """With the seed pinned the loss is a deterministic function of the parameters (fixed masks), so central finite
+    differences must reproduce the analytic gradient at every dropout site (attention, both residual branches, FFN
+    hidden, positional) — they only do if backward regenerates exactly the forward's masks."""
+    m = _model(cuda, impl=impl)
+    feats = [f.to(cuda) for f in seeded_feats(4, [(6, 15, 256)] * 3)]
+    target = torch.tensor([0, 1, 1, 0, 1, 0], device=cuda)
+    a = _loss(m, feats, target, 1234)
+    b = _loss(m, feats, target, 1234)
+    c = _loss(m, feats, target, 99)
+    assert a.item() == b.item(), "same seed must give the same masks"
+    assert abs(a.item() - c.item()) > 1e-6, "a different seed must give different masks"
+    m.zero_grad()
+    _loss(m, feats, target, 1234).backward()
+    probes = [("task_embed", (0, 1, 5)), ("ln.weight", (7,)), ("proj_lam.bias", (3,)),
+              ("transformer_encoder.layers.0.norm1.weight", (11,)), ("transformer_encoder.layers.0.linear2.bias", (2,)),
+              ("transformer_encoder.layers.0.self_attn.in_proj_bias", (140,)), ("linear_head.1.bias", (1,))]
+    named = dict(m.named_parameters())
+    eps = 2e-2
+    for name, idx in probes:
+        pr = named[name]
+        g = pr.grad[idx].item()
+        with torch.no_grad():
+            old = pr[idx].item()
+            pr[idx] = old + eps
+            lp = _loss(m, feats, target, 1234).item()
+            pr[idx] = old - eps
+            lm = _loss(m, feats, target, 1234).item()
+            pr[idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - g) < 2e-2 * max(abs(g), abs(fd)) + 2e-4, f"{name}{idx}: finite difference {fd} vs gradient {g}"
+
+
+def test_keep_rate_and_expectation(egx_lib, cuda):
+    """Inverted dropout: averaged over many seeds the training-mode logits approach the eval-mode logits."""
+    m = _model(cuda, p=0.3)
+    feats = [f.to(cuda) for f in seeded_feats(5, [(32, 15, 256)] * 3)]
+    with torch.no_grad():
+        acc = torch.zeros(32, 2, device=cuda)
+        n = 200
+        for s in range(n):
+            m._egx_seed_dev.fill_(1000 + s)
+            acc += m.forward_features(*feats)
+        m.eval()
+        ref = m.forward_features(*feats)
+    # LayerNorm/softmax are nonlinear, so only the rough level has to agree
+    assert (acc / n - ref).abs().mean().item() < 0.25 * ref.abs().mean().item() + 0.05
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_whole_step_graph_replay(egx_lib, cuda, compute):
+    """Forward + weighted CE + backward captured once with torch.cuda.graph and replayed: gradients stay finite,
+    differ between replays (fresh dropout masks from the device seed) and match eager execution at p = 0."""
+    m = _model(cuda, compute=compute, p=0.5)
+    feats = [f.to(cuda) for f in seeded_feats(6, [(16, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (16,), device=cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    params = list(m.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = torch.nn.functional.cross_entropy(m.forward_features(*feats), target, weight=w)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = step()
+    g.replay()
+    torch.cuda.synchronize()
+    g1 = m.transformer_encoder.layers[0].linear1.weight.grad.clone()
+    l1 = loss.item()
+    g.replay()
+    torch.cuda.synchronize()
+    g2 = m.transformer_encoder.layers[0].linear1.weight.grad.clone()
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+    assert (g1 - g2).abs().max().item() > 0, "replays must draw different dropout masks"
+    assert l1 != loss.item()
