@@ -112,7 +112,10 @@ static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan&
     for (int i = 0; i < pl.nseg; ++i) { d_in[i] = segs[i].d_in; T[i] = segs[i].T; hp[i] = segs[i].proj_w != nullptr; }
     return fused_supported(pl.d, pl.H, pl.dff, pl.S, pl.nseg, d_in, T, hp);
 }
-static size_t fused_act_bytes(const Plan& pl) { return align_up((size_t)(1 + 2 * pl.L) * pl.N * pl.d * 4, 256); }
+static size_t fused_mask_words(const Plan& pl) { return (size_t)pl.L * pl.B * (pl.dff / 32) * 64; }
+static size_t fused_res_bytes(const Plan& pl) { return align_up((size_t)(1 + 2 * pl.L) * pl.N * pl.d * 4, 256); }
+// saved = [pre + 2L residual blocks][ReLU sign bits of the FFN hidden: one u32 per (layer, clip, hidden block, lane)][packs]
+static size_t fused_act_bytes(const Plan& pl) { return fused_res_bytes(pl) + align_up(fused_mask_words(pl) * 4, 256); }
 // Fragment-packed weight copies kept behind the saved activations (written by the forward, reused by the
 // backward): per segment the projection, per layer each matrix in both orientations.
 struct FusedPackLayout {
@@ -343,6 +346,7 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
         fp.tokens_out = tokens_out;
         fp.saved_pre = (float*)saved;
         fp.saved_res = (float*)saved + (size_t)N * d;
+        fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
@@ -448,6 +452,7 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
             bp.d_tokens = d_tokens;
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
+            bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
             bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;

@@ -37,6 +37,7 @@ struct FusedFwdParams {
     float* tokens_out;      // (B, S, 128)
     float* saved_pre;       // (B, S, 128)   projected features before the shared LN (token order)
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
+    uint32_t* relu_bits;    // (L, B, d_ff/32, 64) sign bits of the FFN pre-activation (24 per lane), read by the backward
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };
@@ -101,6 +102,7 @@ struct FusedBwdParams {
     const float* d_tokens;     // (B, S, 128)
     const float* saved_pre;    // from the forward
     const float* saved_res;
+    const uint32_t* relu_bits;
     float* partials; int P;
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;

@@ -458,19 +458,16 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
         BSTAMP(2);
         EGX_PHASE();
-        // P4: FFN input gradient. H^T = relu(W1 x1^T + b1); dH^T = (W2^T g2^T) .* mask; dX1^T += W1^T dH^T
+        // P4: FFN input gradient. dH^T = (W2^T g2^T) .* mask (ReLU sign bits saved by the forward); dX1^T += W1^T dH^T
         {
             constexpr bool XRES = BF16;
             constexpr int XR = XRES ? FD / 32 : 1;
-            Frag<BF16> xb[XR][NT], gb[XR][NT];
+            Frag<BF16> gb[XR][NT];
             if constexpr (XRES) {
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        xb[kb][t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + kb * 32, q);
-                        gb[kb][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
-                    }
+                    for (int t = 0; t < NT; ++t) gb[kb][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
             }
             f32x4 dxa[8][NT];
 #pragma unroll
@@ -481,18 +478,15 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             const int nit = nhb / 4;
             const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
             auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
-            WRaw<BF16> w1r[2][FD / 32], w2r[2][FD / 32], w3r[8];
-            float4 b1r[2];
+            WRaw<BF16> w2r[2][FD / 32], w3r[8];
+            uint32_t relu_word;
+            const uint32_t* relu_bits = p.relu_bits + ((size_t)l * p.B + clip) * (size_t)(p.d_ff / 32) * 64;
             auto issue_a = [&](int hb) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb) {
-                        w1r[i][kb] = load_w<BF16>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
-                        w2r[i][kb] = load_w<BF16>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
-                    }
-                    b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb * 32 + i * 16 + 4 * q);
-                }
+                    for (int kb = 0; kb < FD / 32; ++kb) w2r[i][kb] = load_w<BF16>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
+                relu_word = relu_bits[(size_t)hb * 64 + lane];
             };
             auto issue_b = [&](int hb) {
 #pragma unroll
@@ -501,33 +495,26 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             issue_a(hb_of(0));
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
-                pin_all(w1r); pin_all(w2r);
-                f32x4 hacc[2][NT], dacc[2][NT];
+                pin_all(w2r);
+                const uint32_t bits = relu_word;
+                f32x4 dacc[2][NT];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) { hacc[i][t] = f32x4{0, 0, 0, 0}; dacc[i][t] = f32x4{0, 0, 0, 0}; }
+                    for (int t = 0; t < NT; ++t) dacc[i][t] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb) {
                     if constexpr (!XRES) {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            xb[0][t] = load_frag<BF16>(B4 + (t * 16 + r) * LDX + kb * 32, q);
-                            gb[0][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
-                        }
+                        for (int t = 0; t < NT; ++t) gb[0][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        Frag<BF16> a1 = w_frag<BF16>(w1r[i][kb]);
                         Frag<BF16> a2 = w_frag<BF16>(w2r[i][kb]);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            mma<BF16>(hacc[i][t], a1, xb[XRES ? kb : 0][t]);
-                            mma<BF16>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
-                        }
+                        for (int t = 0; t < NT; ++t) mma<BF16>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
                     }
                 }
-                float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
                 // W1 / W2^T fragments are dead now: fetch W1^T (its latency overlaps the mask/dropout VALU work below);
                 // holding all three weight sets at once overflowed the 256 arch VGPRs and spilled to scratch.
                 __builtin_amdgcn_sched_barrier(0);
@@ -538,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = (hacc[i][t][e] + bv[i][e] > 0.f) ? dacc[i][t][e] : 0.f;
+                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = ((bits >> ((i * NT + t) * 4 + e)) & 1u) ? dacc[i][t][e] : 0.f;
                 if (w.ffn_thresh) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
