@@ -27,7 +27,7 @@ namespace egx {
 //     dW2T[hid][dout] += H^T  g
 // accumulated in registers over the whole token range and written once as fp32 slabs.
 template <bool BF16, int HT>
-__global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
+__global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE = 32 * LDX;             // one tensor, 32 tokens
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,10 +49,12 @@ __global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
 #pragma unroll
     for (int h = 0; h < HT; ++h) { accB1[h] = 0.f; b1v[h] = p.b1[(htile0 + h) * 16 + r]; }
 
-    // packed weight fragments of this wave's hidden tiles (bf16: 64 VGPRs resident; fp32: re-read per K-block)
-    constexpr int WR = BF16 ? HT : 1;
+    // packed weight fragments of this wave's hidden tiles, resident in registers for the whole token range
+    // (bf16: 32 VGPRs per tile, fp32: 64; fp32 with HT > 1 re-reads them per K-block instead)
+    constexpr bool WRES = BF16 || HT == 1;
+    constexpr int WR = WRES ? HT : 1;
     WRaw<BF16> w1f[WR][4], w2f[WR][4];
-    if constexpr (BF16) {
+    if constexpr (WRES) {
 #pragma unroll
         for (int h = 0; h < HT; ++h)
 #pragma unroll
@@ -62,6 +64,13 @@ __global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
             }
     }
 
+    // LDS image of one K-block: fp32 mode keeps [tensor][32][LDX] floats; bf16 mode converts ONCE while staging into
+    // [tensor][32][LDB] bf16 rows, from which row fragments are two ds_read_b64 and the transposed (token-along-K)
+    // fragments are two ds_read_b64_tr_b16 hardware-transposed reads: no per-fragment conversion or gather VALU.
+    constexpr int LDB = 144;                    // halfwords per row: 288 B, conflict-free for the transposed reads
+    typedef short s4v __attribute__((ext_vector_type(4)));
+    unsigned short* ldsh = reinterpret_cast<unsigned short*>(lds);
+    constexpr int TILEH = 32 * LDB;
     float4 pre[8];
     auto gload = [&](int kb) {
 #pragma unroll
@@ -73,91 +82,129 @@ __global__ __launch_bounds__(256, 1) void ffn_dw_kernel(FfnDwParams p) {
             pre[i] = (n < p.N) ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
         }
     };
-    auto lstore = [&](float* buf) {
+    auto lstore = [&](int buf_idx) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int f = tid + i * 256;
             int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
-            *reinterpret_cast<float4*>(buf + tensor * TILE + row * LDX + c4 * 4) = pre[i];
+            if constexpr (BF16) {
+                uint2 pk = make_uint2(pack_bf16(pre[i].x, pre[i].y), pack_bf16(pre[i].z, pre[i].w));
+                *reinterpret_cast<uint2*>(ldsh + (buf_idx * 2 + tensor) * TILEH + row * LDB + c4 * 4) = pk;
+            } else {
+                *reinterpret_cast<float4*>(lds + (buf_idx * 2 + tensor) * TILE + row * LDX + c4 * 4) = pre[i];
+            }
+        }
+    };
+    auto row_frag = [&](int buf_idx, int tensor, int tt, int k4) -> Frag<BF16> {
+        if constexpr (BF16) {
+            const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (tt * 16 + r) * LDB + k4 * 32 + 4 * q;
+            s4v lo = *reinterpret_cast<const s4v*>(b);
+            s4v hi = *reinterpret_cast<const s4v*>(b + 16);
+            Frag<true> f;
+            f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return f;
+        } else {
+            return load_frag<BF16>(lds + (buf_idx * 2 + tensor) * TILE + (tt * 16 + r) * LDX + k4 * 32, q);
+        }
+    };
+    // fragment with the 32 tokens along K for feature tile jt: element (k = token, j = feature jt*16 + r)
+    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<BF16> {
+        if constexpr (BF16) {
+            const int i = lane & 15;
+            const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
+            typedef __attribute__((address_space(3))) s4v lds_s4v;
+            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b));
+            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + 16 * LDB));
+            Frag<true> f;
+            f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return f;
+        } else {
+            const float* c = lds + (buf_idx * 2 + tensor) * TILE + jt * 16 + r;
+            const int t0 = 4 * q;
+            float4 a = make_float4(c[(t0 + 0) * LDX], c[(t0 + 1) * LDX], c[(t0 + 2) * LDX], c[(t0 + 3) * LDX]);
+            float4 b = make_float4(c[(t0 + 16) * LDX], c[(t0 + 17) * LDX], c[(t0 + 18) * LDX], c[(t0 + 19) * LDX]);
+            return make_frag<BF16>(a, b);
         }
     };
 
     if (kb_beg < kb_end) gload(kb_beg);
     int cur = 0;
     for (int kb = kb_beg; kb < kb_end; ++kb) {
-        float* buf = lds + cur * 2 * TILE;
-        lstore(buf);
+        lstore(cur);
         __syncthreads();
         if (kb + 1 < kb_end) gload(kb + 1);
-        const float* Xs = buf;
-        const float* Gs = buf + TILE;
 
-        // token-major A fragments of both tensors: [token tile][K-block of features]
-        Frag<BF16> ax[2][4], ag[2][4];
+        // dropout row keys of this K-block's 8 token rows held by the lane (one short loop instead of a division per element)
+        uint32_t rowkey[8];
+        if (p.drop_thresh) {
+            int base = kb * 32;
+            int clip0 = base / p.S;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                ax[tt][k4] = load_frag<BF16>(Xs + (tt * 16 + r) * LDX + k4 * 32, q);
-                ag[tt][k4] = load_frag<BF16>(Gs + (tt * 16 + r) * LDX + k4 * 32, q);
+            for (int i = 0; i < 8; ++i) {
+                int off = base - clip0 * p.S + (i >> 2) * 16 + 4 * q + (i & 3);
+                int c = clip0;
+                while (off >= p.S) { off -= p.S; ++c; }
+                rowkey[i] = (uint32_t)(c * 64 + off);
             }
+        }
         Frag<BF16> aH[HT], aD[HT];
+        f32x4 hc[HT][2], dc[HT][2];
 #pragma unroll
-        for (int h = 0; h < HT; ++h) {
-            if constexpr (!BF16) {
+        for (int h = 0; h < HT; ++h)
 #pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
+            for (int tt = 0; tt < 2; ++tt) { hc[h][tt] = f32x4{0, 0, 0, 0}; dc[h][tt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            // token-major A fragments, loaded just in time (keeps the kernel at two waves per SIMD)
+            Frag<BF16> ax[2], ag[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                ax[tt] = row_frag(cur, 0, tt, k4);
+                ag[tt] = row_frag(cur, 1, tt, k4);
+            }
+#pragma unroll
+            for (int h = 0; h < HT; ++h) {
+                if constexpr (!WRES) {
                     w1f[0][k4] = load_w<BF16>(p.w1p, htile0 + h, 4, k4, lane);
                     w2f[0][k4] = load_w<BF16>(p.w2tp, htile0 + h, 4, k4, lane);
                 }
-            }
-            f32x4 hc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-            f32x4 dc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                Frag<BF16> b1f = w_frag<BF16>(w1f[BF16 ? h : 0][k4]);
-                Frag<BF16> b2f = w_frag<BF16>(w2f[BF16 ? h : 0][k4]);
+                Frag<BF16> b1f = w_frag<BF16>(w1f[WRES ? h : 0][k4]);
+                Frag<BF16> b2f = w_frag<BF16>(w2f[WRES ? h : 0][k4]);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    mma<BF16>(hc[tt], ax[tt][k4], b1f);
-                    mma<BF16>(dc[tt], ag[tt][k4], b2f);
+                    mma<BF16>(hc[h][tt], ax[tt], b1f);
+                    mma<BF16>(dc[h][tt], ag[tt], b2f);
                 }
             }
+        }
+#pragma unroll
+        for (int h = 0; h < HT; ++h) {
             float bsum = 0.f;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float hv = fmaxf(hc[tt][e] + b1v[h], 0.f);
+                    float hv = fmaxf(hc[h][tt][e] + b1v[h], 0.f);
                     float scale = hv > 0.f ? 1.f : 0.f;
                     if (p.drop_thresh) {
-                        int n = kb * 32 + tt * 16 + 4 * q + e;
-                        int clip = n / p.S, tok = n - clip * p.S;
-                        float ds = drop_scale(drop_key, (uint32_t)(clip * 64 + tok), (uint32_t)((htile0 + h) * 16 + r), p.drop_thresh, p.drop_inv);
+                        float ds = drop_scale(drop_key, rowkey[tt * 4 + e], (uint32_t)((htile0 + h) * 16 + r), p.drop_thresh, p.drop_inv);
                         hv *= ds;
                         scale *= ds;
                     }
-                    hc[tt][e] = hv;
-                    float dv = dc[tt][e] * scale;
-                    dc[tt][e] = dv;
+                    hc[h][tt][e] = hv;
+                    float dv = dc[h][tt][e] * scale;
+                    dc[h][tt][e] = dv;
                     bsum += dv;
                 }
             accB1[h] += bsum;
-            aH[h] = chain_frag<BF16>(hc[0], hc[1]);
-            aD[h] = chain_frag<BF16>(dc[0], dc[1]);
+            aH[h] = chain_frag<BF16>(hc[h][0], hc[h][1]);
+            aD[h] = chain_frag<BF16>(dc[h][0], dc[h][1]);
         }
-        // dW accumulation: B operands gathered transposed from the token-major tiles
-        const int t0 = 4 * q;
+        // dW accumulation: B operands with the tokens along K (transposed view of the staged tiles)
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            const float* xc = Xs + jt * 16 + r;
-            const float* gc = Gs + jt * 16 + r;
-            float4 xa = make_float4(xc[(t0 + 0) * LDX], xc[(t0 + 1) * LDX], xc[(t0 + 2) * LDX], xc[(t0 + 3) * LDX]);
-            float4 xb = make_float4(xc[(t0 + 16) * LDX], xc[(t0 + 17) * LDX], xc[(t0 + 18) * LDX], xc[(t0 + 19) * LDX]);
-            float4 ga = make_float4(gc[(t0 + 0) * LDX], gc[(t0 + 1) * LDX], gc[(t0 + 2) * LDX], gc[(t0 + 3) * LDX]);
-            float4 gb = make_float4(gc[(t0 + 16) * LDX], gc[(t0 + 17) * LDX], gc[(t0 + 18) * LDX], gc[(t0 + 19) * LDX]);
-            Frag<BF16> bx = make_frag<BF16>(xa, xb);
-            Frag<BF16> bg = make_frag<BF16>(ga, gb);
+            Frag<BF16> bx = tok_frag(cur, 0, jt);
+            Frag<BF16> bg = tok_frag(cur, 1, jt);
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
                 mma<BF16>(accW1[h][jt], aD[h], bx);
@@ -210,7 +257,7 @@ size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
 
 template <bool BF16>
 static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
-    constexpr int HT = 2;
+    constexpr int HT = 1;
     size_t lds = (size_t)4 * 32 * LDX * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
