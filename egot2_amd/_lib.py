@@ -51,6 +51,7 @@ SIGNATURES = {
     "egx_last_error": (C.c_char_p, []),
     "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egx_encoder_uses_fused": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_encoder_fwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
                                   _fp, _fp, _fp, C.c_int, C.c_uint64, _fp]),
     "egx_encoder_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,

@@ -289,6 +289,13 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     return 0;
 }
 
+int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B) {
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return 0;
+    bool ferr;
+    return use_fused(cfg, segs, pl, &ferr) ? 1 : 0;
+}
+
 int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
                     const egx_layer* layers, int B, float* tokens_out, void* saved, void* scratch, int training,
                     uint64_t seed, void* stream) {

@@ -235,16 +235,23 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
     }
 }
 
-// out[i] += sum_z slabs[z * n + i], float4-vectorised (n % 4 == 0, 16-byte aligned pointers)
-__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(const float* __restrict__ slabs, int nslab, size_t n, float* __restrict__ out) {
+// Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised.
+struct SlabReduce3 { const float* slab[3]; float* out[3]; size_t n[3]; int nslab; };
+__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) {
     size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    float4 s = *reinterpret_cast<const float4*>(out + i);
-    for (int z = 0; z < nslab; ++z) {
-        float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (i < a.n[k]) {
+            float4 s = *reinterpret_cast<const float4*>(a.out[k] + i);
+            for (int z = 0; z < a.nslab; ++z) {
+                float4 v = *reinterpret_cast<const float4*>(a.slab[k] + (size_t)z * a.n[k] + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4*>(a.out[k] + i) = s;
+            return;
+        }
+        i -= a.n[k];
     }
-    *reinterpret_cast<float4*>(out + i) = s;
 }
 
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
@@ -288,16 +295,18 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     p.slab_b1 = p.slab_w2t + (size_t)splits * p.d_ff * FD;
     int rc = compute == 1 ? launch_ffn_dw<true>(p, st) : launch_ffn_dw<false>(p, st);
     if (rc) return rc;
-    size_t nw = (size_t)p.d_ff * FD;
-    auto red = [&](const float* slab, size_t n, float* out) -> int {
-        EGX_CHECK((((uintptr_t)out) & 15) == 0, "ffn_dw: gradient buffers must be 16-byte aligned");
-        hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slab, splits, n, out);
-        EGX_LAUNCH_CHECK();
-        return 0;
-    };
-    if (dW1 && red(p.slab_w1, nw, dW1)) return 1;
-    if (dW2 && red(p.slab_w2t, nw, dW2)) return 1;
-    if (db1 && red(p.slab_b1, (size_t)p.d_ff, db1)) return 1;
+    SlabReduce3 a;
+    a.slab[0] = p.slab_w1; a.out[0] = dW1; a.n[0] = (size_t)p.d_ff * FD;
+    a.slab[1] = p.slab_w2t; a.out[1] = dW2; a.n[1] = (size_t)p.d_ff * FD;
+    a.slab[2] = p.slab_b1; a.out[2] = db1; a.n[2] = (size_t)p.d_ff;
+    a.nslab = splits;
+    for (int k = 0; k < 3; ++k) {
+        EGX_CHECK(!a.out[k] || (((uintptr_t)a.out[k]) & 15) == 0, "ffn_dw: gradient buffers must be 16-byte aligned");
+        if (!a.out[k]) a.n[k] = 0;
+    }
+    size_t total = a.n[0] + a.n[1] + a.n[2];
+    hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    EGX_LAUNCH_CHECK();
     return 0;
 }
 

@@ -181,6 +181,7 @@ class EncoderFn(torch.autograd.Function):
         check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
                                   ptr(scratch), int(spec.training), C.c_uint64(spec.seed & (2**64 - 1)), _stream()))
         ctx.spec = spec
+        ctx.fused_path = bool(lib.egx_encoder_uses_fused(C.byref(cfg), segs, B))
         ctx.B = B
         ctx.nseg, ctx.nproj = nseg, nproj
         ctx.saved_buf = saved
@@ -249,7 +250,11 @@ class EncoderFn(torch.autograd.Function):
                 setattr(lgr[l], name, ptr(g(i_layer[12 * l + k])))
 
         cfg = spec.config()
-        dtok = d_tokens.contiguous().clone() if d_tokens.dtype == torch.float32 else d_tokens.float().contiguous()
+        # the generic backward overwrites d_tokens (needs a private copy); the fused kernels only read it
+        dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
+        dtok = dtok.contiguous()
+        if dtok.data_ptr() == d_tokens.data_ptr() and not ctx.fused_path:
+            dtok = dtok.clone()
         scratch = _workspace("scratch", device, ctx.scratch_bytes)
         check(lib.egx_encoder_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(ctx.saved_buf),
                                   ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr, int(spec.training),

@@ -130,6 +130,10 @@ const char* egx_last_error(void);
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
                           size_t* saved_bytes, size_t* scratch_bytes);
 
+/* 1 when this configuration runs on the fused per-clip kernels (which leave d_tokens untouched in backward),
+ * 0 for the shape-generic kernels (which consume d_tokens). */
+int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B);
+
 /* tokens_out: (B, S, d). `saved` is written in forward and read in backward.
  * training != 0 applies dropout with masks derived from (seed, site, element). */
 int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs,
