@@ -39,6 +39,14 @@ class LayerGrads(C.Structure):
     _fields_ = [(n, _fp) for n in _LAYER_FIELDS]
 
 
+class Head(C.Structure):
+    _fields_ = [("ln_w", _fp), ("ln_b", _fp), ("W", _fp), ("b", _fp), ("n_out", C.c_int)]
+
+
+class HeadGrads(C.Structure):
+    _fields_ = [("ln_w", _fp), ("ln_b", _fp), ("W", _fp), ("b", _fp)]
+
+
 class Config(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int),
                 ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
@@ -57,6 +65,13 @@ SIGNATURES = {
     "egx_encoder_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
                                   _fp, _fp, _fp, C.POINTER(SegmentGrads), _fp, _fp, C.POINTER(LayerGrads),
                                   C.c_int, C.c_uint64, _fp]),
+    "egx_translator_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egx_translator_fwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.POINTER(Head),
+                                     C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_uint64, _fp]),
+    "egx_translator_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.POINTER(Head),
+                                     C.c_int, _fp, _fp, _fp, C.POINTER(SegmentGrads), _fp, _fp, C.POINTER(LayerGrads),
+                                     C.POINTER(HeadGrads), C.c_int, C.c_uint64, _fp]),
     "egx_pool_head_fwd": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, _fp, C.c_int,
                                     _fp, _fp, _fp]),
     "egx_pool_head_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int,

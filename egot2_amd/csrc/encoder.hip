@@ -155,7 +155,7 @@ struct FusedBwdScratch {
     size_t partials, slabs, slab_bytes, bytes;
     int P;
 };
-static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl) {
+static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl, int head_n_out = 0) {
     FusedBwdScratch s;
     memset(&s, 0, sizeof(s));
     size_t cur = 0;
@@ -165,7 +165,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl
         s.g1[l] = take(cur, nd); s.x_in[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
     }
     for (int i = 0; i < pl.nseg; ++i) s.dseg[i] = take(cur, (size_t)pl.B * segs[i].T * pl.d * 4);
-    s.P = fused_partial_len(pl.L, pl.nseg);
+    s.P = fused_partial_len(pl.L, pl.nseg) + fused_head_partial_len(head_n_out);
     s.partials = take(cur, (size_t)pl.B * s.P * 4);
     size_t slab = ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr);
     slab = max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
@@ -285,7 +285,7 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
     if (saved_bytes) *saved_bytes = max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(segs, pl).bytes : (size_t)0);
+    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
     return 0;
 }
 
@@ -296,17 +296,24 @@ int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B
     return use_fused(cfg, segs, pl, &ferr) ? 1 : 0;
 }
 
-int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
-                    const egx_layer* layers, int B, float* tokens_out, void* saved, void* scratch, int training,
-                    uint64_t seed, void* stream) {
+}  // extern "C"
+
+// Shared body of egx_encoder_fwd (head == null) and egx_translator_fwd (pooled head fused or appended).
+static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                            const egx_layer* layers, const egx_head* head, int B, float* tokens_out, float* logits_out,
+                            void* saved, void* scratch, int training, uint64_t seed, void* stream) {
     (void)scratch;
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    EGX_CHECK(tokens_out && saved && ln_w && ln_b, "null pointer argument");
+    EGX_CHECK(saved && ln_w && ln_b, "null pointer argument");
     EGX_CHECK(pl.L == 0 || layers, "null layers");
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute;
     const int N = (int)pl.N;
+    const bool with_head = head && head->W;
+    EGX_CHECK(with_head ? (logits_out != nullptr) : (tokens_out != nullptr), "null output pointer");
+    EGX_CHECK(!with_head || (head->ln_w && head->ln_b && head->b && head->n_out >= 1 && head->n_out <= FUSED_HEAD_MAX_OUT),
+              "head needs ln_w, ln_b, W, b and 1 <= n_out <= %d", FUSED_HEAD_MAX_OUT);
     bool ferr;
     if (use_fused(cfg, segs, pl, &ferr)) {
         FusedFwdParams fp;
@@ -351,6 +358,10 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
         fp.ln_w = ln_w; fp.ln_b = ln_b; fp.eps = cfg->ln_eps;
         fp.nseg = pl.nseg; fp.n_layers = pl.L; fp.B = B; fp.S = S; fp.d_ff = pl.dff;
         fp.tokens_out = tokens_out;
+        if (with_head) {
+            fp.head.ln_w = head->ln_w; fp.head.ln_b = head->ln_b; fp.head.W = head->W; fp.head.b = head->b; fp.head.n_out = head->n_out;
+            fp.logits_out = logits_out;
+        }
         fp.saved_pre = (float*)saved;
         fp.saved_res = (float*)saved + (size_t)N * d;
         fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
@@ -364,6 +375,13 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
     EGX_CHECK(!(cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)),
               "device-resident dropout seed (seed_ptr) is only supported by the fused kernels");
 
+    // generic path with a head: tokens and the pooled vector live behind the layer intermediates in `saved`
+    float* head_pooled = nullptr;
+    if (with_head) {
+        float* tk = fptr(saved, align_up(pl.saved_bytes, 256));
+        head_pooled = tk + (size_t)N * d;
+        if (!tokens_out) tokens_out = tk;
+    }
     float* x0 = pl.L > 0 ? fptr(saved, pl.layer[0].x_in) : tokens_out;
     for (int i = 0; i < pl.nseg; ++i) {
         const egx_segment& sg = segs[i];
@@ -411,17 +429,22 @@ int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float*
         l2.stats = fptr(saved, o.stats2); l2.y = x_out; l2.rows = N; l2.d = d;
         if (layernorm_fwd(l2, st)) return 1;
     }
+    if (with_head)
+        return pool_head_fwd(tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out,
+                             head_pooled, logits_out, st);
     return 0;
 }
 
-int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
-                    const egx_layer* layers, int B, float* d_tokens, const void* saved, void* scratch,
-                    const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
-                    const egx_layer_grads* layer_grads, int training, uint64_t seed, void* stream) {
+static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                            const egx_layer* layers, const egx_head* head, int B, float* d_tokens, const float* d_logits,
+                            const void* saved, void* scratch, const egx_segment_grads* seg_grads, float* d_ln_w,
+                            float* d_ln_b, const egx_layer_grads* layer_grads, const egx_head_grads* head_grads,
+                            int training, uint64_t seed, void* stream) {
     (void)ln_b;
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    EGX_CHECK(d_tokens && saved && scratch && ln_w, "null pointer argument");
+    const bool with_head = head && head->W;
+    EGX_CHECK((with_head ? (const void*)d_logits : (const void*)d_tokens) && saved && scratch && ln_w, "null pointer argument");
     {
         bool ferr;
         if (use_fused(cfg, segs, pl, &ferr)) {
@@ -429,7 +452,7 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
             const int d = pl.d, S = pl.S, comp = cfg->compute;
             const int N = (int)pl.N;
             FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
-            FusedBwdScratch SC = fused_bwd_scratch(segs, pl);
+            FusedBwdScratch SC = fused_bwd_scratch(segs, pl, with_head ? head->n_out : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int i = 0; i < pl.nseg; ++i) {
@@ -457,6 +480,11 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
             bp.ln_w = ln_w; bp.ln_b = ln_b; bp.eps = cfg->ln_eps;
             bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = B; bp.S = S; bp.d_ff = pl.dff;
             bp.d_tokens = d_tokens;
+            if (with_head) {
+                bp.head.ln_w = head->ln_w; bp.head.ln_b = head->ln_b; bp.head.W = head->W; bp.head.b = head->b; bp.head.n_out = head->n_out;
+                bp.d_logits = d_logits;
+                bp.head_off = fused_partial_len(pl.L, pl.nseg);
+            }
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
             bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
@@ -485,6 +513,12 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
                 EGX_CHECK(!seg_grads[i].pos && !seg_grads[i].feat, "fused backward: positional / feature gradients are not supported (use impl=generic)");
                 add_dst(seg_grads[i].add_vec, og + 256 + i * 256, 128);
                 add_dst(seg_grads[i].proj_b, og + 256 + i * 256 + 128, 128);
+            }
+            if (with_head && head_grads) {
+                int oh = fused_partial_len(pl.L, pl.nseg);
+                add_dst(head_grads->ln_w, oh, 128); add_dst(head_grads->ln_b, oh + 128, 128);
+                add_dst(head_grads->b, oh + 256, head->n_out);
+                add_dst(head_grads->W, oh + 256 + FUSED_HEAD_MAX_OUT, head->n_out * 128);
             }
             if (reduce_partials(rp, st)) return 1;
 
@@ -532,6 +566,14 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;
     const int N = (int)pl.N;
+    if (with_head) {
+        const float* tk = cfptr(saved, align_up(pl.saved_bytes, 256));
+        const float* pooled = tk + (size_t)N * d;
+        d_tokens = fptr(scratch, align_up(pl.scratch_bytes, 256));
+        if (pool_head_bwd(d_logits, pooled, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->n_out, d_tokens,
+                          head_grads ? head_grads->ln_w : nullptr, head_grads ? head_grads->ln_b : nullptr,
+                          head_grads ? head_grads->W : nullptr, head_grads ? head_grads->b : nullptr, st)) return 1;
+    }
     float* dA = fptr(scratch, pl.s_dA);
     float* dBm = fptr(scratch, pl.s_dB);
     float* dqkv = fptr(scratch, pl.s_dqkv);
@@ -621,6 +663,52 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float*
         }
     }
     return 0;
+}
+
+extern "C" {
+
+int egx_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B, float* tokens_out, void* saved, void* scratch, int training,
+                    uint64_t seed, void* stream) {
+    return encoder_fwd_impl(cfg, segs, ln_w, ln_b, layers, nullptr, B, tokens_out, nullptr, saved, scratch, training, seed, stream);
+}
+
+int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                    const egx_layer* layers, int B, float* d_tokens, const void* saved, void* scratch,
+                    const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
+                    const egx_layer_grads* layer_grads, int training, uint64_t seed, void* stream) {
+    return encoder_bwd_impl(cfg, segs, ln_w, ln_b, layers, nullptr, B, d_tokens, nullptr, saved, scratch, seg_grads, d_ln_w,
+                            d_ln_b, layer_grads, nullptr, training, seed, stream);
+}
+
+int egx_translator_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return 1;
+    size_t sv = 0, sc = 0;
+    if (egx_encoder_workspace(cfg, segs, B, &sv, &sc)) return 1;
+    // generic path extras: tokens + pooled behind `saved`, d_tokens behind `scratch`
+    size_t extra_sv = align_up(pl.saved_bytes, 256) + (pl.N + (size_t)B) * pl.d * 4 + 256;
+    size_t extra_sc = align_up(pl.scratch_bytes, 256) + pl.N * pl.d * 4 + 256;
+    if (saved_bytes) *saved_bytes = max(sv, extra_sv);
+    if (scratch_bytes) *scratch_bytes = max(sc, extra_sc);
+    return 0;
+}
+
+int egx_translator_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                       const egx_layer* layers, const egx_head* head, int B, float* logits_out, float* tokens_out,
+                       void* saved, void* scratch, int training, uint64_t seed, void* stream) {
+    EGX_CHECK(head && head->W, "egx_translator_fwd needs a head (use egx_encoder_fwd otherwise)");
+    return encoder_fwd_impl(cfg, segs, ln_w, ln_b, layers, head, B, tokens_out, logits_out, saved, scratch, training, seed, stream);
+}
+
+int egx_translator_bwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                       const egx_layer* layers, const egx_head* head, int B, const float* d_logits, const void* saved,
+                       void* scratch, const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
+                       const egx_layer_grads* layer_grads, const egx_head_grads* head_grads, int training,
+                       uint64_t seed, void* stream) {
+    EGX_CHECK(head && head->W, "egx_translator_bwd needs a head (use egx_encoder_bwd otherwise)");
+    return encoder_bwd_impl(cfg, segs, ln_w, ln_b, layers, head, B, nullptr, d_logits, saved, scratch, seg_grads, d_ln_w,
+                            d_ln_b, layer_grads, head_grads, training, seed, stream);
 }
 
 int egx_pool_head_fwd(const float* tokens, int B, int S, int d, const float* ln_w, const float* ln_b, float ln_eps,

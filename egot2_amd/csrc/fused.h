@@ -28,13 +28,24 @@ struct FusedLayer {
     float drop_inv;
 };
 
+// Optional pooled task head fused into the per-clip kernels: logits = Linear(LN(mean_s tokens)).
+struct FusedHead {
+    const float* ln_w; const float* ln_b;   // head LayerNorm
+    const float* W; const float* b;         // [n_out, 128], [n_out]
+    int n_out;                               // 0 = no head
+};
+constexpr int FUSED_HEAD_MAX_OUT = 64;
+// head section of the per-clip partial row: ln_w, ln_b (128 each), b (64 slots), W (n_out * 128)
+static inline int fused_head_partial_len(int n_out) { return n_out > 0 ? 256 + FUSED_HEAD_MAX_OUT + n_out * 128 : 0; }
+
 struct FusedFwdParams {
     FusedSeg seg[FUSED_MAX_SEG];
     FusedLayer layer[FUSED_MAX_LAYERS];
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
-    float* tokens_out;      // (B, S, 128)
+    float* tokens_out;      // (B, S, 128) or null when only the head output is wanted
+    FusedHead head; float* logits_out;   // (B, n_out) when head.n_out > 0
     float* saved_pre;       // (B, S, 128)   projected features before the shared LN (token order)
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
     uint32_t* relu_bits;    // (L, B, d_ff/32, 64) sign bits of the FFN pre-activation (24 per lane), read by the backward
@@ -99,7 +110,8 @@ struct FusedBwdParams {
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
-    const float* d_tokens;     // (B, S, 128)
+    const float* d_tokens;     // (B, S, 128), or null when the head is fused (then d_logits drives the backward)
+    FusedHead head; const float* d_logits; int head_off;   // head_off: offset of the head section in the partial row
     const float* saved_pre;    // from the forward
     const float* saved_res;
     const uint32_t* relu_bits;

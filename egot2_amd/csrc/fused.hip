@@ -566,8 +566,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             bool last = (l + 1 == p.n_layers);
             ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 store32(sv_res2 + (size_t)row * FD + c0, x);
-                if (last) store32(p.tokens_out + ((size_t)clip * S + row) * FD + c0, y);
-                else store32(Xs + row * LDX + c0, y);
+                if (last && p.tokens_out) store32(p.tokens_out + ((size_t)clip * S + row) * FD + c0, y);
+                if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
             });
         }
         __syncthreads();
@@ -575,6 +575,27 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         if (l + 1 < p.n_layers) {
             for (int i = tid; i < (SP - S) * LDX; i += 256) Xs[S * LDX + i] = 0.f;
             __syncthreads();
+        }
+    }
+
+    // ---- optional pooled head: logits = Linear(LN(mean_s tokens)); tokens of the last layer are in Xs
+    if (p.head.n_out > 0) {
+        float* pooled = X1;                      // 128 floats of scratch (X1 is dead)
+        if (tid < FD) pooled[tid] = colsum_lds(Xs, 0, S, tid) * (1.f / (float)S);
+        __syncthreads();
+        if (wave == 0) {
+            float2 x = *reinterpret_cast<float2*>(pooled + 2 * lane);
+            float mean = wsum(x.x + x.y) * (1.f / FD);
+            float dx = x.x - mean, dy = x.y - mean;
+            float rstd = rsqrtf(wsum(dx * dx + dy * dy) * (1.f / FD) + p.eps);
+            float2 lw = *reinterpret_cast<const float2*>(p.head.ln_w + 2 * lane);
+            float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
+            float y0 = dx * rstd * lw.x + lb.x, y1 = dy * rstd * lw.y + lb.y;
+            for (int o = 0; o < p.head.n_out; ++o) {
+                float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
+                float sdot = wsum(y0 * wv.x + y1 * wv.y);
+                if (lane == 0) p.logits_out[(size_t)clip * p.head.n_out + o] = sdot + p.head.b[o];
+            }
         }
     }
 }

@@ -465,7 +465,55 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
     for (int i = tid; i < 6 * BLK; i += 256) lds[i] = 0.f;
     __syncthreads();
-    load_block(Gs, p.d_tokens + tok0 * FD);
+    if (p.head.n_out > 0) {
+        // Fused pooled head backward: rebuild the last layer's output tokens y = LN2(res2), pool them, run the head
+        // forward/backward for this clip (wave 0) and broadcast d(tokens) = d(pooled) / S into Gs.
+        const FusedBwdLayer& wl = p.layer[p.n_layers - 1];
+        float* hp = part + p.head_off;
+        load_block(Gs, p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD);
+        __syncthreads();
+        ln_rows(Gs, S, wl.norm2_w, wl.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            store32(Gs + row * LDX + c0, y);
+        });
+        __syncthreads();
+        float* pooled = B1;        // [0,128): pooled; [128,256): d(pooled)
+        if (tid < FD) pooled[tid] = colsum_lds(Gs, 0, S, tid) * (1.f / (float)S);
+        __syncthreads();
+        if (wave == 0) {
+            float2 x = *reinterpret_cast<float2*>(pooled + 2 * lane);
+            float mean = wsum(x.x + x.y) * (1.f / FD);
+            float xh0 = x.x - mean, xh1 = x.y - mean;
+            float rstd = rsqrtf(wsum(xh0 * xh0 + xh1 * xh1) * (1.f / FD) + p.eps);
+            xh0 *= rstd; xh1 *= rstd;
+            float2 lw = *reinterpret_cast<const float2*>(p.head.ln_w + 2 * lane);
+            float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
+            float y0 = xh0 * lw.x + lb.x, y1 = xh1 * lw.y + lb.y;
+            float d0 = 0.f, d1 = 0.f;
+            for (int o = 0; o < p.head.n_out; ++o) {
+                float go = p.d_logits[(size_t)clip * p.head.n_out + o];
+                float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
+                d0 += go * wv.x; d1 += go * wv.y;
+                *reinterpret_cast<float2*>(hp + 256 + FUSED_HEAD_MAX_OUT + o * FD + 2 * lane) = make_float2(go * y0, go * y1);
+                if (lane == 0) hp[256 + o] = go;
+            }
+            *reinterpret_cast<float2*>(hp + 2 * lane) = make_float2(d0 * xh0, d1 * xh1);          // d(head ln_w)
+            *reinterpret_cast<float2*>(hp + 128 + 2 * lane) = make_float2(d0, d1);                // d(head ln_b)
+            float g0 = d0 * lw.x, g1 = d1 * lw.y;
+            float s1 = wsum(g0 + g1) * (1.f / FD);
+            float s2 = wsum(g0 * xh0 + g1 * xh1) * (1.f / FD);
+            float inv_s = 1.f / (float)S;
+            *reinterpret_cast<float2*>(pooled + 128 + 2 * lane) =
+                make_float2(rstd * (g0 - s1 - xh0 * s2) * inv_s, rstd * (g1 - s1 - xh1 * s2) * inv_s);
+        }
+        __syncthreads();
+        for (int i = tid; i < S * (FD / 4); i += 256) {
+            int row = i >> 5, c = (i & 31) << 2;
+            *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(pooled + 128 + c);
+        }
+        __syncthreads();
+    } else {
+        load_block(Gs, p.d_tokens + tok0 * FD);
+    }
 
     for (int l = p.n_layers - 1; l >= 0; --l) {
         const FusedBwdLayer& w = p.layer[l];

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (Config, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
+from ._lib import (Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
                    EGX_F32, EGX_BF16, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED)
 
 COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16}
@@ -44,6 +44,7 @@ class EncoderSpec:
     training: bool = False
     seed: int = 0
     seed_ptr: int = 0      # device address of a uint64 seed (hipGraph-replayable dropout), 0 = use `seed`
+    head_n_out: int = 0    # > 0: pooled head (mean -> LN -> Linear) evaluated with the encoder; output = logits
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
@@ -113,9 +114,10 @@ class _GradPacker:
 
 
 class EncoderFn(torch.autograd.Function):
-    """tokens(B,S,d) = encoder(token_prep(feats)). Argument order:
-    spec, task_embed|None, pos_table|None, ln_w, ln_b, feats[n_seg], (proj_w, proj_b) per projecting segment,
-    12 tensors per layer in _LAYER_FIELDS order."""
+    """tokens(B,S,d) = encoder(token_prep(feats)) — or, with spec.head_n_out > 0, logits(B,n_out) = head(tokens).
+    Argument order: spec, task_embed|None, pos_table|None, ln_w, ln_b, feats[n_seg], (proj_w, proj_b) per projecting
+    segment, 12 tensors per layer in _LAYER_FIELDS order, then (head_ln_w, head_ln_b, head_W, head_b) when a head
+    is requested."""
 
     @staticmethod
     def forward(ctx, spec: EncoderSpec, task_embed, pos_table, ln_w, ln_b, *rest):
@@ -124,7 +126,9 @@ class EncoderFn(torch.autograd.Function):
         feats = [_dev_f32(t, f"feats[{i}]") for i, t in enumerate(rest[:nseg])]
         nproj = sum(1 for s in spec.segments if s.has_proj)
         proj = [_dev_f32(t, "projection weight") for t in rest[nseg:nseg + 2 * nproj]]
-        layer_t = [_dev_f32(t, "layer weight") for t in rest[nseg + 2 * nproj:]]
+        nhead = 4 if spec.head_n_out else 0
+        layer_t = [_dev_f32(t, "layer weight") for t in rest[nseg + 2 * nproj:len(rest) - nhead]]
+        head_t = [_dev_f32(t, "head parameter") for t in rest[len(rest) - nhead:]] if nhead else []
         assert len(layer_t) == 12 * spec.n_layers, "layer parameter count mismatch"
         ln_w = _dev_f32(ln_w, "ln.weight")
         ln_b = _dev_f32(ln_b, "ln.bias")
@@ -170,25 +174,33 @@ class EncoderFn(torch.autograd.Function):
             spec = dataclasses.replace(spec, impl="generic")
         cfg = spec.config()
         sv, sc = C.c_size_t(0), C.c_size_t(0)
-        check(lib.egx_encoder_workspace(C.byref(cfg), segs, B, C.byref(sv), C.byref(sc)))
+        ws = lib.egx_translator_workspace if nhead else lib.egx_encoder_workspace
+        check(ws(C.byref(cfg), segs, B, C.byref(sv), C.byref(sc)))
         S = sum(s.T for s in spec.segments)
-        tokens = torch.empty((B, S, d), dtype=torch.float32, device=device)
         if needs_grad:
             saved = torch.empty(max(sv.value, 256), dtype=torch.uint8, device=device)
         else:
             saved = _workspace("saved", device, sv.value)
         scratch = _workspace("scratch", device, sc.value)
-        check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
-                                  ptr(scratch), int(spec.training), C.c_uint64(spec.seed & (2**64 - 1)), _stream()))
+        seed = C.c_uint64(spec.seed & (2**64 - 1))
+        if nhead:
+            head = Head(ptr(head_t[0]), ptr(head_t[1]), ptr(head_t[2]), ptr(head_t[3]), spec.head_n_out)
+            tokens = torch.empty((B, spec.head_n_out), dtype=torch.float32, device=device)   # logits
+            check(lib.egx_translator_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(tokens),
+                                         None, ptr(saved), ptr(scratch), int(spec.training), seed, _stream()))
+        else:
+            tokens = torch.empty((B, S, d), dtype=torch.float32, device=device)
+            check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
+                                      ptr(scratch), int(spec.training), seed, _stream()))
         ctx.spec = spec
         ctx.fused_path = bool(lib.egx_encoder_uses_fused(C.byref(cfg), segs, B))
         ctx.B = B
-        ctx.nseg, ctx.nproj = nseg, nproj
+        ctx.nseg, ctx.nproj, ctx.nhead = nseg, nproj, nhead
         ctx.saved_buf = saved
         ctx.scratch_bytes = sc.value
         ctx.has_te = task_embed is not None
         ctx.has_pos = pos_table is not None
-        ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t))
+        ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t + head_t))
         return tokens
 
     @staticmethod
@@ -202,7 +214,9 @@ class EncoderFn(torch.autograd.Function):
         nseg, nproj = ctx.nseg, ctx.nproj
         feats = sv[2:2 + nseg]
         proj = sv[2 + nseg:2 + nseg + 2 * nproj]
-        layer_t = sv[2 + nseg + 2 * nproj:]
+        nhead = ctx.nhead
+        layer_t = sv[2 + nseg + 2 * nproj:len(sv) - nhead]
+        head_t = sv[len(sv) - nhead:] if nhead else []
         d = spec.d_model
         B = ctx.B
         device = d_tokens.device
@@ -216,6 +230,7 @@ class EncoderFn(torch.autograd.Function):
         i_feat = [pk.add(f, need[5 + i]) for i, f in enumerate(feats)]
         i_proj = [pk.add(t, need[5 + nseg + i]) for i, t in enumerate(proj)]
         i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i]) for i, t in enumerate(layer_t)]
+        i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i]) for i, t in enumerate(head_t)]
         grads = pk.materialise(device)
 
         def g(i):
@@ -250,23 +265,34 @@ class EncoderFn(torch.autograd.Function):
                 setattr(lgr[l], name, ptr(g(i_layer[12 * l + k])))
 
         cfg = spec.config()
-        # the generic backward overwrites d_tokens (needs a private copy); the fused kernels only read it
-        dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
-        dtok = dtok.contiguous()
-        if dtok.data_ptr() == d_tokens.data_ptr() and not ctx.fused_path:
-            dtok = dtok.clone()
         scratch = _workspace("scratch", device, ctx.scratch_bytes)
-        check(lib.egx_encoder_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(ctx.saved_buf),
-                                  ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr, int(spec.training),
-                                  C.c_uint64(spec.seed & (2**64 - 1)), _stream()))
+        seed = C.c_uint64(spec.seed & (2**64 - 1))
+        if nhead:
+            head = Head(ptr(head_t[0]), ptr(head_t[1]), ptr(head_t[2]), ptr(head_t[3]), spec.head_n_out)
+            hg = HeadGrads(ptr(g(i_head[0])), ptr(g(i_head[1])), ptr(g(i_head[2])), ptr(g(i_head[3])))
+            dlog = d_tokens.float().contiguous()
+            check(lib.egx_translator_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(dlog),
+                                         ptr(ctx.saved_buf), ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr,
+                                         C.byref(hg), int(spec.training), seed, _stream()))
+        else:
+            # the generic backward overwrites d_tokens (needs a private copy); the fused kernels only read it
+            dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
+            dtok = dtok.contiguous()
+            if dtok.data_ptr() == d_tokens.data_ptr() and not ctx.fused_path:
+                dtok = dtok.clone()
+            check(lib.egx_encoder_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(ctx.saved_buf),
+                                      ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr, int(spec.training), seed,
+                                      _stream()))
         out = [None, g(i_te), g(i_pos), g(i_lnw), g(i_lnb)]
-        out += [g(i) for i in i_feat] + [g(i) for i in i_proj] + [g(i) for i in i_layer]
+        out += [g(i) for i in i_feat] + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
         return tuple(out)
 
 
 def encoder(spec: EncoderSpec, feats: Sequence[torch.Tensor], task_embed, pos_table, ln_w, ln_b,
-            proj: Sequence[torch.Tensor], layer_params: Sequence[torch.Tensor]) -> torch.Tensor:
-    return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params)
+            proj: Sequence[torch.Tensor], layer_params: Sequence[torch.Tensor],
+            head_params: Sequence[torch.Tensor] = ()) -> torch.Tensor:
+    """head_params = (head_ln_w, head_ln_b, head_W, head_b) with spec.head_n_out = head_W.shape[0] -> logits."""
+    return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, *head_params)
 
 
 class PoolHeadFn(torch.autograd.Function):

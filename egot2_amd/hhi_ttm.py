@@ -69,12 +69,13 @@ class _TTMTranslator(TaskFusion3Task, TranslatorMixin):
             nn.Linear(self.dim, 2)
         )
 
-    def _tokens(self, feats, projs, task_ids):
+    def _tokens(self, feats, projs, task_ids, with_head=False):
         segs = [SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=True, add_row=k, pos_row0=0)
                 for f, k in zip(feats, task_ids)]
+        head = (self.linear_head[0], self.linear_head[1]) if with_head else None
         return self._egx_encode(feats, segs, encoder=self.transformer_encoder, ln=self.ln, projs=projs,
                                 task_embed=self.task_embed, pos_table=self.pos_embed.pe,
-                                p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p)
+                                p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p, head=head)
 
     def _head(self, tokens):
         ln, fc = self.linear_head[0], self.linear_head[1]
@@ -95,8 +96,7 @@ class TaskFusionMFTransformer2Task(_TTMTranslator):
 
     def forward_features(self, ttm_out, lam_out):
         """ttm_out, lam_out: (B, T, 256) backbone features -> (B, 2) logits. Token order ttm, lam (task ids 0, 1)."""
-        tokens = self._tokens([ttm_out, lam_out], [self.proj_ttm, self.proj_lam], [0, 1])
-        return self._head(tokens)
+        return self._tokens([ttm_out, lam_out], [self.proj_ttm, self.proj_lam], [0, 1], with_head=True)
 
     def forward(self, video, audio):
         lam_out = self.lam_model(video, middle=True)  # (bs, T, 256)
@@ -119,8 +119,8 @@ class TaskFusionMFTransformer3Task(_TTMTranslator):
 
     def forward_features(self, ttm_out, lam_out, asd_out):
         """(B, T, 256) features of the three backbones -> (B, 2) logits. Token order ttm, lam, asd = task ids 0, 1, 2."""
-        tokens = self._tokens([ttm_out, lam_out, asd_out], [self.proj_ttm, self.proj_lam, self.proj_asd], [0, 1, 2])
-        return self._head(tokens)
+        return self._tokens([ttm_out, lam_out, asd_out], [self.proj_ttm, self.proj_lam, self.proj_asd], [0, 1, 2],
+                            with_head=True)
 
     def forward(self, video, video_asd, audio, audio_asd):
         N, D, H, W = video_asd.shape

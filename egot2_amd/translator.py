@@ -78,7 +78,9 @@ class TranslatorMixin:
 
     def _egx_encode(self, feats: Sequence[torch.Tensor], segments: List[SegmentSpec], *, encoder: nn.TransformerEncoder,
                     ln: nn.LayerNorm, projs: Sequence[Optional[nn.Linear]], task_embed: Optional[torch.Tensor],
-                    pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0) -> torch.Tensor:
+                    pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0,
+                    head=None) -> torch.Tensor:
+        """head = (nn.LayerNorm, nn.Linear): evaluate the pooled head with the encoder and return logits (B, n_out)."""
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
@@ -90,10 +92,12 @@ class TranslatorMixin:
                            compute=self.egx_compute, impl=self.egx_impl,
                            p_drop=p_drop, p_pos=p_pos, p_feat=p_feat,
                            training=bool(self.training), seed=self._egx_seed() if self.training else 0,
-                           seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0)
+                           seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
+                           head_n_out=head[1].out_features if head is not None else 0)
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:
                 proj_t += [p.weight, p.bias]
+        head_t = (head[0].weight, head[0].bias, head[1].weight, head[1].bias) if head is not None else ()
         return F_egx.encoder(spec, list(feats), task_embed, pos_table, ln.weight, ln.bias, proj_t,
-                             encoder_layer_tensors(encoder))
+                             encoder_layer_tensors(encoder), head_t)

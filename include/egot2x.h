@@ -151,6 +151,27 @@ int egx_encoder_bwd(const egx_config* cfg, const egx_segment* segs,
                     const egx_layer_grads* layer_grads,
                     int training, uint64_t seed, void* stream);
 
+/* Encoder + pooled task head in one call: logits = Linear(LN(mean_s tokens)), the TTM / PNR head
+ * (HHI/models/ttm/model_taskspecific.py:243-244). On the fused per-clip path the head runs inside the encoder
+ * kernels (tokens never leave the chip unless tokens_out != NULL); on the generic path it is appended.
+ * Workspaces: egx_translator_workspace(). n_out <= 64. */
+typedef struct egx_head {
+    const float* ln_w; const float* ln_b;   /* head LayerNorm [d] */
+    const float* W; const float* b;         /* [n_out, d], [n_out] */
+    int n_out;
+} egx_head;
+typedef struct egx_head_grads { float* ln_w; float* ln_b; float* W; float* b; } egx_head_grads;   /* accumulated (+=) */
+int egx_translator_workspace(const egx_config* cfg, const egx_segment* segs, int B,
+                             size_t* saved_bytes, size_t* scratch_bytes);
+int egx_translator_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                       const egx_layer* layers, const egx_head* head, int B, float* logits_out, float* tokens_out,
+                       void* saved, void* scratch, int training, uint64_t seed, void* stream);
+int egx_translator_bwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b,
+                       const egx_layer* layers, const egx_head* head, int B, const float* d_logits, const void* saved,
+                       void* scratch, const egx_segment_grads* seg_grads, float* d_ln_w, float* d_ln_b,
+                       const egx_layer_grads* layer_grads, const egx_head_grads* head_grads, int training,
+                       uint64_t seed, void* stream);
+
 /* pooled = mean_s tokens[b, s, :]; y = ln_w ? LN(pooled) : pooled; out = W ? y W^T + b : y.
  * `pooled_saved` (B, d) is kept for backward. n_out <= 64 when W != NULL. */
 int egx_pool_head_fwd(const float* tokens, int B, int S, int d,
