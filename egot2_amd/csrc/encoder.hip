@@ -3,6 +3,7 @@
 // no synchronisation, hipGraph-capturable.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/egot2x.h"
 #include "common.h"
@@ -143,8 +144,23 @@ static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segmen
     L.bytes = cur;
     return L;
 }
+// The FFN hidden activation H (forward) and its gradient dH (backward) are handed to the weight-gradient kernel as
+// operand tiles instead of being recomputed there (EGX_FFN_RECOMPUTE=1 restores the recompute variant, which needs no
+// (B, 48, d_ff) tensors in HBM).
+static bool store_hidden() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_FFN_RECOMPUTE"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
+    return store_hidden() ? align_up((size_t)pl.L * fused_hid_bytes(pl.B, pl.dff, cfg->compute == EGX_BF16), 256) : 0;
+}
+// saved = [activations][packed weights][H tiles]
+static size_t fused_hid_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return align_up(fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
+}
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes;
+    return fused_hid_offset(cfg, segs, pl) + fused_hid_total(cfg, pl);
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
@@ -152,10 +168,10 @@ static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, 
 struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], x_in[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
-    size_t partials, slabs, slab_bytes, bytes;
+    size_t partials, slabs, slab_bytes, dhid, bytes;
     int P;
 };
-static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl, int head_n_out = 0) {
+static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segment* segs, const Plan& pl, int head_n_out = 0) {
     FusedBwdScratch s;
     memset(&s, 0, sizeof(s));
     size_t cur = 0;
@@ -173,6 +189,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_segment* segs, const Plan& pl
     for (int i = 0; i < pl.nseg; ++i) slab = max(slab, gemm_scratch_bytes(2, pl.d, segs[i].d_in, pl.B * segs[i].T));
     s.slab_bytes = slab;
     s.slabs = take(cur, slab);
+    s.dhid = take(cur, fused_hid_total(cfg, pl));
     s.bytes = cur;
     return s;
 }
@@ -285,7 +302,7 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
     if (saved_bytes) *saved_bytes = max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
+    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
     return 0;
 }
 
@@ -365,6 +382,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.saved_pre = (float*)saved;
         fp.saved_res = (float*)saved + (size_t)N * d;
         fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
+        fp.hid_out = store_hidden() ? (char*)saved + fused_hid_offset(cfg, segs, pl) : nullptr;
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
@@ -452,7 +470,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             const int d = pl.d, S = pl.S, comp = cfg->compute;
             const int N = (int)pl.N;
             FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
-            FusedBwdScratch SC = fused_bwd_scratch(segs, pl, with_head ? head->n_out : 0);
+            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, pl, with_head ? head->n_out : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int i = 0; i < pl.nseg; ++i) {
@@ -488,6 +506,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
             bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
+            bp.dhid_out = store_hidden() ? (char*)scratch + SC.dhid : nullptr;
             bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
@@ -534,6 +553,12 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                     fp.N = N; fp.S = S; fp.d_ff = pl.dff;
                     fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
                     fp.seed_ptr = cfg->seed_ptr; fp.layer = l;
+                    if (store_hidden()) {
+                        size_t lo = (size_t)l * fused_hid_bytes(B, pl.dff, comp == EGX_BF16);
+                        fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, pl) + lo;
+                        fp.dhs = (const char*)scratch + SC.dhid + lo;
+                        fp.B = B;
+                    }
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st)) return 1;
                 }
             }

@@ -49,6 +49,8 @@ struct FusedFwdParams {
     float* saved_pre;       // (B, S, 128)   projected features before the shared LN (token order)
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
     uint32_t* relu_bits;    // (L, B, d_ff/32, 64) sign bits of the FFN pre-activation (24 per lane), read by the backward
+    void* hid_out;          // optional (L, B, 3, d_ff/16) tiles of the FFN hidden activation (after ReLU and dropout) in
+                            // ffn_dw's token-along-K operand order (fused_dev.h store_hid_tile); fp32 or bf16 elements
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };
@@ -75,9 +77,15 @@ struct FfnDwParams {
     int N, S, d_ff;
     uint64_t drop_key; uint32_t drop_thresh; float drop_inv;   // FFN hidden dropout (same keying as the forward)
     const uint64_t* seed_ptr; int layer;                       // device-resident seed (see FusedFwdParams)
+    // stored-operand variant: H and dH tiles written by the clip-parallel kernels (no recompute, no weights needed)
+    const void* hs; const void* dhs; int B;
     float* slab_w1; float* slab_w2t; float* slab_b1;           // set by ffn_dw()
     int splits, kb_per_split;
 };
+constexpr int FUSED_TOK_TILES = 3;   // 16-token tiles per clip in the fused kernels (S <= 48)
+static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer of hidden tiles
+    return (size_t)B * FUSED_TOK_TILES * (d_ff / 16) * 256 * (bf16 ? 2 : 4);
+}
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st);
 
@@ -115,6 +123,7 @@ struct FusedBwdParams {
     const float* saved_pre;    // from the forward
     const float* saved_res;
     const uint32_t* relu_bits;
+    void* dhid_out;         // optional gradient of the FFN pre-activation, same tile layout as FusedFwdParams::hid_out
     float* partials; int P;
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;

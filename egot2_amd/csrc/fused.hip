@@ -518,6 +518,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 Frag<BF16> hbq[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<BF16>(hacc[0][t], hacc[1][t]);
+                if (p.hid_out) {        // H tiles for the weight-gradient kernel (which then skips its recompute)
+                    constexpr int ESZ = BF16 ? 2 : 4;
+                    const int nht = p.d_ff / 16;
+                    char* hb_base = (char*)p.hid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            store_hid_tile<BF16>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     Frag<BF16> a = w_frag<BF16>(w2r[i]);

@@ -235,6 +235,131 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
     }
 }
 
+// Stored-operand variant: the clip-parallel kernels have already written H (forward) and dH (backward) as
+// token-along-K operand tiles (fused_dev.h store_hid_tile), so a wave's A fragments are plain coalesced 1 KB loads
+// and only the two weight-gradient GEMMs remain. K-blocks are pairs of 16-token tiles of the clip-padded token
+// grid (FUSED_TOK_TILES per clip); x1 / g rows of padding tokens are staged as zeros.
+template <bool BF16>
+__global__ __launch_bounds__(256, 2) void ffn_dw_stored_kernel(FfnDwParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TILE = 32 * LDX;
+    constexpr int ESZ = BF16 ? 2 : 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int htile = blockIdx.x * 4 + wave, split = blockIdx.y;
+    const int nht = p.d_ff / 16;
+    const int ntile = p.B * FUSED_TOK_TILES;
+    const int nkb_total = (ntile + 1) / 2;
+    const int kb_beg = split * p.kb_per_split;
+    const int kb_end = min(nkb_total, kb_beg + p.kb_per_split);
+
+    f32x4 accW1[8], accW2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accW1[j] = f32x4{0, 0, 0, 0}; accW2[j] = f32x4{0, 0, 0, 0}; }
+    float accB1 = 0.f;
+
+    constexpr int LDB = 144;
+    typedef short s4v __attribute__((ext_vector_type(4)));
+    unsigned short* ldsh = reinterpret_cast<unsigned short*>(lds);
+    constexpr int TILEH = 32 * LDB;
+    float4 pre[8];
+    Frag<BF16> nH, nD;
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int f = tid + i * 256;
+            int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
+            int tile = kb * 2 + (row >> 4);
+            int clip = tile / FUSED_TOK_TILES;
+            int tok = (tile - clip * FUSED_TOK_TILES) * 16 + (row & 15);
+            const float* src = (tensor ? p.g : p.x1) + ((size_t)clip * p.S + tok) * FD + c4 * 4;
+            pre[i] = (tile < ntile && tok < p.S) ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
+        }
+        int ta = kb * 2, tb = min(kb * 2 + 1, ntile - 1);     // a missing second tile meets zero x1 / g rows
+        size_t oa = ((size_t)ta * nht + htile) * (HTILE_ELEMS * ESZ), ob = ((size_t)tb * nht + htile) * (HTILE_ELEMS * ESZ);
+        nH = load_hid_frag<BF16>((const char*)p.hs + oa, (const char*)p.hs + ob, lane);
+        nD = load_hid_frag<BF16>((const char*)p.dhs + oa, (const char*)p.dhs + ob, lane);
+    };
+    auto lstore = [&](int buf_idx) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int f = tid + i * 256;
+            int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
+            if constexpr (BF16) {
+                uint2 pk = make_uint2(pack_bf16(pre[i].x, pre[i].y), pack_bf16(pre[i].z, pre[i].w));
+                *reinterpret_cast<uint2*>(ldsh + (buf_idx * 2 + tensor) * TILEH + row * LDB + c4 * 4) = pk;
+            } else {
+                *reinterpret_cast<float4*>(lds + (buf_idx * 2 + tensor) * TILE + row * LDX + c4 * 4) = pre[i];
+            }
+        }
+    };
+    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<BF16> {
+        if constexpr (BF16) {
+            const int i = lane & 15;
+            const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
+            typedef __attribute__((address_space(3))) s4v lds_s4v;
+            s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b));
+            s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + 16 * LDB));
+            Frag<true> f;
+            f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return f;
+        } else {
+            const float* c = lds + (buf_idx * 2 + tensor) * TILE + jt * 16 + r;
+            const int t0 = 4 * q;
+            float4 a = make_float4(c[(t0 + 0) * LDX], c[(t0 + 1) * LDX], c[(t0 + 2) * LDX], c[(t0 + 3) * LDX]);
+            float4 b = make_float4(c[(t0 + 16) * LDX], c[(t0 + 17) * LDX], c[(t0 + 18) * LDX], c[(t0 + 19) * LDX]);
+            return make_frag<BF16>(a, b);
+        }
+    };
+
+    if (kb_beg < kb_end) gload(kb_beg);
+    int cur = 0;
+    for (int kb = kb_beg; kb < kb_end; ++kb) {
+        lstore(cur);
+        Frag<BF16> aH = nH, aD = nD;
+        __syncthreads();
+        if (kb + 1 < kb_end) gload(kb + 1);
+        const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
+        if constexpr (BF16) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 u = __builtin_bit_cast(u32x4, aD.v);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                s0 += __uint_as_float(u[j] << 16) + __uint_as_float(u[j] & 0xffff0000u);
+                s1 += __uint_as_float(u[2 + j] << 16) + __uint_as_float(u[2 + j] & 0xffff0000u);
+            }
+            accB1 += s0 + (has_b ? s1 : 0.f);
+        } else {
+            float s0 = (aD.v[0] + aD.v[1]) + (aD.v[2] + aD.v[3]), s1 = (aD.v[4] + aD.v[5]) + (aD.v[6] + aD.v[7]);
+            accB1 += s0 + (has_b ? s1 : 0.f);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            Frag<BF16> bx = tok_frag(cur, 0, jt);
+            Frag<BF16> bg = tok_frag(cur, 1, jt);
+            mma<BF16>(accW1[jt], aD, bx);
+            mma<BF16>(accW2[jt], aH, bg);
+        }
+        cur ^= 1;
+    }
+
+    float* sw1 = p.slab_w1 + (size_t)split * p.d_ff * FD;
+    float* sw2 = p.slab_w2t + (size_t)split * p.d_ff * FD;
+    const int hrow = htile * 16 + 4 * q;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[jt][e];
+        *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
+            make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
+    }
+    float bs = accB1;
+    bs += __shfl_xor(bs, 16, 64);
+    bs += __shfl_xor(bs, 32, 64);
+    if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+}
+
 // Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised.
 struct SlabReduce3 { const float* slab[3]; float* out[3]; size_t n[3]; int nslab; };
 __global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) {
@@ -274,7 +399,17 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     }
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
-    hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
+    if (p.hs) {
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr2_set = true;
+        }
+        hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16>), grid, dim3(256), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
+    }
     timing_end(TIMER_FFN_DW, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -285,7 +420,8 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
     int splits;
     ffn_dw_scratch_bytes(p.N, p.d_ff, &splits);
-    int nkb = (p.N + 31) / 32;
+    EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
+    int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
     p.splits = splits;
     p.kb_per_split = cdiv(nkb, splits);
     p.splits = cdiv(nkb, p.kb_per_split);
@@ -644,6 +780,16 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 Frag<BF16> dq_[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<BF16>(dacc[0][t], dacc[1][t]);
+                if (p.dhid_out) {       // dH tiles for the weight-gradient kernel
+                    constexpr int ESZ = BF16 ? 2 : 4;
+                    const int nht = p.d_ff / 16;
+                    char* hb_base = (char*)p.dhid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            store_hid_tile<BF16>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), dacc[i][t], lane, S - t * 16);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(w3r);
                 if (it + 1 < nit) issue_a(hb_of(it + 1));   // next block's W1 / W2^T stream in under the dX GEMM

@@ -131,6 +131,66 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<BF16>& a, const Frag<
     }
 }
 
+// ---- hidden-activation tiles for ffn_dw ----------------------------------------------------------------------
+// The clip-parallel kernels hold the FFN hidden activation (and its gradient) as C tiles with the hidden unit on the
+// registers (row 4q+e) and the token on the lane (col r). The weight-gradient kernel needs them as MFMA operands
+// with the TOKEN along K, i.e. lane (r' = hidden % 16, q') holding tokens 4q'..4q'+3. A 4x4 transpose inside each
+// lane quad (two DPP butterfly steps) converts one into the other, after which the whole 16x16 tile leaves as ONE
+// dense store (1 KB fp32 / 512 B bf16): tile[lane' = hid%16 + 16*((tok%16)>>2)][tok&3].
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// afterwards v[j] of quad-lane l holds what v[l] of quad-lane j held
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    const bool h2 = (lane & 2) != 0, h1 = (lane & 1) != 0;
+    float a = h2 ? v[0] : v[2], b = h2 ? v[1] : v[3];
+    a = dpp_quad<0x4E>(a);      // quad_perm [2,3,0,1]
+    b = dpp_quad<0x4E>(b);
+    if (h2) { v[0] = a; v[1] = b; } else { v[2] = a; v[3] = b; }
+    float c = h1 ? v[0] : v[1], d = h1 ? v[2] : v[3];
+    c = dpp_quad<0xB1>(c);      // quad_perm [1,0,3,2]
+    d = dpp_quad<0xB1>(d);
+    if (h1) { v[0] = c; v[2] = d; } else { v[1] = c; v[3] = d; }
+}
+constexpr int HTILE_ELEMS = 256;   // one (16 tokens x 16 hidden units) tile
+// `tile` = start of the (token tile, hidden tile) block; tokens >= n_valid (within this 16-token tile) are stored as 0
+template <bool BF16>
+__device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int lane, int n_valid) {
+    float v[4] = {c[0], c[1], c[2], c[3]};
+    quad_transpose(v, lane);
+    const int r = lane & 15, q = lane >> 4;
+    const int t0 = 4 * (r >> 2);
+    if (t0 + 4 > n_valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (t0 + j < n_valid) ? v[j] : 0.f;
+    }
+    const int dst = 4 * q + (r & 3) + 16 * (r >> 2);
+    if constexpr (BF16) {
+        reinterpret_cast<uint2*>(tile)[dst] = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    } else {
+        reinterpret_cast<float4*>(tile)[dst] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+// A/B operand of one K-block of 32 tokens = two consecutive 16-token tiles of one hidden tile
+template <bool BF16>
+__device__ __forceinline__ Frag<BF16> load_hid_frag(const void* tile_a, const void* tile_b, int lane) {
+    Frag<BF16> f;
+    if constexpr (BF16) {
+        uint2 a = reinterpret_cast<const uint2*>(tile_a)[lane];
+        uint2 b = reinterpret_cast<const uint2*>(tile_b)[lane];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 u = {a.x, a.y, b.x, b.y};
+        f.v = __builtin_bit_cast(bf16x8, u);
+    } else {
+        float4 a = reinterpret_cast<const float4*>(tile_a)[lane];
+        float4 b = reinterpret_cast<const float4*>(tile_b)[lane];
+        f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+        f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    }
+    return f;
+}
+
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
