@@ -49,28 +49,38 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
-// Counter-based dropout RNG: a 64-bit (seed, site) key and a 32-bit element index -> uniform u32.
-// Forward and backward regenerate identical masks; nothing is stored.
+// Counter-based dropout RNG: a 64-bit (seed, site) key and a (row, column) element index -> 16 uniform bits.
+// Forward and backward regenerate identical masks; nothing is stored. One 32-bit hash serves the two columns of a
+// pair (2c, 2c+1), so a lane that owns adjacent columns pays one integer-multiply round per two elements (the
+// quarter-rate v_mul_lo_u32 of a full hash per element used to cost more than the FFN epilogue around it).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t rand_u32(uint64_t key, uint32_t idx_hi, uint32_t idx_lo) {
+__device__ __forceinline__ uint32_t rand_pair(uint64_t key, uint32_t row, uint32_t colpair) {
     uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-    uint32_t h = mix32(idx_lo ^ k0);
-    h = mix32(h + idx_hi * 0x9E3779B9U + k1);
-    return mix32(h ^ (k0 * 0x85ebca6bU));
+    return mix32((row * 0x9E3779B1U + k1) ^ (colpair * 0x85EBCA77U + k0));
 }
-// keep-scale for inverted dropout: returns 0 or 1/(1-p)
-__device__ __forceinline__ float drop_scale(uint64_t key, uint32_t idx_hi, uint32_t idx_lo,
-                                            uint32_t thresh, float inv_keep) {
-    return rand_u32(key, idx_hi, idx_lo) >= thresh ? inv_keep : 0.f;
+// keep-scale for inverted dropout: returns 0 or 1/(1-p). `thresh` is on the 16-bit scale (drop_threshold).
+__device__ __forceinline__ float drop_scale(uint64_t key, uint32_t row, uint32_t col, uint32_t thresh, float inv_keep) {
+    uint32_t h = rand_pair(key, row, col >> 1);
+    uint32_t v = (col & 1u) ? (h >> 16) : (h & 0xffffu);
+    return v >= thresh ? inv_keep : 0.f;
+}
+// four adjacent columns col0..col0+3 (col0 a multiple of 4) of one row: two hashes
+__device__ __forceinline__ void drop_scale4(uint64_t key, uint32_t row, uint32_t col0, uint32_t thresh, float inv_keep, float (&out)[4]) {
+    uint32_t h0 = rand_pair(key, row, col0 >> 1), h1 = rand_pair(key, row, (col0 >> 1) + 1);
+    out[0] = (h0 & 0xffffu) >= thresh ? inv_keep : 0.f;
+    out[1] = (h0 >> 16) >= thresh ? inv_keep : 0.f;
+    out[2] = (h1 & 0xffffu) >= thresh ? inv_keep : 0.f;
+    out[3] = (h1 >> 16) >= thresh ? inv_keep : 0.f;
 }
 static inline uint32_t drop_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0;
     if (t <= 0) return 0u;
-    if (t >= 4294967295.0) return 0xFFFFFFFFu;
-    return (uint32_t)t;
+    if (t >= 65536.0) return 65536u;
+    uint32_t u = (uint32_t)(t + 0.5);
+    return u ? u : 1u;
 }
 __host__ __device__ static inline uint64_t site_key(uint64_t seed, uint32_t layer, uint32_t site) {
     uint64_t k = seed * 0x9E3779B97F4A7C15ull + ((uint64_t)layer << 8 | site) * 0xD1B54A32D192ED03ull;

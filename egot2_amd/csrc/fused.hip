@@ -509,10 +509,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     for (int i = 0; i < 2; ++i) {
                         int h0 = hb * 32 + i * 16 + 4 * q;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NT; ++t) {
+                            float ds[4];
+                            drop_scale4(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)h0, w.ffn_thresh, w.drop_inv, ds);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                hacc[i][t][e] *= drop_scale(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)(h0 + e), w.ffn_thresh, w.drop_inv);
+                            for (int e = 0; e < 4; ++e) hacc[i][t][e] *= ds[e];
+                        }
                     }
                 }
                 Frag<BF16> hbq[NT];

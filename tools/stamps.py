@@ -6,7 +6,8 @@ from egot2_amd import hhi_ttm, _lib
 from tests.util import hhi_args
 lib = _lib.load()
 dev = torch.device("cuda:0")
-m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args()).to(dev).eval()
+p_drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
+m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=p_drop)).to(dev).train()
 feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]
 names = ["zero", "proj", "ln0", "qkv", "attn", "outproj", "ln1", "ffn", "part-store", "ln2"]
 for comp in ("f32", "bf16"):
