@@ -817,4 +817,19 @@ int egx_attention_bwd(const float* qkv, const float* out, const float* lse, cons
     return attention_bwd(qkv, out, lse, d_out, d_qkv, B, S, H, d, da.key, da.thresh, da.inv_keep, (hipStream_t)stream);
 }
 
+int egx_weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
+                    float* d_logits, void* stream) {
+    return weighted_ce(logits, target, weight, B, C, loss, d_logits, (hipStream_t)stream);
+}
+
+int egx_counter_add(int64_t* counter, int64_t inc, void* stream) { return counter_add(counter, inc, (hipStream_t)stream); }
+
+int egx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, const int64_t* step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                  void* stream) {
+    EGX_CHECK(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adam_step: invalid hyper-parameters");
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale,
+                     (hipStream_t)stream);
+}
+
 }  // extern "C"

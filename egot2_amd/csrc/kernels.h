@@ -91,4 +91,11 @@ int pool_head_bwd(const float* d_out, const float* pooled, int B, int S, int d, 
                   const float* ln_b, float eps, const float* W, int n_out, float* d_tokens, float* d_ln_w,
                   float* d_ln_b, float* d_W, float* d_b, hipStream_t st);
 
+// train.hip
+int weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
+                float* dlogits, hipStream_t st);
+int counter_add(int64_t* c, int64_t inc, hipStream_t st);
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, const int64_t* step, float lr, float b1, float b2,
+              float eps, float wd, int decoupled, float grad_scale, hipStream_t st);
+
 }  // namespace egx

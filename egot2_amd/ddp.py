@@ -29,16 +29,21 @@ def shard_batch(tensors: Iterable[torch.Tensor], rank: int, world: int) -> List[
 
 
 def _flat_groups(params: Iterable[torch.nn.Parameter]):
-    """Group gradients by the flat buffer they are views of; stragglers are returned separately."""
+    """Group gradients by the storage they share (the encoder's backward carves all of them out of one flat buffer);
+    gradients that own their storage alone are returned separately and coalesced by the caller."""
+    from .functional import flat_storage_view
+    count: Dict[int, int] = {}
+    grads = [p.grad for p in params if p.grad is not None]
+    for g in grads:
+        k = g.untyped_storage().data_ptr()
+        count[k] = count.get(k, 0) + 1
     bases: Dict[int, torch.Tensor] = {}
     loose: List[torch.Tensor] = []
-    for p in params:
-        g = p.grad
-        if g is None:
-            continue
-        base = g._base if g._base is not None else None
-        if base is not None and base.dim() == 1 and base.dtype == g.dtype:
-            bases[base.data_ptr()] = base
+    for g in grads:
+        k = g.untyped_storage().data_ptr()
+        if count[k] > 1 and g.is_contiguous():
+            if k not in bases:
+                bases[k] = flat_storage_view(g)
         else:
             loose.append(g)
     return list(bases.values()), loose

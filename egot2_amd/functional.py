@@ -113,6 +113,14 @@ class _GradPacker:
         return out
 
 
+def flat_storage_view(t: torch.Tensor) -> torch.Tensor:
+    """1-D view over the WHOLE storage `t` lives in. Gradients handed out by _GradPacker reach `.grad` detached (autograd
+    drops `_base`), so the flat buffer behind them is recovered through the storage: every gradient of one backward
+    shares it, which is what lets the all-reduce and the optimizer run once per buffer."""
+    st = t.untyped_storage()
+    return torch.empty(0, dtype=t.dtype, device=t.device).set_(st, 0, (st.nbytes() // t.element_size(),))
+
+
 class EncoderFn(torch.autograd.Function):
     """tokens(B,S,d) = encoder(token_prep(feats)) — or, with spec.head_n_out > 0, logits(B,n_out) = head(tokens).
     Argument order: spec, task_embed|None, pos_table|None, ln_w, ln_b, feats[n_seg], (proj_w, proj_b) per projecting
@@ -391,3 +399,36 @@ def linear(x, W, b=None, compute: str = "f32"):
     shp = x.shape
     y = LinearFn.apply(x.reshape(-1, shp[-1]), W, b, compute)
     return y.view(*shp[:-1], W.shape[0])
+
+
+class WeightedCEFn(torch.autograd.Function):
+    """loss = sum_i w[y_i] nll_i / sum_i w[y_i]; the same launch leaves d loss / d logits behind for backward."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        lib = _lib.load()
+        z = _dev_f32(logits, "logits")
+        if z.dim() != 2:
+            raise ValueError(f"weighted_cross_entropy expects (B, C) logits, got {tuple(z.shape)}")
+        if target.dtype != torch.int64 or target.shape != z.shape[:1] or target.device != z.device:
+            raise ValueError("target must be an int64 tensor of shape (B,) on the logits' device")
+        tgt = target.contiguous()
+        w = None if weight is None else _dev_f32(weight, "weight")
+        if w is not None and w.numel() != z.shape[1]:
+            raise ValueError("weight must have one entry per class")
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        dl = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        check(lib.egx_weighted_ce(ptr(z), ptr(tgt), ptr(w) if w is not None else None, z.shape[0], z.shape[1],
+                                  ptr(loss), ptr(dl) if dl is not None else None, _stream()))
+        ctx.dl = dl
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dl, ctx.dl = ctx.dl, None
+        return (dl * grad_out if dl is not None else None), None, None
+
+
+def weighted_cross_entropy(logits, target, weight=None):
+    """F.cross_entropy(logits, target, weight=weight) with mean reduction (HHI/tasks/ttm/video_task_2loader.py:21-22,34)."""
+    return WeightedCEFn.apply(logits, target, weight)

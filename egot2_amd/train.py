@@ -1,0 +1,102 @@
+"""Training-step pieces around the translator: the TTM criterion and the optimizer.
+
+`CrossEntropyLoss` mirrors `nn.CrossEntropyLoss(weight=...)` as built at HHI/tasks/ttm/video_task_2loader.py:21-22
+(same constructor argument and `weight` buffer name, so Lightning checkpoints carrying `criterion.weight` load).
+`FusedAdam` mirrors `torch.optim.Adam` / `AdamW` as configured at HHI/tasks/ttm/video_task_2loader.py:62-64 and
+HOI/tasks/multitask/video_task.py:624-626: the translator's gradients already arrive as views of ONE flat buffer
+(functional._GradPacker), so the parameters are re-pointed into a flat buffer with the same layout and the whole
+update is a single launch per buffer, with the step count in device memory (hipGraph-replayable).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import functional as F_egx
+from ._lib import check, ptr
+
+
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, weight: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else weight.detach().clone().float())
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return F_egx.weighted_cross_entropy(input, target, self.weight)
+
+
+class _Bucket:
+    __slots__ = ("sig", "param", "exp_avg", "exp_avg_sq", "numel")
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """Adam (adamw=False) / AdamW (adamw=True) with torch.optim semantics, one launch per flat gradient buffer."""
+
+    def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, adamw: bool = False):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
+        self._buckets: Dict[tuple, _Bucket] = {}
+        self._step_dev: Optional[torch.Tensor] = None
+
+    def _make_bucket(self, sig, base: torch.Tensor, members) -> _Bucket:
+        b = _Bucket()
+        b.sig = sig
+        b.numel = base.numel()
+        if len(members) == 1 and members[0][1] == 0 and members[0][0].numel() == base.numel() and members[0][0].is_contiguous():
+            b.param = members[0][0].data.view(-1)          # stand-alone tensor: update it in place where it lives
+        else:
+            b.param = torch.zeros_like(base)
+            for p, off in members:                          # move the parameters behind the gradient layout
+                n = p.numel()
+                b.param[off:off + n].copy_(p.data.reshape(-1))
+                p.data = b.param[off:off + n].view(p.shape)
+        b.exp_avg = torch.zeros_like(b.param)
+        b.exp_avg_sq = torch.zeros_like(b.param)
+        for p, off in members:
+            n = p.numel()
+            self.state[p] = {"step": self._step_dev, "exp_avg": b.exp_avg[off:off + n].view(p.shape),
+                             "exp_avg_sq": b.exp_avg_sq[off:off + n].view(p.shape)}
+        return b
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        bumped = False
+        for gi, group in enumerate(self.param_groups):
+            by_base: Dict[int, Tuple[torch.Tensor, List]] = {}
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+                    raise ValueError("FusedAdam needs contiguous fp32 gradients on the GPU")
+                base = F_egx.flat_storage_view(g)           # the flat buffer this gradient was carved out of
+                by_base.setdefault(base.data_ptr(), (base, []))[1].append((p, g.storage_offset()))
+            for base, members in by_base.values():
+                if self._step_dev is None:
+                    self._step_dev = torch.zeros((), dtype=torch.int64, device=base.device)
+                if not bumped:
+                    check(lib.egx_counter_add(ptr(self._step_dev), 1, stream))
+                    bumped = True
+                sig = (gi,) + tuple((id(p), off) for p, off in members) + (base.numel(),)
+                b = self._buckets.get(sig)
+                if b is not None and any(p.data_ptr() != b.param.data_ptr() + 4 * off for p, off in members):
+                    b = None                                 # somebody re-allocated a parameter: rebuild the bucket
+                if b is None:
+                    b = self._buckets[sig] = self._make_bucket(sig, base.reshape(-1), members)
+                gflat = base.reshape(-1)
+                check(lib.egx_adam_step(ptr(b.param), ptr(gflat), ptr(b.exp_avg), ptr(b.exp_avg_sq), b.numel,
+                                        ptr(self._step_dev), group["lr"], group["betas"][0], group["betas"][1],
+                                        group["eps"], group["weight_decay"], int(group["adamw"]), 1.0, stream))
+        return loss

@@ -219,6 +219,24 @@ int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1
                void* scratch, void* stream);
 /* *seed = lcg(*seed) on the stream (one tiny kernel): the per-step dropout seed of a replayed hipGraph. */
 int egx_seed_advance(uint64_t* seed, void* stream);
+
+/* ---- training step around the translator ------------------------------------------------
+ * loss = sum_i w[y_i] * nll_i / sum_i w[y_i] with nll_i = -log_softmax(logits_i)[y_i]  (weight NULL: w = 1), and
+ * d_logits = d loss / d logits when d_logits != NULL - in one launch. logits (B, C) fp32, target (B) int64, weight (C).
+ * Replaces nn.CrossEntropyLoss(weight=[0.266, 0.734]) and its backward, HHI/tasks/ttm/video_task_2loader.py:21-22,34. */
+int egx_weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
+                    float* d_logits, void* stream);
+/* *counter += inc on the stream (device-resident step count of the optimizer). */
+int egx_counter_add(int64_t* counter, int64_t inc, void* stream);
+/* One Adam (decoupled = 0) / AdamW (decoupled = 1) update of n fp32 elements with torch.optim semantics:
+ *   g = grad * grad_scale (+ weight_decay * p if !decoupled);  p *= 1 - lr * weight_decay if decoupled;
+ *   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * with t = *step (1-based, device memory: advance it with egx_counter_add first, which also makes the update
+ * replayable inside a hipGraph). Replaces torch.optim.Adam(lr=5e-4) HHI/tasks/ttm/video_task_2loader.py:62-64 and
+ * AdamW(lr=1e-4, weight_decay=1e-4) HOI/tasks/multitask/video_task.py:624-626 over a flat parameter buffer. */
+int egx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, const int64_t* step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                  void* stream);
 /* Per-kernel device timing for bench.py's roofline block: hipEvents recorded on the launch stream around the
  * fused kernels while enabled (which: 0 = fused forward, 1 = fused per-clip backward, 2 = FFN weight gradients).
  * egx_timing_read synchronises on the recorded events; never call it inside a timed or captured region. */

@@ -1,0 +1,153 @@
+"""-m gpu: the training-step kernels around the translator: fused weighted cross-entropy
+against the oracle / torch, FusedAdam against torch.optim.Adam and AdamW, and the whole step inside one hipGraph."""
+import copy
+
+import pytest
+import torch
+
+from tests.util import hhi_args, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+CE_W = [0.266, 0.734]
+
+
+@pytest.mark.parametrize("B,C,weighted", [(256, 2, True), (3000, 2, True), (5, 7, True), (64, 3, False), (1, 2, True)])
+def test_weighted_ce_matches_oracle_and_torch(egx_lib, cuda, B, C, weighted):
+    from egot2_amd import functional as F_egx
+    from oracle import translator_ref as ref
+    g = torch.Generator().manual_seed(B * 31 + C)
+    logits = (torch.randn(B, C, generator=g) * 3).to(cuda).requires_grad_(True)
+    target = torch.randint(0, C, (B,), generator=g).to(cuda)
+    w = torch.rand(C, generator=g) + 0.1 if weighted else None
+    loss = F_egx.weighted_cross_entropy(logits, target, None if w is None else w.to(cuda))
+    (loss * 1.7).backward()
+    l64 = logits.detach().cpu().double().requires_grad_(True)
+    want = ref.weighted_ce(l64, target.cpu(), list(w.double()) if w is not None else [1.0] * C)
+    (want * 1.7).backward()
+    assert abs(loss.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    assert (logits.grad.cpu().double() - l64.grad).abs().max().item() < 1e-6
+    t = torch.nn.functional.cross_entropy(logits.detach(), target, weight=None if w is None else w.to(cuda))
+    assert abs(loss.item() - t.item()) < 1e-5 * max(1.0, abs(t.item()))
+
+
+def test_cross_entropy_module_mirrors_reference_criterion(egx_lib, cuda):
+    from egot2_amd.train import CrossEntropyLoss
+    crit = CrossEntropyLoss(weight=torch.FloatTensor(CE_W)).to(cuda)
+    assert list(crit.state_dict().keys()) == ["weight"]        # `criterion.weight` in the reference's Lightning ckpt
+    ref = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor(CE_W)).to(cuda)
+    x = torch.randn(32, 2, device=cuda)
+    y = torch.randint(0, 2, (32,), device=cuda)
+    assert abs(crit(x, y).item() - ref(x, y).item()) < 1e-6
+    with pytest.raises(ValueError):
+        crit(x, y.int())
+
+
+def _ttm(cuda, seed=5):
+    from egot2_amd import hhi_ttm
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.0))
+    m.pos_embed.dropout.p = 0.0
+    m.load_state_dict(seeded_state_dict(m, seed))
+    return m.to(cuda).train()
+
+
+@pytest.mark.parametrize("adamw,wd,lr", [(False, 0.0, 5e-4), (True, 1e-4, 1e-4), (False, 1e-2, 1e-3)])
+def test_fused_adam_matches_torch(egx_lib, cuda, adamw, wd, lr):
+    """Reference optimizers: Adam(lr=5e-4) HHI/tasks/ttm/video_task_2loader.py:62-64, AdamW(1e-4, wd=1e-4)
+    HOI/tasks/multitask/video_task.py:624-626. Both models take their gradients from the same HIP path."""
+    from egot2_amd.train import FusedAdam
+    a, b = _ttm(cuda), _ttm(cuda)
+    opt_a = FusedAdam(a.parameters(), lr=lr, weight_decay=wd, adamw=adamw)
+    opt_b = (torch.optim.AdamW if adamw else torch.optim.Adam)(b.parameters(), lr=lr, weight_decay=wd)
+    w = torch.tensor(CE_W, device=cuda)
+    for step in range(6):
+        feats = [f.to(cuda) for f in seeded_feats(100 + step, [(8, 15, 256)] * 3)]
+        target = torch.randint(0, 2, (8,), generator=torch.Generator().manual_seed(step)).to(cuda)
+        for m, opt in ((a, opt_a), (b, opt_b)):
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m.forward_features(*feats), target, weight=w).backward()
+            opt.step()
+    # Elements whose gradient is rounding noise (e.g. the key bias, to which softmax is invariant) move by +-lr per
+    # step in either run, so the model-level bound is the largest possible drift; exact update arithmetic is pinned
+    # by test_adam_kernel_semantics below.
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 2.0 * lr * 6, n
+        assert (pa - pb).abs().median().item() < 1e-6 + 1e-2 * lr, n
+    # the optimizer state is visible per parameter (torch's state_dict layout) and the translator's parameters now
+    # live in one flat buffer (a single launch per step)
+    st = opt_a.state[a.ln.weight]
+    assert st["exp_avg"].shape == a.ln.weight.shape and int(st["step"].item()) == 6
+    assert len({p.untyped_storage().data_ptr() for p in a.parameters()}) == 1
+    sd = opt_a.state_dict()
+    assert len(sd["state"]) == len(list(a.parameters()))
+
+
+@pytest.mark.parametrize("adamw,wd", [(False, 0.0), (False, 0.05), (True, 0.05)])
+def test_adam_kernel_semantics(egx_lib, cuda, adamw, wd):
+    """Identical gradients into FusedAdam and torch.optim: parameters must agree to fp32 rounding. Covers stand-alone
+    tensors, sizes that are not multiples of 4 and gradients that are unaligned views of a shared buffer."""
+    from egot2_amd.train import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(7,), (128, 33), (1, 3, 128), (5,), (2048, 128)]
+    pa = [torch.nn.Parameter(torch.randn(s, generator=g).to(cuda)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FusedAdam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd, adamw=adamw)
+    ob = (torch.optim.AdamW if adamw else torch.optim.Adam)(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd)
+    for step in range(8):
+        flat = torch.randn(3 + sum(torch.Size(s).numel() + 1 for s in shapes[:3]), generator=g).to(cuda)
+        off = 3                                            # the first three gradients are unaligned views of `flat`
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if i < 3:
+                n = x.numel()
+                x.grad = flat[off:off + n].view(x.shape)
+                off += n + 1
+            else:
+                x.grad = torch.randn(x.shape, generator=g).to(cuda)
+            y.grad = x.grad.detach().clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=2e-5, atol=2e-6), (x - y).abs().max().item()
+
+
+def test_whole_training_step_in_one_graph(egx_lib, cuda):
+    """forward + fused CE + backward + FusedAdam captured once and replayed: parameters must follow the eager run."""
+    from egot2_amd.train import CrossEntropyLoss, FusedAdam
+    ref_model, m = _ttm(cuda, 3), _ttm(cuda, 3)
+    crit = CrossEntropyLoss(torch.FloatTensor(CE_W)).to(cuda)
+    feats = [f.to(cuda) for f in seeded_feats(77, [(16, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (16,), generator=torch.Generator().manual_seed(1)).to(cuda)
+
+    def one_step(model, opt):
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model.forward_features(*feats), target)
+        loss.backward()
+        opt.step()
+        return loss
+
+    opt_r = FusedAdam(ref_model.parameters(), lr=5e-4)
+    for _ in range(5):
+        one_step(ref_model, opt_r)
+
+    opt = FusedAdam(m.parameters(), lr=5e-4)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one_step(m, opt)                      # eager step 1: builds the flat parameter buffer before capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss = one_step(m, opt)
+    for _ in range(3):                        # capture does not execute: steps 2..4 by replay, then compare at 4 vs 5?
+        graph.replay()
+    torch.cuda.synchronize()
+    # eager 1 + 3 replays = 4 steps; bring the reference to the same count
+    ref4 = _ttm(cuda, 3)
+    opt4 = FusedAdam(ref4.parameters(), lr=5e-4)
+    for _ in range(4):
+        one_step(ref4, opt4)
+    for (n, pa), (_, pb) in zip(m.named_parameters(), ref4.named_parameters()):
+        # atomically accumulated gradients differ in the last bits between runs; noise-level gradients (key bias)
+        # then move by +-lr per step in either run
+        assert (pa - pb).abs().max().item() <= 2.0 * 5e-4 * 4, n
+        assert (pa - pb).abs().median().item() < 1e-5, n
+    assert int(opt._step_dev.item()) == 4 and torch.isfinite(loss).item()
