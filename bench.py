@@ -196,6 +196,23 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(dtype, B, T, L, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate runs, KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes). PMC
+    collection needs the profiler, so the number is read from profiles/ and only when it was taken on this workload."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_{dtype}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            w = d.get("workload", {})
+            if (w.get("batch"), w.get("frames"), w.get("layers")) == (B, T, L) and kernel in d["kernels"]:
+                return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(f, here)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
 def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
     """Dominant kernel = fused_bwd_kernel (the per-clip backward: LayerNorm/attention/projection input gradients and the
     FFN input gradient with H recomputed). Its ALGORITHMIC FLOPs per launch are the dX-type GEMMs of the backward
@@ -225,8 +242,10 @@ def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
                 "frac": None, "traffic": None}
     t = res["fused_bwd_kernel"]
     ach = flops["fused_bwd_kernel"] / t / 1e12
+    traffic, traffic_src = pmc_traffic(dtype, B, T, L, "egx::fused_bwd_kernel")
     return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": PEAK_TFLOPS[dtype],
-            "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": None,
+            "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": traffic, "traffic_unit": "bytes/launch",
+            "traffic_source": traffic_src,
             "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
             "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
                                   "frac": flops[k] / v / 1e12 / PEAK_TFLOPS[dtype]} for k, v in res.items() if k != "fused_bwd_kernel"}}
