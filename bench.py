@@ -221,10 +221,14 @@ def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
     import ctypes as C
     S = K * T
     N = B * S
+    ffn = L * 4.0 * N * d * dff
+    attn_fwd = K * 2.0 * B * T * 256 * d + L * (2.0 * N * d * 3 * d + 4.0 * B * S * S * d + 2.0 * N * d * d)
     flops = {
-        "fused_bwd_kernel": L * (2.0 * N * d * 3 * d + 2.0 * N * d * d + 4.0 * N * d * dff + 8.0 * B * S * S * d),
-        "fused_fwd_kernel": K * 2.0 * B * T * 256 * d + L * (2.0 * N * d * 3 * d + 4.0 * B * S * S * d + 2.0 * N * d * d + 4.0 * N * d * dff),
-        "ffn_dw_kernel": L * 4.0 * N * d * dff,
+        "fused_bwd_kernel": L * (2.0 * N * d * 3 * d + 2.0 * N * d * d + 8.0 * B * S * S * d) + ffn,
+        "fused_fwd_kernel": attn_fwd + ffn,
+        "ffn_dw_kernel": ffn,
+        "ffn_fwd_kernel": ffn,
+        "ffn_bwd_kernel": ffn,
     }
     lib.egx_timing_enable(1)
     reps = 16
@@ -232,10 +236,15 @@ def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
         step()
     torch.cuda.synchronize()
     res = {}
-    for which, name in enumerate(("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel")):
+    for which, name in enumerate(("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel")):
         tot, cnt = C.c_double(0), C.c_int(0)
         if lib.egx_timing_read(which, C.byref(tot), C.byref(cnt)) == 0 and cnt.value:
             res[name] = tot.value / cnt.value * 1e-3
+    # split mode: the FFN halves run as their own launches; the per-clip kernels then hold only the attention halves
+    if "ffn_fwd_kernel" in res:
+        flops["fused_fwd_kernel"] -= ffn
+    if "ffn_bwd_kernel" in res:
+        flops["fused_bwd_kernel"] -= ffn
     lib.egx_timing_enable(0)
     if "fused_bwd_kernel" not in res:   # generic path (shape outside the fused kernels)
         return {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
