@@ -222,11 +222,12 @@ static int chunk_rows(int S, int DH, size_t extra_per_row) {
 
 #define EGX_ATTN_DISPATCH(KERNEL, ...)                                                                   \
     switch (DH) {                                                                                        \
+        case 16: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds, st, __VA_ARGS__); break;            \
         case 32: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), lds, st, __VA_ARGS__); break;            \
         case 64: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(256), lds, st, __VA_ARGS__); break;           \
         case 96: hipLaunchKernelGGL(KERNEL<24>, grid, dim3(256), lds, st, __VA_ARGS__); break;           \
         case 128: hipLaunchKernelGGL(KERNEL<32>, grid, dim3(256), lds, st, __VA_ARGS__); break;          \
-        default: EGX_CHECK(false, "attention: head dim %d unsupported (32/64/96/128)", DH);              \
+        default: EGX_CHECK(false, "attention: head dim %d unsupported (16/32/64/96/128)", DH);              \
     }
 
 int attention_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, int d,

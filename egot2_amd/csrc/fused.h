@@ -133,12 +133,12 @@ int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 // One "dW[R][C] += G^T X" problem of the grouped small-weight-gradient kernel: G (K, R) and X (K, C) token-major.
 struct SmallDwProblem {
     const float* G; const float* X; float* out;
-    int R, C, K, ldg, ldx, first_item;
+    int R, C, K, ldg, ldx, first_block, splits;   // first_block / splits are set by small_dw()
 };
 constexpr int SMALL_DW_MAX = 8;
 struct SmallDwParams {
     SmallDwProblem pr[SMALL_DW_MAX];
-    int n, items, splits;
+    int n, per;           // per = K-blocks (32 tokens) per workgroup, the same for every problem (balanced grid)
 };
 int small_dw(SmallDwParams& p, int compute, hipStream_t st);
 int seed_advance(uint64_t* seed, hipStream_t st);

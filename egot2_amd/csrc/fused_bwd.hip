@@ -9,6 +9,7 @@
 //
 // Same operand convention as the forward (fused_dev.h). Reference math: autograd of
 // torch.nn.TransformerEncoderLayer as built at HHI/models/ttm/model_taskspecific.py:212-215.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
@@ -467,14 +468,14 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     int pi = 0;
-    while (pi + 1 < p.n && (int)blockIdx.x >= p.pr[pi + 1].first_item) ++pi;
+    while (pi + 1 < p.n && (int)blockIdx.x >= p.pr[pi + 1].first_block) ++pi;
     const SmallDwProblem& pr = p.pr[pi];
-    const int item = blockIdx.x - pr.first_item;
+    const int local = blockIdx.x - pr.first_block;
+    const int item = local / pr.splits, split = local - item * pr.splits;
     const int ncol = (pr.C + 127) / 128;
     const int row0 = (item / ncol) * 64, col0 = (item % ncol) * 128;
     const int nkb = (pr.K + 31) / 32;
-    const int per = (nkb + p.splits - 1) / p.splits;
-    const int kb_beg = blockIdx.y * per, kb_end = min(nkb, kb_beg + per);
+    const int kb_beg = split * p.per, kb_end = min(nkb, kb_beg + p.per);
     if (kb_beg >= kb_end) return;
 
     f32x4 acc[8];
@@ -527,21 +528,33 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
 }
 
 int small_dw(SmallDwParams& p, int compute, hipStream_t st) {
-    int items = 0, maxk = 1;
+    int items[SMALL_DW_MAX], nkb[SMALL_DW_MAX], total_items = 0;
     for (int i = 0; i < p.n; ++i) {
         EGX_CHECK(p.pr[i].R % 4 == 0 && p.pr[i].C % 4 == 0 && p.pr[i].ldg % 4 == 0 && p.pr[i].ldx % 4 == 0,
                   "small_dw: problem %d needs 4-aligned dimensions", i);
-        p.pr[i].first_item = items;
-        items += cdiv(p.pr[i].R, 64) * cdiv(p.pr[i].C, 128);
-        maxk = max(maxk, p.pr[i].K);
+        items[i] = cdiv(p.pr[i].R, 64) * cdiv(p.pr[i].C, 128);
+        nkb[i] = cdiv(p.pr[i].K, 32);
+        total_items += items[i];
     }
-    if (!items) return 0;
-    p.items = items;
-    int nkb = cdiv(maxk, 32);
-    p.splits = max(1, min(nkb / 4, 512 / items));
-    dim3 grid(items, p.splits);
-    if (compute == 1) hipLaunchKernelGGL(small_dw_kernel<true>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(small_dw_kernel<false>, grid, dim3(256), 0, st, p);
+    if (!total_items) return 0;
+    // the same number of K-blocks per workgroup for every problem (so all workgroups finish together), as small as
+    // two workgroups per CU allow
+    int per = 1;
+    for (;; ++per) {
+        int blocks = 0;
+        for (int i = 0; i < p.n; ++i) blocks += items[i] * cdiv(nkb[i], per);
+        if (blocks <= 512 || per >= 4096) break;
+    }
+    if (const char* e = getenv("EGX_SMALL_DW_PER")) per = max(1, atoi(e));     // tuning aid
+    p.per = per;
+    int blocks = 0;
+    for (int i = 0; i < p.n; ++i) {
+        p.pr[i].first_block = blocks;
+        p.pr[i].splits = cdiv(nkb[i], per);
+        blocks += items[i] * p.pr[i].splits;
+    }
+    if (compute == 1) hipLaunchKernelGGL(small_dw_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(small_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
     EGX_LAUNCH_CHECK();
     return 0;
 }

@@ -87,9 +87,12 @@ class TranslatorMixin:
         if seed_dev is not None and self.training:
             from ._lib import load, check
             check(load().egx_seed_advance(seed_dev.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        impl = self.egx_impl
+        if impl == "auto" and pos_table is not None and pos_table.requires_grad:
+            impl = "generic"       # learned positions (HOI `pe`): their gradient comes from the shape-generic backward
         spec = EncoderSpec(d_model=d, n_heads=layer0.self_attn.num_heads, d_ff=layer0.linear1.out_features,
                            n_layers=len(encoder.layers), segments=segments, ln_eps=ln.eps,
-                           compute=self.egx_compute, impl=self.egx_impl,
+                           compute=self.egx_compute, impl=impl,
                            p_drop=p_drop, p_pos=p_pos, p_feat=p_feat,
                            training=bool(self.training), seed=self._egx_seed() if self.training else 0,
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,

@@ -227,3 +227,88 @@ def ref_lta4_forward(model, feat_pnr, feat_oscc, feat_action, feat_lta):
     f = model.ln(f) + model.pe
     out = model.transformer(f).mean(dim=1)
     return model.decode(out)
+
+
+# ---- HOI EgoT2-s: PNR/OSCC translator and the two action-recognition translators -------------
+class _Pick(nn.Module):
+    """Frozen-backbone stand-in that returns element `i` of the list it is called with (the reference hands the same
+    input list to the PNR and OSCC backbones: `x_oscc = x_pnr.copy()`)."""
+
+    def __init__(self, i):
+        super().__init__()
+        self.i = i
+
+    def forward(self, x, *a, **k):
+        return x[self.i]
+
+
+class _ListPass(nn.Module):
+    """SlowFast stand-in: `model(x, middle=True)` returns the [slow, fast] pathway list unchanged."""
+
+    def forward(self, x, *a, **k):
+        return list(x)
+
+
+class _LtaPass(nn.Module):
+    """ForecastingEncoderDecoder stand-in: (n, B, 2048) clip features = the slow input's first spatial element
+    (indexing only, no arithmetic), transposed the way the reference expects it."""
+
+    def forward(self, x, *a, **k):
+        return x[0][:, :, :, 0, 0, 0].transpose(0, 1)
+
+
+def hoi_s_cfg(d=128, layers=2, heads=8, num_classes=(5, 7), task="state_change_detection", n_clips=2, dropout=0.0,
+              feat_dropout=0.0):
+    from types import SimpleNamespace as NS
+    return NS(DATA=NS(TASK=task),
+              FORECASTING=NS(NUM_INPUT_CLIPS=n_clips, INPUT_OFFSET=0),
+              MODEL=NS(TRANSLATION_INPUT_FEATURES=d, TRANSLATION_LAYERS=layers, TRANSLATION_HEADS=heads,
+                       TRANSLATION_DROPOUT=dropout, FEAT_DROPOUT_RATE=feat_dropout, TRANSFORMER_DROPOUT_RATE=dropout,
+                       NUM_CLASSES=list(num_classes)),
+              PRETRAIN=NS(PNR_CFG=None, OSCC_CFG=None, ACTION_CFG=None, LTA_CFG=None, PNR_FT=True, OSCC_FT=True, ACTION_FT=True))
+
+
+def ref_pnr3(cfg) -> nn.Module:
+    """Real TaskFusionMFTransformer3TaskDropout (HOI/models/pnr/video_model_transfer_3task.py:212-258). With the
+    PRETRAIN.*_CFG entries None the base class builds no backbone; pass-through stand-ins are attached instead and the
+    REAL forward(x1, x2) runs on x1 = [pnr_feat, oscc_feat], x2 = [slow (B,2048,8,1,1), fast (B,256,8,1,1)]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.pnr.video_model_transfer_3task as m
+    model = m.TaskFusionMFTransformer3TaskDropout(cfg)
+    model.pnr_model, model.oscc_model, model.recognition_model = _Pick(0), _Pick(1), _ListPass()
+    return model
+
+
+def ref_ar3(cfg) -> nn.Module:
+    """Real TaskFusionMFTransformer3Task of the action-recognition task (HOI/models/lta/lta_models_transfer.py:96-137):
+    forward(x_action=[slow, fast], x_pnr=[pnr_feat, oscc_feat]) -> [verb logits, noun logits]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.lta.lta_models_transfer as m
+    model = m.TaskFusionMFTransformer3Task(cfg)
+    model.pnr_model, model.oscc_model, model.recognition_model = _Pick(0), _Pick(1), _ListPass()
+    return model
+
+
+def ref_ar2(cfg) -> nn.Module:
+    """Real TaskFusionMFTransformer2TaskAR (HOI/models/lta/lta_models_transfer.py:170-235); the constructors and
+    checkpoint loaders of its two frozen backbones are patched out. forward(x) with x = [slow (B, n+1, 2048, 8, 1, 1),
+    fast (B, n+1, 256, 8, 1, 1)]: the last clip feeds the action pathway, the first n clips the LTA pathway."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.lta.lta_models_transfer as m
+    from types import SimpleNamespace as NS
+    m.load_lta_config = lambda path: NS(MODEL=NS(NUM_CLASSES=None, HEAD_ACT=None), CHECKPOINT_FILE_PATH=None)
+    m.SlowFast = lambda cfg, with_head=True: _ListPass()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _LtaPass()
+    m.load_lta_backbone = lambda *a, **k: None
+    m.freeze_params = lambda *a, **k: None
+    m.freeze_backbone_params = lambda *a, **k: None
+    return m.TaskFusionMFTransformer2TaskAR(cfg)
+
+
+def pathway5d(feat: torch.Tensor) -> torch.Tensor:
+    """(B, T, C) pooled pathway features -> the (B, C, T, 1, 1) tensor a SlowFast pathway would hand over (the
+    reference's adaptive average pools are the identity on it when T already has the pooled length)."""
+    return feat.permute(0, 2, 1)[..., None, None].contiguous()

@@ -191,5 +191,16 @@ def pnr3_forward(sd, n_heads: int, pnr_feat, oscc_feat, slow_feat, fast_feat) ->
     return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])
 
 
+def ar_forward(sd, n_heads: int, feats: Sequence[torch.Tensor], proj_names: Sequence[str]):
+    """HOI/models/lta/lta_models_transfer.py:125-137 (3-task) and :227-235 (2-task AR) on features: cat(proj_k(feat_k))
+    -> ln + pe -> encoder -> token mean -> two heads that both start with the SAME `ln`
+    (`linear_head{1,2} = Sequential(self.ln, Linear)`); only `ln.*` is read so that its gradient sums all three uses."""
+    x = hoi_tokens(sd, list(feats), list(proj_names))
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+    y = layer_norm(x.mean(dim=1), sd["ln.weight"], sd["ln.bias"])
+    return [linear(y, sd["linear_head1.1.weight"], sd["linear_head1.1.bias"]),
+            linear(y, sd["linear_head2.1.weight"], sd["linear_head2.1.bias"])]
+
+
 def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

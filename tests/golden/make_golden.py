@@ -30,6 +30,11 @@ HHI_CASES = [
 ]
 HOI_CASES = [
     dict(name="lta4_B3_n4_L2_d256", kind="lta4", B=3, n=4, L=2, d=256, h=8, classes=[5, 7], z=3, wseed=61, fseed=62),
+    # HOI EgoT2-s (row F3): real recipes ts_pnr.yaml (d=128, 8 heads -> head dim 16, d_ff = 2d) and ts_ar.yaml
+    dict(name="pnr3_B2_L2_d128", kind="pnr3", B=2, L=2, d=128, h=8, task="state_change_detection", wseed=71, fseed=72),
+    dict(name="pnr3kf_B2_L1_d256", kind="pnr3", B=2, L=1, d=256, h=8, task="keyframe_localization", wseed=73, fseed=74),
+    dict(name="ar3_B2_L2_d128", kind="ar3", B=2, L=2, d=128, h=8, classes=[11, 70], wseed=81, fseed=82),
+    dict(name="ar2_B3_L1_d128", kind="ar2", B=3, L=1, d=128, h=4, n=2, classes=[11, 70], wseed=91, fseed=92),
 ]
 
 
@@ -90,24 +95,60 @@ def run_hhi():
         print("wrote", c["name"], "loss", float(loss))
 
 
+def hoi_feat_shapes(c):
+    B = c["B"]
+    if c["kind"] == "lta4":
+        return [(B, c["n"], 8192), (B, c["n"], 8192), (B, c["n"], c["d"]), (B, c["n"], 2048)]
+    if c["kind"] == "pnr3":
+        return [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)]           # pnr, oscc, slow, fast
+    if c["kind"] == "ar3":
+        return [(B, 8, 2048), (B, 8, 256), (B, 16, 8192), (B, 16, 8192)]           # slow, fast, pnr, oscc
+    if c["kind"] == "ar2":
+        return [(B, 8, 2048), (B, 8, 256), (B, c["n"], 2048)]                      # slow, fast, lta
+    raise KeyError(c["kind"])
+
+
 def run_hoi():
     import numpy as np
     import torch
     from oracle import ref_harness as rh
     from tests.util import seeded_feats, seeded_state_dict
+    lin = lambda o: (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum()  # noqa: E731
     for c in HOI_CASES:
-        cfg = rh.hoi_cfg(d=c["d"], heads=c["h"], layers=c["L"], n_clips=c["n"], num_classes=c["classes"], z=c["z"])
-        m = rh.ref_lta4(cfg)
+        feats = seeded_feats(c["fseed"], hoi_feat_shapes(c))
+        if c["kind"] == "lta4":
+            cfg = rh.hoi_cfg(d=c["d"], heads=c["h"], layers=c["L"], n_clips=c["n"], num_classes=c["classes"], z=c["z"])
+            m = rh.ref_lta4(cfg)
+        elif c["kind"] == "pnr3":
+            m = rh.ref_pnr3(rh.hoi_s_cfg(d=c["d"], layers=c["L"], task=c["task"]))
+        elif c["kind"] == "ar3":
+            m = rh.ref_ar3(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"]))
+        else:
+            m = rh.ref_ar2(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"], n_clips=c["n"]))
         m.load_state_dict(seeded_state_dict(m, c["wseed"]))
         m.train()
-        B, n, d = c["B"], c["n"], c["d"]
-        feats = seeded_feats(c["fseed"], [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
-        outs = rh.ref_lta4_forward(m, *feats)
-        loss = sum((o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum() for o in outs)
+        if c["kind"] == "lta4":
+            outs = rh.ref_lta4_forward(m, *feats)
+            named = {"out_verb": outs[0], "out_noun": outs[1]}
+        elif c["kind"] == "pnr3":       # the REAL forward(x1, x2) over pass-through backbones
+            named = {"out": m([feats[0], feats[1]], [rh.pathway5d(feats[2]), rh.pathway5d(feats[3])])}
+        elif c["kind"] == "ar3":        # REAL forward(x_action, x_pnr)
+            outs = m([rh.pathway5d(feats[0]), rh.pathway5d(feats[1])], [feats[2], feats[3]])
+            named = {"out_verb": outs[0], "out_noun": outs[1]}
+        else:                           # REAL forward(x): clips 0..n-1 feed the LTA pathway, the last clip SlowFast
+            B, n = c["B"], c["n"]
+            x_slow = torch.zeros(B, n + 1, 2048, 8, 1, 1)
+            x_fast = torch.zeros(B, n + 1, 256, 8, 1, 1)
+            x_slow[:, -1] = rh.pathway5d(feats[0])
+            x_fast[:, -1] = rh.pathway5d(feats[1])
+            x_slow[:, :n, :, 0, 0, 0] = feats[2]
+            outs = m([x_slow, x_fast])
+            named = {"out_verb": outs[0], "out_noun": outs[1]}
+        loss = sum(lin(o) for o in named.values())
         m.zero_grad()
         loss.backward()
-        out = {"config": np.array(json.dumps(c)), "sd_keys": np.array(sd_keys(m)), "loss": loss.detach().numpy(),
-               "out_verb": outs[0].detach().numpy(), "out_noun": outs[1].detach().numpy()}
+        out = {"config": np.array(json.dumps(c)), "sd_keys": np.array(sd_keys(m)), "loss": loss.detach().numpy()}
+        out.update({k: v.detach().numpy() for k, v in named.items()})
         digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, out)
         np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **out)
         print("wrote", c["name"], "loss", float(loss))

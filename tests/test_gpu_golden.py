@@ -31,6 +31,12 @@ def hip_run(c, model, feats):
     if c["kind"] == "lta4":
         o = model.forward_features(*feats)
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
+    if c["kind"] == "pnr3":
+        out = model.forward_features(*feats)
+        return {"out": out}, lin(out)
+    if c["kind"] in ("ar3", "ar2"):
+        o = model.forward_features(*feats)
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
     raise KeyError(c["kind"])
 
 

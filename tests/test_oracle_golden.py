@@ -42,13 +42,32 @@ def build_ours(c):
                           TRANSLATION_DROPOUT=0.0, NUM_CLASSES=c["classes"], DROPOUT_RATE=0.0, HEAD_ACT="softmax"),
                  TEST=NS(NO_ACT=False))
         return hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+    if c["kind"] == "pnr3":
+        from egot2_amd import hoi_pnr
+        cfg = NS(DATA=NS(TASK=c["task"]),
+                 MODEL=NS(TRANSLATION_INPUT_FEATURES=c["d"], TRANSLATION_LAYERS=c["L"], FEAT_DROPOUT_RATE=0.0,
+                          TRANSFORMER_DROPOUT_RATE=0.0))
+        return hoi_pnr.TaskFusionMFTransformer3TaskDropout(cfg)
+    if c["kind"] in ("ar3", "ar2"):
+        from egot2_amd import hoi_ar
+        cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=c.get("n", 2), INPUT_OFFSET=0),
+                 MODEL=NS(TRANSLATION_INPUT_FEATURES=c["d"], TRANSLATION_LAYERS=c["L"], TRANSLATION_HEADS=c["h"],
+                          TRANSLATION_DROPOUT=0.0, NUM_CLASSES=c["classes"]))
+        return (hoi_ar.TaskFusionMFTransformer3Task if c["kind"] == "ar3" else hoi_ar.TaskFusionMFTransformer2TaskAR)(cfg)
     raise KeyError(c["kind"])
 
 
 def fixture_feats(c):
+    B = c["B"]
     if c["kind"] == "lta4":
-        B, n, d = c["B"], c["n"], c["d"]
+        n, d = c["n"], c["d"]
         return seeded_feats(c["fseed"], [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
+    if c["kind"] == "pnr3":
+        return seeded_feats(c["fseed"], [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)])
+    if c["kind"] == "ar3":
+        return seeded_feats(c["fseed"], [(B, 8, 2048), (B, 8, 256), (B, 16, 8192), (B, 16, 8192)])
+    if c["kind"] == "ar2":
+        return seeded_feats(c["fseed"], [(B, 8, 2048), (B, 8, 256), (B, c["n"], 2048)])
     return seeded_feats(c["fseed"], [(c["B"], c["T"], 256)] * c["n_tasks"])
 
 
@@ -74,6 +93,16 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
         return outs, loss, sdd
     if c["kind"] == "lta4":
         o = tr.lta4_forward(sdd, c["h"], *f, c["classes"])
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
+    if c["kind"] == "pnr3":
+        out = tr.pnr3_forward(sdd, c["h"], *f)
+        out = out.unsqueeze(1 if "keyframe_localization" in c["task"] else 2)
+        return {"out": out}, lin(out), sdd
+    if c["kind"] == "ar3":
+        o = tr.ar_forward(sdd, c["h"], f, ["proj3_slow", "proj3_fast", "proj1", "proj2"])
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
+    if c["kind"] == "ar2":
+        o = tr.ar_forward(sdd, c["h"], f, ["proj_slow", "proj_fast", "proj_lta"])
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
     raise KeyError(c["kind"])
 
@@ -106,7 +135,10 @@ def test_oracle_matches_reference_fixture(name):
     ref_keys = json.loads(str(z["sd_keys"]))
     ours = {k: list(v.shape) for k, v in model.state_dict().items()}
     assert ours == ref_keys, "state_dict keys/shapes differ from the reference module"
-    sd = seeded_state_dict(model, c["wseed"])
+    # through load_state_dict: modules that appear under two names (the HOI heads start with the shared `ln`) end up
+    # with ONE value, exactly as in the reference
+    model.load_state_dict(seeded_state_dict(model, c["wseed"]))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     outs, loss, sdd = oracle_run(c, sd, fixture_feats(c), torch.float64)
     loss.backward()
     grads = {k: v.grad for k, v in sdd.items() if v.grad is not None}
