@@ -312,3 +312,78 @@ def pathway5d(feat: torch.Tensor) -> torch.Tensor:
     """(B, T, C) pooled pathway features -> the (B, C, T, 1, 1) tensor a SlowFast pathway would hand over (the
     reference's adaptive average pools are the identity on it when T already has the pooled length)."""
     return feat.permute(0, 2, 1)[..., None, None].contiguous()
+
+
+# ---- HOI EgoT2-g (config C5) ----------------------------------------------------------------------------------------
+class _Flip(nn.Module):
+    """OSCC stand-in for the 'lta' prompts, where the reference feeds PNR and OSCC the same clip tensor
+    (`copy.deepcopy(video_pnr)`): returns its input reversed along the channel axis (indexing only) so that the two
+    feature streams differ."""
+
+    def forward(self, x, *a, **k):
+        return x[0].flip(-1)
+
+
+class _AcPass(nn.Module):
+    """Recognition-model stand-in with the two call protocols of the 6-task model: `model(x, middle=True)` -> the
+    [slow, fast] pathway list; `model([a_i, l_i])` (per-clip, with head) -> a_i."""
+
+    def forward(self, x, *a, middle=False, **k):
+        return list(x) if middle else x[0]
+
+
+class _LtaPass2(nn.Module):
+    """`lta_model(video_ac, None, middle=True)` -> (n, B, 2048): the second element of video_ac, transposed."""
+
+    def forward(self, x, *a, **k):
+        return x[1].transpose(0, 1)
+
+
+def hoi_g_args(hidden_dim=256, num_heads=8, num_layers=2, dropout=0.0):
+    return Namespace(hidden_dim=hidden_dim, num_heads=num_heads, num_layers=num_layers, dropout=dropout,
+                     pnr_cfg_file=None, oscc_cfg_file=None, action_cfg_file=None, lta_cfg_file=None)
+
+
+HOI_G_VOCAB = {'</s>': 0, '<unk>': 1, 'pnr': 2, 'oscc': 3, 'action_verb': 4, 'action_noun': 5, 'lta_verb': 6, 'lta_noun': 7,
+               '0': 8, '1': 9, '2': 10, '3': 11}
+
+
+def ref_hoi_g(args, vocab=None) -> nn.Module:
+    """Real TaskTranslationPromptTransformer6Task (HOI/models/multitask/video_model_builder.py:278-383); config loaders,
+    backbone constructors and checkpoint loaders are patched out, the encoder arithmetic is the reference's. Call
+    `model.encode(video_pnr, video_ac, task)`:
+      other tasks: video_pnr = [pnr_feat (B,16,8192), oscc_feat], video_ac = [slow (B,2048,8,1,1), fast (B,256,8,1,1)]
+      'lta*'     : video_pnr = (B, n, 1, 8192) tensor, video_ac = [action (B, n, d), lta (B, n, 2048)]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.multitask.video_model_builder as m
+    from types import SimpleNamespace as NS
+    mk = lambda: NS(MISC=NS(CHECKPOINT_FILE_PATH=None), MODEL=NS(NO_TEMP_POOL=False, NUM_CLASSES=None, HEAD_ACT=None),  # noqa: E731
+                    CHECKPOINT_FILE_PATH=None, CHECKPOINT_FILE_PATH_LTA=None, FORECASTING=NS(NUM_ACTIONS_TO_PREDICT=20))
+    m.load_config_file = lambda path: mk()
+    m.load_lta_config = lambda path: mk()
+    m.KeyframeLocalizationResNet = lambda cfg: _Pick(0)
+    m.StateChangeClsResNet = lambda cfg: _Pick(1)
+    m.SlowFast = lambda cfg, with_head=True: _AcPass()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _LtaPass2()
+    for name in ("load_checkpoint", "load_lta_backbone", "freeze_params", "load_recognition_backbone", "freeze_backbone_params"):
+        setattr(m, name, lambda *a, **k: None)
+    orig = m.CustomDecoderLayer._mha_block
+    if orig.__code__.co_argcount == 5:      # torch >= 2 passes is_causal
+
+        def _mha_block(self, x, mem, attn_mask, key_padding_mask, is_causal=False):
+            return orig(self, x, mem, attn_mask, key_padding_mask)
+        m.CustomDecoderLayer._mha_block = _mha_block
+    return m.TaskTranslationPromptTransformer6Task(args, vocab or HOI_G_VOCAB)
+
+
+def hoi_g_encode_lta(model, feat_pnr_clips, feat_action, feat_lta):
+    """Runs the REAL encode() on the 'lta' branch. feat_pnr_clips (B, n, 1, 8192): the reference averages each clip's
+    frames itself (`.mean(dim=1)`, one frame here); the OSCC stream is the channel-reversed copy (see _Flip)."""
+    model.pnr_model, model.oscc_model = _Pick(0), _Flip()
+    return model.encode(feat_pnr_clips, [feat_action, feat_lta], "lta_verb")
+
+
+def hoi_g_encode_other(model, task, feat_pnr, feat_oscc, slow, fast):
+    model.pnr_model, model.oscc_model = _Pick(0), _Pick(1)
+    return model.encode([feat_pnr, feat_oscc], [pathway5d(slow), pathway5d(fast)], task)

@@ -202,5 +202,27 @@ def ar_forward(sd, n_heads: int, feats: Sequence[torch.Tensor], proj_names: Sequ
             linear(y, sd["linear_head2.1.weight"], sd["linear_head2.1.bias"])]
 
 
+def hoi_g_encode(sd, n_heads: int, task: str, feat_pnr, feat_oscc, a, b) -> torch.Tensor:
+    """TaskTranslationPromptTransformer6Task.encode (HOI/models/multitask/video_model_builder.py:320-347) on features.
+    'lta' prompts: a = action features (B, n, d) used unprojected (task id 2), b = LTA features (B, n, 2048) (task id 3);
+    otherwise a / b are the pooled SlowFast slow / fast pathways, projected separately, concatenated to ONE 16-token
+    block that shares task id 2 and one position run. Returns the decoder memory (S, B, d)."""
+    pe = sd["pos_embed.pe"][:, 0, :]
+    lw, lb, te = sd["ln.weight"], sd["ln.bias"], sd["task_embed"]
+    x1 = encode_prepare(feat_pnr, sd["proj_pnr.weight"], sd["proj_pnr.bias"], lw, lb, te[0, 0], pe[:feat_pnr.shape[1]])
+    x2 = encode_prepare(feat_oscc, sd["proj_oscc.weight"], sd["proj_oscc.bias"], lw, lb, te[0, 1], pe[:feat_oscc.shape[1]])
+    if "lta" in task:
+        x3 = encode_prepare(a, None, None, lw, lb, te[0, 2], pe[:a.shape[1]])
+        x4 = encode_prepare(b, sd["proj_lta.weight"], sd["proj_lta.bias"], lw, lb, te[0, 3], pe[:b.shape[1]])
+        x = torch.cat((x1, x2, x3, x4), dim=1)
+    else:
+        f3 = torch.cat((linear(a, sd["proj_action_slow.weight"], sd["proj_action_slow.bias"]),
+                        linear(b, sd["proj_action_fast.weight"], sd["proj_action_fast.bias"])), dim=1)
+        x3 = encode_prepare(f3, None, None, lw, lb, te[0, 2], pe[:f3.shape[1]])
+        x = torch.cat((x1, x2, x3), dim=1)
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    return x.permute(1, 0, 2)
+
+
 def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

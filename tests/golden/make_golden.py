@@ -35,6 +35,8 @@ HOI_CASES = [
     dict(name="pnr3kf_B2_L1_d256", kind="pnr3", B=2, L=1, d=256, h=8, task="keyframe_localization", wseed=73, fseed=74),
     dict(name="ar3_B2_L2_d128", kind="ar3", B=2, L=2, d=128, h=8, classes=[11, 70], wseed=81, fseed=82),
     dict(name="ar2_B3_L1_d128", kind="ar2", B=3, L=1, d=128, h=4, n=2, classes=[11, 70], wseed=91, fseed=92),
+    # HOI EgoT2-g encoder (config C5): REAL encode() of the 6-task model on the 48-token and on the per-clip 'lta' layout
+    dict(name="hoig_B2_n3_L2_d256", kind="hoig", B=2, n=3, L=2, d=256, h=8, wseed=95, fseed=96),
 ]
 
 
@@ -105,6 +107,9 @@ def hoi_feat_shapes(c):
         return [(B, 8, 2048), (B, 8, 256), (B, 16, 8192), (B, 16, 8192)]           # slow, fast, pnr, oscc
     if c["kind"] == "ar2":
         return [(B, 8, 2048), (B, 8, 256), (B, c["n"], 2048)]                      # slow, fast, lta
+    if c["kind"] == "hoig":     # pnr, oscc, slow, fast (48-token layout); per-clip pnr frames, action, lta ('lta' layout)
+        n, d = c["n"], c["d"]
+        return [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256), (B, n, 1, 8192), (B, n, d), (B, n, 2048)]
     raise KeyError(c["kind"])
 
 
@@ -121,13 +126,19 @@ def run_hoi():
             m = rh.ref_lta4(cfg)
         elif c["kind"] == "pnr3":
             m = rh.ref_pnr3(rh.hoi_s_cfg(d=c["d"], layers=c["L"], task=c["task"]))
+        elif c["kind"] == "hoig":
+            m = rh.ref_hoi_g(rh.hoi_g_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
         elif c["kind"] == "ar3":
             m = rh.ref_ar3(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"]))
         else:
             m = rh.ref_ar2(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"], n_clips=c["n"]))
         m.load_state_dict(seeded_state_dict(m, c["wseed"]))
         m.train()
-        if c["kind"] == "lta4":
+        if c["kind"] == "hoig":
+            m.pos_embed.dropout.p = 0.0
+            named = {"out_pnr": rh.hoi_g_encode_other(m, "pnr", *feats[:4]),
+                     "out_lta": rh.hoi_g_encode_lta(m, *feats[4:])}
+        elif c["kind"] == "lta4":
             outs = rh.ref_lta4_forward(m, *feats)
             named = {"out_verb": outs[0], "out_noun": outs[1]}
         elif c["kind"] == "pnr3":       # the REAL forward(x1, x2) over pass-through backbones

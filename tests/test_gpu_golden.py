@@ -31,6 +31,9 @@ def hip_run(c, model, feats):
     if c["kind"] == "lta4":
         o = model.forward_features(*feats)
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
+    if c["kind"] == "hoig":
+        outs = {"out_pnr": model.encode_features("pnr", *feats[:4]), "out_lta": model.encode_features("lta_verb", *feats[4:])}
+        return outs, lin(outs["out_pnr"]) + lin(outs["out_lta"])
     if c["kind"] == "pnr3":
         out = model.forward_features(*feats)
         return {"out": out}, lin(out)

@@ -48,6 +48,11 @@ def build_ours(c):
                  MODEL=NS(TRANSLATION_INPUT_FEATURES=c["d"], TRANSLATION_LAYERS=c["L"], FEAT_DROPOUT_RATE=0.0,
                           TRANSFORMER_DROPOUT_RATE=0.0))
         return hoi_pnr.TaskFusionMFTransformer3TaskDropout(cfg)
+    if c["kind"] == "hoig":
+        from egot2_amd import hoi_multitask
+        from oracle.ref_harness import HOI_G_VOCAB
+        return hoi_multitask.TaskTranslationPromptTransformer6Task(
+            NS(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"], dropout=0.0), HOI_G_VOCAB)
     if c["kind"] in ("ar3", "ar2"):
         from egot2_amd import hoi_ar
         cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=c.get("n", 2), INPUT_OFFSET=0),
@@ -68,6 +73,13 @@ def fixture_feats(c):
         return seeded_feats(c["fseed"], [(B, 8, 2048), (B, 8, 256), (B, 16, 8192), (B, 16, 8192)])
     if c["kind"] == "ar2":
         return seeded_feats(c["fseed"], [(B, 8, 2048), (B, 8, 256), (B, c["n"], 2048)])
+    if c["kind"] == "hoig":
+        n, d = c["n"], c["d"]
+        f = seeded_feats(c["fseed"], [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256), (B, n, 1, 8192), (B, n, d), (B, n, 2048)])
+        # feature-level view of the 'lta' branch: one frame per clip (its mean is itself); the OSCC stream of the fixture
+        # is the channel-reversed PNR stream (oracle/ref_harness.py _Flip)
+        pnr_clips = f[4][:, :, 0, :].contiguous()
+        return f[:4] + [pnr_clips, pnr_clips.flip(-1).contiguous(), f[5], f[6]]
     return seeded_feats(c["fseed"], [(c["B"], c["T"], 256)] * c["n_tasks"])
 
 
@@ -98,6 +110,9 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
         out = tr.pnr3_forward(sdd, c["h"], *f)
         out = out.unsqueeze(1 if "keyframe_localization" in c["task"] else 2)
         return {"out": out}, lin(out), sdd
+    if c["kind"] == "hoig":
+        outs = {"out_pnr": tr.hoi_g_encode(sdd, c["h"], "pnr", *f[:4]), "out_lta": tr.hoi_g_encode(sdd, c["h"], "lta_verb", *f[4:])}
+        return outs, lin(outs["out_pnr"]) + lin(outs["out_lta"]), sdd
     if c["kind"] == "ar3":
         o = tr.ar_forward(sdd, c["h"], f, ["proj3_slow", "proj3_fast", "proj1", "proj2"])
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
