@@ -339,6 +339,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         PackParams pk;
         memset(&pk, 0, sizeof(pk));
         pk.bf16 = comp == EGX_BF16;
+        pk.seed_advance = (cfg->advance_seed && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
         FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
         auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose) -> const void* {
             PackDesc& dsc = pk.d[pk.n++];
@@ -507,6 +508,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.saved_res = (const float*)saved + (size_t)N * d;
             bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
             bp.dhid_out = store_hidden() ? (char*)scratch + SC.dhid : nullptr;
+            EGX_CHECK(cfg->zero_bytes % 16 == 0 && (((uintptr_t)cfg->zero_buf) & 15) == 0, "zero_buf must be 16-byte aligned and sized");
+            bp.zero_buf = (float*)cfg->zero_buf; bp.zero_n = cfg->zero_buf ? cfg->zero_bytes / 4 : 0;
             bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
@@ -539,8 +542,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(head_grads->b, oh + 256, head->n_out);
                 add_dst(head_grads->W, oh + 256 + FUSED_HEAD_MAX_OUT, head->n_out * 128);
             }
-            if (reduce_partials(rp, st)) return 1;
-
+            // the partial-row reduction rides in the slab-reduction launch of the first FFN weight gradient
+            bool rp_pending = true;
             void* slab = (char*)scratch + SC.slabs;
             for (int l = 0; l < pl.L; ++l) {
                 const egx_layer& w = layers[l];
@@ -559,9 +562,11 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
                         fp.B = B;
                     }
-                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st)) return 1;
+                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr)) return 1;
+                    rp_pending = false;
                 }
             }
+            if (rp_pending && reduce_partials(rp, st)) return 1;
             // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches
             {
                 SmallDwParams sp;
@@ -591,6 +596,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;
     const int N = (int)pl.N;
+    if (cfg->zero_buf && cfg->zero_bytes) EGX_HIP(hipMemsetAsync(cfg->zero_buf, 0, cfg->zero_bytes, st));
     if (with_head) {
         const float* tk = cfptr(saved, align_up(pl.saved_bytes, 256));
         const float* pooled = tk + (size_t)N * d;

@@ -64,6 +64,7 @@ constexpr int PACK_MAX = 40;
 struct PackParams {
     PackDesc d[PACK_MAX];
     int n, bf16;
+    uint64_t* seed_advance;     // optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed)
 };
 int pack_weights(PackParams& pp, hipStream_t st);
 static inline size_t packed_bytes(int R, int K, int bf16) { return (size_t)R * K * (bf16 ? 2 : 4); }
@@ -87,7 +88,10 @@ static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer
     return (size_t)B * FUSED_TOK_TILES * (d_ff / 16) * 256 * (bf16 ? 2 : 4);
 }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
-int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st);
+struct ReducePartialsParams;
+// `rp` (optional): per-clip partial sums to reduce in the same launch as the slab reduction
+int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
+           const ReducePartialsParams* rp = nullptr);
 
 struct FusedBwdLayer {
     const void* in_proj_wp;    // packed W_in   (R = 384, K = 128): QKV recompute
@@ -124,6 +128,7 @@ struct FusedBwdParams {
     const float* saved_res;
     const uint32_t* relu_bits;
     void* dhid_out;         // optional gradient of the FFN pre-activation, same tile layout as FusedFwdParams::hid_out
+    float* zero_buf; size_t zero_n;   // optional: floats the kernel zero-fills first (the caller's flat gradient buffer)
     float* partials; int P;
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;

@@ -23,6 +23,8 @@ namespace egx {
 
 __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
     int blk = blockIdx.x;
+    if (pp.seed_advance && blk == 0 && threadIdx.x == 0)      // same LCG as seed_advance_kernel
+        *pp.seed_advance = *pp.seed_advance * 6364136223846793005ull + 1442695040888963407ull;
     int di = 0;
     while (di + 1 < pp.n && blk >= pp.d[di + 1].first_block) ++di;
     const PackDesc& d = pp.d[di];

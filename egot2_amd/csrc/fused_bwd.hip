@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 // token-along-K operand tiles (fused_dev.h store_hid_tile), so a wave's A fragments are plain coalesced 1 KB loads
 // and only the two weight-gradient GEMMs remain. K-blocks are pairs of 16-token tiles of the clip-padded token
 // grid (FUSED_TOK_TILES per clip); x1 / g rows of padding tokens are staged as zeros.
-template <bool BF16>
-__global__ __launch_bounds__(256, 2) void ffn_dw_stored_kernel(FfnDwParams p) {
+template <bool BF16, int OCC>
+__global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) {
+    constexpr bool PF = OCC <= 2;      // OCC 3: single LDS buffer, no register prefetch, three workgroups per CU
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE = 32 * LDX;
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -313,13 +314,17 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_stored_kernel(FfnDwParams p) {
         }
     };
 
-    if (kb_beg < kb_end) gload(kb_beg);
+    if (PF && kb_beg < kb_end) gload(kb_beg);
     int cur = 0;
     for (int kb = kb_beg; kb < kb_end; ++kb) {
+        if constexpr (!PF) {
+            gload(kb);
+            __syncthreads();            // everyone is done reading the previous K-block
+        }
         lstore(cur);
         Frag<BF16> aH = nH, aD = nD;
         __syncthreads();
-        if (kb + 1 < kb_end) gload(kb + 1);
+        if (PF && kb + 1 < kb_end) gload(kb + 1);
         const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
         if constexpr (BF16) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_stored_kernel(FfnDwParams p) {
             mma<BF16>(accW1[jt], aD, bx);
             mma<BF16>(accW2[jt], aH, bg);
         }
-        cur ^= 1;
+        if constexpr (PF) cur ^= 1;
     }
 
     float* sw1 = p.slab_w1 + (size_t)split * p.d_ff * FD;
@@ -361,10 +366,11 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_stored_kernel(FfnDwParams p) {
     if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
 }
 
-// Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised.
+// Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised. The same launch can
+// carry the reduction of the per-clip partial rows (blocks >= slab_blocks; see reduce_partials_kernel).
 struct SlabReduce3 { const float* slab[3]; float* out[3]; size_t n[3]; int nslab; };
-__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) {
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+__device__ __forceinline__ void reduce_slabs_block(const SlabReduce3& a, unsigned block) {
+    size_t i = ((size_t)block * 256 + threadIdx.x) * 4;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (i < a.n[k]) {
@@ -379,11 +385,46 @@ __global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) {
         i -= a.n[k];
     }
 }
+// grads[dst] += sum_clip partials[clip][off .. off+len): block (bx, by) of a (P / 64, clip chunks) grid; 256 threads =
+// 64 columns x 4 clip lanes, LDS tree, one atomic per column per block (<= 16 adders per address).
+__device__ __forceinline__ void reduce_partials_block(const ReducePartialsParams& rp, int bx, int by, int ny) {
+    __shared__ float red[4][64];
+    int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    int j = bx * 64 + c;
+    int per = (rp.B + ny - 1) / ny;
+    int b0 = by * per, b1 = min(rp.B, b0 + per);
+    float s = 0.f;
+    if (j < rp.P)
+        for (int b = b0 + g; b < b1; b += 4) s += rp.partials[(size_t)b * rp.P + j];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < rp.P) {
+        float* dst = nullptr;
+        for (int i = 0; i < rp.n; ++i)
+            if (j >= rp.d[i].off && j < rp.d[i].off + rp.d[i].len) dst = rp.d[i].dst + (j - rp.d[i].off);
+        if (dst) atomicAdd(dst, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    }
+}
+__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) { reduce_slabs_block(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void reduce_tail_kernel(SlabReduce3 a, ReducePartialsParams rp, unsigned slab_blocks, int chunks) {
+    if (blockIdx.x < slab_blocks) { reduce_slabs_block(a, blockIdx.x); return; }
+    unsigned pb = blockIdx.x - slab_blocks;
+    reduce_partials_block(rp, (int)(pb / chunks), (int)(pb % chunks), chunks);
+}
+static int partial_chunks(int B) { return B >= 64 ? 16 : (B >= 8 ? 4 : 1); }
 
+// fp32 stored-operand kernel: three workgroups per CU (single LDS buffer, no register prefetch) with 24 token splits;
+// every other variant: two per CU, 16 splits. EGX_FFN_DW_OCC=2|3 overrides (tuning aid).
+static int ffn_dw_occ(bool stored, bool bf16) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("EGX_FFN_DW_OCC"); env = (e && (e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 0; }
+    if (!stored) return 2;
+    return env ? env : (bf16 ? 2 : 3);
+}
+static int ffn_dw_splits(int nkb, int occ) { return min(nkb, occ == 3 ? 24 : 16); }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
     int nkb = (N + 31) / 32;
-    int splits = 16;
-    if (nkb < splits) splits = nkb;
+    int splits = min(nkb, 24);           // sized for the largest split count any variant uses
     if (splits_out) *splits_out = splits;
     return (size_t)splits * ((size_t)2 * d_ff * FD + d_ff) * sizeof(float);
 }
@@ -401,13 +442,17 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
     if (p.hs) {
+        const int occ = ffn_dw_occ(true, BF16);
         static bool attr2_set = false;
         if (!attr2_set) {
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16>),
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16, 2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16, 3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr2_set = true;
         }
-        hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16>), grid, dim3(256), lds, st, p);
+        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16, 3>), grid, dim3(256), lds / 2, st, p);
+        else hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16, 2>), grid, dim3(256), lds, st, p);
     } else {
         hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
     }
@@ -417,12 +462,12 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
 }
 
 // dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H with H, dH recomputed. `slabs` holds ffn_dw_scratch_bytes().
-int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st) {
+int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
+           const ReducePartialsParams* rp) {
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
-    int splits;
-    ffn_dw_scratch_bytes(p.N, p.d_ff, &splits);
     EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
     int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
+    int splits = ffn_dw_splits((p.N + 31) / 32, ffn_dw_occ(p.hs != nullptr, compute == 1));
     p.splits = splits;
     p.kb_per_split = cdiv(nkb, splits);
     p.splits = cdiv(nkb, p.kb_per_split);
@@ -442,7 +487,13 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
         if (!a.out[k]) a.n[k] = 0;
     }
     size_t total = a.n[0] + a.n[1] + a.n[2];
-    hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, a);
+    unsigned slab_blocks = (unsigned)((total / 4 + 255) / 256);
+    if (rp) {
+        int chunks = partial_chunks(rp->B);
+        hipLaunchKernelGGL(reduce_tail_kernel, dim3(slab_blocks + (unsigned)(cdiv(rp->P, 64) * chunks)), dim3(256), 0, st, a, *rp, slab_blocks, chunks);
+    } else {
+        hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3(slab_blocks), dim3(256), 0, st, a);
+    }
     EGX_LAUNCH_CHECK();
     return 0;
 }
@@ -591,6 +642,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
     const int clip = blockIdx.x;
     const int S = p.S;
+    if (p.zero_buf) {       // the caller's flat gradient buffer: every accumulation into it happens in later launches
+        const size_t n4 = p.zero_n / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
+        const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
+        for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
+    }
+
     const size_t tok0 = (size_t)clip * S;
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
@@ -1207,30 +1264,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     BSTAMP(11);
 }
 
-// grads[dst] += sum_clip partials[clip][off .. off+len): grid = (P / 64, clip chunks); 256 threads = 64 columns x 4
-// clip lanes, LDS tree, one atomic per column per block (<= 16 adders per address).
 __global__ __launch_bounds__(256) void reduce_partials_kernel(ReducePartialsParams rp) {
-    __shared__ float red[4][64];
-    int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    int j = blockIdx.x * 64 + c;
-    int per = (rp.B + gridDim.y - 1) / gridDim.y;
-    int b0 = blockIdx.y * per, b1 = min(rp.B, b0 + per);
-    float s = 0.f;
-    if (j < rp.P)
-        for (int b = b0 + g; b < b1; b += 4) s += rp.partials[(size_t)b * rp.P + j];
-    red[g][c] = s;
-    __syncthreads();
-    if (g == 0 && j < rp.P) {
-        float* dst = nullptr;
-        for (int i = 0; i < rp.n; ++i)
-            if (j >= rp.d[i].off && j < rp.d[i].off + rp.d[i].len) dst = rp.d[i].dst + (j - rp.d[i].off);
-        if (dst) atomicAdd(dst, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
-    }
+    reduce_partials_block(rp, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st) {
-    int chunks = rp.B >= 64 ? 16 : (rp.B >= 8 ? 4 : 1);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(rp.P, 64), chunks), dim3(256), 0, st, rp);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(rp.P, 64), partial_chunks(rp.B)), dim3(256), 0, st, rp);
     EGX_LAUNCH_CHECK();
     return 0;
 }

@@ -45,11 +45,12 @@ class EncoderSpec:
     seed: int = 0
     seed_ptr: int = 0      # device address of a uint64 seed (hipGraph-replayable dropout), 0 = use `seed`
     head_n_out: int = 0    # > 0: pooled head (mean -> LN -> Linear) evaluated with the encoder; output = logits
+    advance_seed: bool = False   # with seed_ptr: the training forward advances the device seed in its first kernel
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
                       COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
-                      self.seed_ptr or None)
+                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0)
 
 
 _scratch_cache = {}
@@ -98,8 +99,11 @@ class _GradPacker:
         self.total += (t.numel() + 3) // 4 * 4
         return len(self.shapes) - 1
 
-    def materialise(self, device) -> List[Optional[torch.Tensor]]:
-        flat = torch.zeros(max(self.total, 4), dtype=torch.float32, device=device)
+    def materialise(self, device, zero: bool = True) -> List[Optional[torch.Tensor]]:
+        """zero=False: the caller hands `self.flat` to the library, whose backward zero-fills it (egx_config.zero_buf)."""
+        n = max(self.total, 4)
+        flat = torch.zeros(n, dtype=torch.float32, device=device) if zero else torch.empty(n, dtype=torch.float32, device=device)
+        self.flat = flat
         out = []
         for s in self.shapes:
             if s is None:
@@ -239,7 +243,7 @@ class EncoderFn(torch.autograd.Function):
         i_proj = [pk.add(t, need[5 + nseg + i]) for i, t in enumerate(proj)]
         i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i]) for i, t in enumerate(layer_t)]
         i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i]) for i, t in enumerate(head_t)]
-        grads = pk.materialise(device)
+        grads = pk.materialise(device, zero=False)      # zero-filled by the library's backward (saves a fill launch)
 
         def g(i):
             return grads[i] if i >= 0 else None
@@ -273,6 +277,7 @@ class EncoderFn(torch.autograd.Function):
                 setattr(lgr[l], name, ptr(g(i_layer[12 * l + k])))
 
         cfg = spec.config()
+        cfg.zero_buf, cfg.zero_bytes = ptr(pk.flat), pk.flat.numel() * 4
         scratch = _workspace("scratch", device, ctx.scratch_bytes)
         seed = C.c_uint64(spec.seed & (2**64 - 1))
         if nhead:
@@ -401,6 +406,19 @@ def linear(x, W, b=None, compute: str = "f32"):
     return y.view(*shp[:-1], W.shape[0])
 
 
+_UNIT_GRAD = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    """A persistent scalar 1.0 on `device` for `loss.backward(gradient=unit_grad(dev))`: autograd then needs no
+    ones-fill, and weighted_cross_entropy recognises it and skips the multiplication by 1 (two launches per step)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    t = _UNIT_GRAD.get(key)
+    if t is None:
+        t = _UNIT_GRAD[key] = torch.ones((), dtype=torch.float32, device=torch.device("cuda", key))
+    return t
+
+
 class WeightedCEFn(torch.autograd.Function):
     """loss = sum_i w[y_i] nll_i / sum_i w[y_i]; the same launch leaves d loss / d logits behind for backward."""
 
@@ -426,7 +444,12 @@ class WeightedCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         dl, ctx.dl = ctx.dl, None
-        return (dl * grad_out if dl is not None else None), None, None
+        if dl is None:
+            return None, None, None
+        u = _UNIT_GRAD.get(dl.device.index)
+        if u is not None and grad_out.data_ptr() == u.data_ptr():
+            return dl, None, None
+        return dl * grad_out, None, None
 
 
 def weighted_cross_entropy(logits, target, weight=None):

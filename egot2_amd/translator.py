@@ -84,9 +84,6 @@ class TranslatorMixin:
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
-        if seed_dev is not None and self.training:
-            from ._lib import load, check
-            check(load().egx_seed_advance(seed_dev.data_ptr(), torch.cuda.current_stream().cuda_stream))
         impl = self.egx_impl
         if impl == "auto" and pos_table is not None and pos_table.requires_grad:
             impl = "generic"       # learned positions (HOI `pe`): their gradient comes from the shape-generic backward
@@ -96,7 +93,8 @@ class TranslatorMixin:
                            p_drop=p_drop, p_pos=p_pos, p_feat=p_feat,
                            training=bool(self.training), seed=self._egx_seed() if self.training else 0,
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
-                           head_n_out=head[1].out_features if head is not None else 0)
+                           head_n_out=head[1].out_features if head is not None else 0,
+                           advance_seed=seed_dev is not None and bool(self.training))   # fresh masks per (replayed) step
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 2
+#define EGX_ABI_VERSION 3
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
@@ -120,7 +120,13 @@ typedef struct egx_config {
     float p_feat;     /* dropout on projected features before LN (HOI `dp`) */
     const uint64_t* seed_ptr; /* optional DEVICE pointer: when non-NULL the fused kernels derive their dropout keys
                                  from *seed_ptr instead of the host `seed` argument, so a captured hipGraph draws fresh
-                                 masks on every replay (advance it with egx_seed_advance inside the graph). */
+                                 masks on every replay (advance it with egx_seed_advance inside the graph, or set
+                                 advance_seed). */
+    int advance_seed;         /* != 0 with seed_ptr: a training-mode forward advances *seed_ptr by one LCG step before
+                                 using it (folded into its first kernel), the backward of that forward reads the
+                                 advanced value. */
+    void* zero_buf;           /* optional: a device buffer the BACKWARD zero-fills before any gradient is accumulated */
+    size_t zero_bytes;        /* (the caller's flat gradient buffer: saves a separate fill launch); multiple of 16 */
 } egx_config;
 
 int egx_abi_version(void);
