@@ -25,7 +25,10 @@ def _oracle_ttm(sd, n_heads, feats, target):
 # fp32 gradients: 1e-2 relative — a single ReLU pre-activation within 1e-6 of zero flips between the
 # fp32 kernels and the fp64 oracle and moves a weight gradient by ~1e-3; everything else agrees to ~1e-6.
 @pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 1e-1)])
-@pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1), (3, 6, 16, 2)])
+@pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1), (3, 6, 16, 2),
+                                           # edges: one clip of one frame per task, S = 48 with 4 layers, short ragged
+                                           # tiles with an odd clip count, one clip more than the CU count
+                                           (3, 1, 1, 1), (3, 1, 16, 4), (2, 3, 7, 3), (3, 257, 3, 1)])
 def test_ttm_translator_vs_oracle(egx_lib, cuda, impl, compute, tol_logit, tol_grad, n_tasks, B, T, L):
     if impl == "fused" and n_tasks * T > 48:
         pytest.skip("fused kernels cover S <= 48")
