@@ -73,6 +73,15 @@ SIGNATURES = {
     "egx_translator_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.POINTER(Head),
                                      C.c_int, _fp, _fp, _fp, C.POINTER(SegmentGrads), _fp, _fp, C.POINTER(LayerGrads),
                                      C.POINTER(HeadGrads), C.c_int, C.c_uint64, _fp]),
+    "egx_small_attention_fwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
+    "egx_small_attention_bwd": (C.c_int, [_fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, C.c_int, _fp, _fp, _fp, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
+    "egx_embed_pos_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    C.c_uint64, _fp]),
+    "egx_embed_pos_bwd": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_relu_mask": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
+    "egx_dropout": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
     "egx_weighted_ce": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "egx_counter_add": (C.c_int, [_fp, C.c_int64, _fp]),
     "egx_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, _fp, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -1,0 +1,216 @@
+// Kernels of the EgoT2-g sequence decoder: the reference decodes a 2-5 token target against the
+// encoder memory with a stock nn.TransformerDecoder (HHI/models/multitask/task_prompt_model.py:260-269,
+// HOI/models/multitask/video_model_builder.py:150-159). Its GEMMs and LayerNorms reuse gemm.hip / norm.hip; what is
+// specific to it lives here:
+//   small_attention_fwd/bwd  attention of a FEW queries (Sq <= 8: the target tokens) against Sk <= 64 keys with separate
+//                            Q and K/V operands: causal self-attention over the target (packed qkv rows) and cross-
+//                            attention onto the memory (Q from the target, packed kv rows from the memory projection).
+//                            One wave per (batch element, head); probabilities are recomputed in the backward.
+//   embed_pos_fwd/bwd        y = embedding[token] * sqrt(d) + pe[position] (+ dropout), and the scatter-add of its gradient.
+//   relu_mask                dy <- dy where y > 0 (backward of the ReLU fused into the linear1 GEMM epilogue).
+#include "common.h"
+#include "kernels.h"
+
+namespace egx {
+
+constexpr int SA_MAXQ = 8, SA_MAXK = 64, SA_MAXDH = 128;
+
+
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid = B * H, block = 64. LDS: K, V [Sk][dh + 1]; Q (and dO) [Sq][dh]; P / dS [Sq][64].
+template <bool BWD>
+__global__ __launch_bounds__(64) void small_attention_kernel(SmallAttnParams p) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int dh = p.dh, LDK = dh + 1;
+    float* Ks = sm;
+    float* Vs = Ks + SA_MAXK * LDK;
+    float* Qs = Vs + SA_MAXK * LDK;
+    float* Gs = Qs + SA_MAXQ * dh;        // dO (backward only)
+    float* Ps = Gs + SA_MAXQ * dh;        // probabilities after dropout, [Sq][64]
+    float* Ds = Ps + SA_MAXQ * 64;        // dS (backward only)
+    const float* kb = p.k + (size_t)b * p.Sk * p.ldk + h * dh;
+    const float* vb = p.v + (size_t)b * p.Sk * p.ldv + h * dh;
+    const float* qb = p.q + (size_t)b * p.Sq * p.ldq + h * dh;
+    for (int i = lane; i < p.Sk * dh; i += 64) {
+        int j = i / dh, c = i - j * dh;
+        Ks[j * LDK + c] = kb[(size_t)j * p.ldk + c];
+        Vs[j * LDK + c] = vb[(size_t)j * p.ldv + c];
+    }
+    for (int i = lane; i < p.Sq * dh; i += 64) {
+        int r = i / dh, c = i - r * dh;
+        Qs[i] = qb[(size_t)r * p.ldq + c];
+        if constexpr (BWD) Gs[i] = p.d_o[((size_t)b * p.Sq + r) * p.ldo + h * dh + c];
+    }
+    __syncthreads();
+    // lane j = key j: scores, softmax across the wave, dropout; one query at a time
+    for (int i = 0; i < p.Sq; ++i) {
+        const bool live = lane < p.Sk && !(p.causal && lane > i);
+        float s = -INFINITY;
+        if (live) {
+            s = 0.f;
+            for (int c = 0; c < dh; ++c) s += Qs[i * dh + c] * Ks[lane * LDK + c];
+            s *= p.scale;
+        }
+        float m = wave_max64(s);
+        float e = live ? __expf(s - m) : 0.f;
+        float prob = e / wave_sum64(e);
+        float mask = 1.f;
+        if (p.drop_thresh) mask = drop_scale(p.drop_key, (uint32_t)(blockIdx.x * SA_MAXQ + i), (uint32_t)lane, p.drop_thresh, p.drop_inv);
+        Ps[i * 64 + lane] = prob * mask;
+        if constexpr (BWD) {
+            float dp = 0.f;
+            if (live) {
+                for (int c = 0; c < dh; ++c) dp += Gs[i * dh + c] * Vs[lane * LDK + c];
+                dp *= mask;
+            }
+            float delta = wave_sum64(prob * dp);
+            Ds[i * 64 + lane] = live ? prob * (dp - delta) * p.scale : 0.f;
+        }
+    }
+    __syncthreads();
+    // lane c = channel c (and c + 64 for dh > 64)
+    for (int c = lane; c < dh; c += 64) {
+        if constexpr (!BWD) {
+            for (int i = 0; i < p.Sq; ++i) {
+                float acc = 0.f;
+                for (int j = 0; j < p.Sk; ++j) acc += Ps[i * 64 + j] * Vs[j * LDK + c];
+                p.o[((size_t)b * p.Sq + i) * p.ldo + h * dh + c] = acc;
+            }
+        } else {
+            for (int i = 0; i < p.Sq; ++i) {
+                float acc = 0.f;
+                for (int j = 0; j < p.Sk; ++j) acc += Ds[i * 64 + j] * Ks[j * LDK + c];
+                p.dq[((size_t)b * p.Sq + i) * p.ldq + h * dh + c] = acc;
+            }
+            for (int j = 0; j < p.Sk; ++j) {
+                float ak = 0.f, av = 0.f;
+                for (int i = 0; i < p.Sq; ++i) {
+                    ak += Ds[i * 64 + j] * Qs[i * dh + c];
+                    av += Ps[i * 64 + j] * Gs[i * dh + c];
+                }
+                p.dk[((size_t)b * p.Sk + j) * p.ldk + h * dh + c] = ak;
+                p.dv[((size_t)b * p.Sk + j) * p.ldv + h * dh + c] = av;
+            }
+        }
+    }
+}
+
+static size_t small_attn_lds(int dh) {
+    return ((size_t)2 * SA_MAXK * (dh + 1) + (size_t)2 * SA_MAXQ * dh + (size_t)2 * SA_MAXQ * 64) * sizeof(float);
+}
+
+static int small_attention_check(const SmallAttnParams& p) {
+    EGX_CHECK(p.B >= 1 && p.H >= 1, "small_attention: B=%d H=%d", p.B, p.H);
+    EGX_CHECK(p.Sq >= 1 && p.Sq <= SA_MAXQ, "small_attention: Sq=%d outside 1..%d (target tokens)", p.Sq, SA_MAXQ);
+    EGX_CHECK(p.Sk >= 1 && p.Sk <= SA_MAXK, "small_attention: Sk=%d outside 1..%d", p.Sk, SA_MAXK);
+    EGX_CHECK(p.dh >= 1 && p.dh <= SA_MAXDH, "small_attention: head dim %d outside 1..%d", p.dh, SA_MAXDH);
+    EGX_CHECK(!p.causal || p.Sq == p.Sk, "small_attention: the causal mask needs Sq == Sk");
+    return 0;
+}
+
+int small_attention_fwd(SmallAttnParams p, hipStream_t st) {
+    EGX_CHECK(p.q && p.k && p.v && p.o, "small_attention_fwd: null pointer argument");
+    if (small_attention_check(p)) return 1;
+    p.scale = 1.f / sqrtf((float)p.dh);
+    size_t lds = small_attn_lds(p.dh);
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_attention_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_attn_lds(SA_MAXDH)));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_attention_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_attn_lds(SA_MAXDH)));
+        attr = true;
+    }
+    hipLaunchKernelGGL(small_attention_kernel<false>, dim3(p.B * p.H), dim3(64), lds, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+int small_attention_bwd(SmallAttnParams p, hipStream_t st) {
+    EGX_CHECK(p.q && p.k && p.v && p.d_o && p.dq && p.dk && p.dv, "small_attention_bwd: null pointer argument");
+    if (small_attention_check(p)) return 1;
+    p.scale = 1.f / sqrtf((float)p.dh);
+    size_t lds = small_attn_lds(p.dh);
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&small_attention_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_attn_lds(SA_MAXDH)));
+        attr = true;
+    }
+    hipLaunchKernelGGL(small_attention_kernel<true>, dim3(p.B * p.H), dim3(64), lds, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- embedding * sqrt(d) + positional encoding ------------------------------------------------------------------
+// tokens (B, sy) int64; emb (V, d); pe rows at pe + t * pe_stride; out (B, sy, d) batch-first.
+__global__ __launch_bounds__(256) void embed_pos_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb,
+                                                        const float* __restrict__ pe, int pe_stride, float scale,
+                                                        float* __restrict__ out, int rows, int sy, int d, int V,
+                                                        uint64_t key, uint32_t thresh, float inv) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * d) return;
+    int row = (int)(i / d), c = (int)(i - (size_t)row * d);
+    int64_t t = tok[row];
+    float e = (t >= 0 && t < V) ? emb[(size_t)t * d + c] : 0.f;
+    float y = e * scale + pe[(size_t)(row % sy) * pe_stride + c];
+    if (thresh) y *= drop_scale(key, (uint32_t)row, (uint32_t)c, thresh, inv);
+    out[i] = y;
+}
+__global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dy,
+                                                         float* __restrict__ d_emb, float scale, int rows, int d, int V,
+                                                         uint64_t key, uint32_t thresh, float inv) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * d) return;
+    int row = (int)(i / d), c = (int)(i - (size_t)row * d);
+    int64_t t = tok[row];
+    if (t < 0 || t >= V) return;
+    float g = dy[i] * scale;
+    if (thresh) g *= drop_scale(key, (uint32_t)row, (uint32_t)c, thresh, inv);
+    atomicAdd(d_emb + (size_t)t * d + c, g);
+}
+
+int embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, int pe_stride, float scale, float* out, int B, int sy,
+                  int d, int V, uint64_t key, uint32_t thresh, float inv, hipStream_t st) {
+    EGX_CHECK(tok && emb && pe && out, "embed_pos_fwd: null pointer argument");
+    size_t n = (size_t)B * sy * d;
+    hipLaunchKernelGGL(embed_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tok, emb, pe, pe_stride, scale, out,
+                       B * sy, sy, d, V, key, thresh, inv);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+int embed_pos_bwd(const int64_t* tok, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V, uint64_t key,
+                  uint32_t thresh, float inv, hipStream_t st) {
+    EGX_CHECK(tok && dy && d_emb, "embed_pos_bwd: null pointer argument");
+    size_t n = (size_t)B * sy * d;
+    hipLaunchKernelGGL(embed_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tok, dy, d_emb, scale, B * sy, d, V,
+                       key, thresh, inv);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, const float* __restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && !(y[i] > 0.f)) dy[i] = 0.f;
+}
+int relu_mask(float* dy, const float* y, size_t n, hipStream_t st) {
+    EGX_CHECK(dy && y, "relu_mask: null pointer argument");
+    if (!n) return 0;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, n);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace egx

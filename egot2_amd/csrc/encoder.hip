@@ -838,4 +838,51 @@ int egx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                      (hipStream_t)stream);
 }
 
+// ---- EgoT2-g sequence decoder pieces (decoder.hip) ---------------------------------------------------------------
+static SmallAttnParams small_attn_params(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int B, int Sq,
+                                         int Sk, int H, int dh, int causal, float p_drop, uint64_t seed, uint32_t site) {
+    SmallAttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+    p.B = B; p.Sq = Sq; p.Sk = Sk; p.H = H; p.dh = dh; p.causal = causal;
+    Drop dr = make_drop(p_drop > 0.f, p_drop, seed, site >> 8, site & 0xffu);
+    p.drop_key = dr.key; p.drop_thresh = dr.thresh; p.drop_inv = dr.inv_keep;
+    return p;
+}
+
+int egx_small_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B,
+                            int Sq, int Sk, int H, int dh, int causal, float p_drop, uint64_t seed, uint32_t site, void* stream) {
+    SmallAttnParams p = small_attn_params(q, ldq, k, ldk, v, ldv, B, Sq, Sk, H, dh, causal, p_drop, seed, site);
+    p.o = o; p.ldo = ldo;
+    return small_attention_fwd(p, (hipStream_t)stream);
+}
+
+int egx_small_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o, int ldo,
+                            float* dq, float* dk, float* dv, int B, int Sq, int Sk, int H, int dh, int causal, float p_drop,
+                            uint64_t seed, uint32_t site, void* stream) {
+    SmallAttnParams p = small_attn_params(q, ldq, k, ldk, v, ldv, B, Sq, Sk, H, dh, causal, p_drop, seed, site);
+    p.d_o = d_o; p.ldo = ldo; p.dq = dq; p.dk = dk; p.dv = dv;
+    return small_attention_bwd(p, (hipStream_t)stream);
+}
+
+int egx_embed_pos_fwd(const int64_t* tokens, const float* emb, const float* pe, int pe_stride, float scale, float* out, int B,
+                      int sy, int d, int V, float p_drop, uint64_t seed, void* stream) {
+    Drop dr = make_drop(p_drop > 0.f, p_drop, seed, 0xDECu, SITE_POS);
+    return embed_pos_fwd(tokens, emb, pe, pe_stride, scale, out, B, sy, d, V, dr.key, dr.thresh, dr.inv_keep, (hipStream_t)stream);
+}
+
+int egx_embed_pos_bwd(const int64_t* tokens, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V, float p_drop,
+                      uint64_t seed, void* stream) {
+    Drop dr = make_drop(p_drop > 0.f, p_drop, seed, 0xDECu, SITE_POS);
+    return embed_pos_bwd(tokens, dy, d_emb, scale, B, sy, d, V, dr.key, dr.thresh, dr.inv_keep, (hipStream_t)stream);
+}
+
+int egx_relu_mask(float* dy, const float* y, size_t n, void* stream) { return relu_mask(dy, y, n, (hipStream_t)stream); }
+
+int egx_dropout(float* x, int rows, int cols, float p_drop, uint64_t seed, uint32_t site, void* stream) {
+    EGX_CHECK(x || rows * cols == 0, "egx_dropout: null pointer");
+    Drop dr = make_drop(p_drop > 0.f, p_drop, seed, site >> 8, site & 0xffu);
+    return apply_dropout_mask(x, rows, cols, dr.key, dr.thresh, dr.inv_keep, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -98,4 +98,23 @@ int counter_add(int64_t* c, int64_t inc, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, const int64_t* step, float lr, float b1, float b2,
               float eps, float wd, int decoupled, float grad_scale, hipStream_t st);
 
+// decoder.hip
+struct SmallAttnParams {
+    const float* q; const float* k; const float* v;
+    int ldq, ldk, ldv;
+    float* o; int ldo;                  // forward output
+    const float* d_o;                   // backward input (same ld as o)
+    float* dq; float* dk; float* dv;    // backward outputs (same ld as q / k / v)
+    int B, Sq, Sk, H, dh, causal;
+    float scale;
+    uint64_t drop_key; uint32_t drop_thresh; float drop_inv;
+};
+int small_attention_fwd(SmallAttnParams p, hipStream_t st);
+int small_attention_bwd(SmallAttnParams p, hipStream_t st);
+int embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, int pe_stride, float scale, float* out, int B, int sy,
+                  int d, int V, uint64_t key, uint32_t thresh, float inv, hipStream_t st);
+int embed_pos_bwd(const int64_t* tok, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V, uint64_t key,
+                  uint32_t thresh, float inv, hipStream_t st);
+int relu_mask(float* dy, const float* y, size_t n, hipStream_t st);
+
 }  // namespace egx

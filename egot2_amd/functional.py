@@ -367,7 +367,7 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b for a 2-D x, through the MFMA GEMM."""
 
     @staticmethod
-    def forward(ctx, x, W, b, compute: str):
+    def forward(ctx, x, W, b, compute: str, relu: bool = False):
         lib = _lib.load()
         x = _dev_f32(x, "x")
         W = _dev_f32(W, "W")
@@ -375,17 +375,21 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = W.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        check(lib.egx_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, N, K, 0, COMPUTE[compute], _stream()))
+        check(lib.egx_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, N, K, int(relu), COMPUTE[compute], _stream()))
         ctx.compute = compute
         ctx.has_b = b is not None
-        ctx.save_for_backward(x, W)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(*((x, W, y) if relu else (x, W)))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, W = ctx.saved_tensors
+        x, W = ctx.saved_tensors[:2]
         dy = dy.contiguous().float()
+        if ctx.relu:                                  # d relu: zero the gradient where the output was clamped
+            dy = dy.clone()
+            check(lib.egx_relu_mask(ptr(dy), ptr(ctx.saved_tensors[2]), dy.numel(), _stream()))
         M, K = x.shape
         N = W.shape[0]
         need = ctx.needs_input_grad
@@ -397,12 +401,12 @@ class LinearFn(torch.autograd.Function):
         scratch = _workspace("linear", dev, nbytes)
         check(lib.egx_linear_bwd(ptr(dy), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K, COMPUTE[ctx.compute],
                                  ptr(scratch), _stream()))
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
-def linear(x, W, b=None, compute: str = "f32"):
+def linear(x, W, b=None, compute: str = "f32", relu: bool = False):
     shp = x.shape
-    y = LinearFn.apply(x.reshape(-1, shp[-1]), W, b, compute)
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), W, b, compute, relu)
     return y.view(*shp[:-1], W.shape[0])
 
 
@@ -455,3 +459,170 @@ class WeightedCEFn(torch.autograd.Function):
 def weighted_cross_entropy(logits, target, weight=None):
     """F.cross_entropy(logits, target, weight=weight) with mean reduction (HHI/tasks/ttm/video_task_2loader.py:21-22,34)."""
     return WeightedCEFn.apply(logits, target, weight)
+
+
+# ---- EgoT2-g sequence decoder pieces (SURVEY.md §8f row F1; kernels in csrc/decoder.hip) ------------------------------
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + res) * w + b over the last dimension of 2-D inputs (post-LN residual blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, res, w, b, eps: float):
+        lib = _lib.load()
+        x = _dev_f32(x, "x")
+        res = _dev_f32(res, "res") if res is not None else None
+        w, b = _dev_f32(w, "ln weight"), _dev_f32(b, "ln bias")
+        rows, d = x.shape
+        pre = torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib.egx_layernorm_fwd(ptr(x), ptr(res) if res is not None else None, ptr(w), ptr(b), float(eps), ptr(pre),
+                                    ptr(stats), ptr(y), rows, d, _stream()))
+        ctx.has_res = res is not None
+        ctx.save_for_backward(pre, stats, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        pre, stats, w = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        rows, d = pre.shape
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(pre)
+        dw = torch.zeros(d, dtype=torch.float32, device=dy.device) if need[2] else None
+        db = torch.zeros(d, dtype=torch.float32, device=dy.device) if need[3] else None
+        check(lib.egx_layernorm_bwd(ptr(dy), ptr(pre), ptr(stats), ptr(w), ptr(dx), ptr(dw) if dw is not None else None,
+                                    ptr(db) if db is not None else None, rows, d, _stream()))
+        return (dx if need[0] else None), (dx if (ctx.has_res and need[1]) else None), dw, db, None
+
+
+def layer_norm_residual(x, res, w, b, eps: float = 1e-5):
+    return LayerNormFn.apply(x, res, w, b, eps)
+
+
+class DropoutFn(torch.autograd.Function):
+    """Inverted dropout with the library's counter-based mask (seed, site, row, column); the backward regenerates it."""
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int, site: int):
+        lib = _lib.load()
+        y = _dev_f32(x, "x").clone()
+        rows = y.numel() // y.shape[-1]
+        check(lib.egx_dropout(ptr(y), rows, y.shape[-1], float(p), C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        ctx.cfg = (float(p), seed, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        p, seed, site = ctx.cfg
+        g = dy.contiguous().float().clone()
+        rows = g.numel() // g.shape[-1]
+        check(lib.egx_dropout(ptr(g), rows, g.shape[-1], p, C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        return g, None, None, None
+
+
+def dropout(x, p: float, training: bool, seed: int, site: int):
+    return DropoutFn.apply(x, p, seed, site) if (training and p > 0.0) else x
+
+
+class EmbedPosFn(torch.autograd.Function):
+    """(B, sy) int64 tokens -> (B * sy, d): embedding[token] * scale + pe[t] (+ dropout)."""
+
+    @staticmethod
+    def forward(ctx, tokens, emb, pe, scale: float, p: float, seed: int):
+        lib = _lib.load()
+        emb = _dev_f32(emb, "embedding")
+        pe2 = _dev_f32(pe, "pe")
+        if tokens.dtype != torch.int64 or tokens.dim() != 2 or tokens.device != emb.device:
+            raise ValueError("tokens must be a (B, sy) int64 tensor on the embedding's device")
+        tok = tokens.contiguous()
+        B, sy = tok.shape
+        V, d = emb.shape
+        if sy > pe2.shape[0]:
+            raise ValueError("target longer than the positional table")
+        out = torch.empty((B * sy, d), dtype=torch.float32, device=emb.device)
+        check(lib.egx_embed_pos_fwd(ptr(tok), ptr(emb), ptr(pe2), pe2.stride(0), float(scale), ptr(out), B, sy, d, V, float(p),
+                                    C.c_uint64(seed & (2**64 - 1)), _stream()))
+        ctx.cfg = (float(scale), float(p), seed, V)
+        ctx.save_for_backward(tok)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (tok,) = ctx.saved_tensors
+        scale, p, seed, V = ctx.cfg
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        dy = dy.contiguous().float()
+        B, sy = tok.shape
+        d = dy.shape[-1]
+        d_emb = torch.zeros((V, d), dtype=torch.float32, device=dy.device)
+        check(lib.egx_embed_pos_bwd(ptr(tok), ptr(dy), ptr(d_emb), scale, B, sy, d, V, p, C.c_uint64(seed & (2**64 - 1)), _stream()))
+        return None, d_emb, None, None, None, None
+
+
+class SelfAttnSmallFn(torch.autograd.Function):
+    """Causal self-attention over a few target tokens from packed (B * sy, 3d) qkv rows -> (B * sy, d)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B: int, sy: int, H: int, causal: bool, p: float, seed: int, site: int):
+        lib = _lib.load()
+        qkv = _dev_f32(qkv, "qkv")
+        d = qkv.shape[1] // 3
+        out = torch.empty((B * sy, d), dtype=torch.float32, device=qkv.device)
+        e = qkv.element_size()
+        base = qkv.data_ptr()
+        check(lib.egx_small_attention_fwd(base, 3 * d, base + d * e, 3 * d, base + 2 * d * e, 3 * d, ptr(out), d, B, sy, sy, H,
+                                          d // H, int(causal), float(p), C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        ctx.cfg = (B, sy, H, int(causal), float(p), seed, site)
+        ctx.save_for_backward(qkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        (qkv,) = ctx.saved_tensors
+        B, sy, H, causal, p, seed, site = ctx.cfg
+        d = qkv.shape[1] // 3
+        d_out = d_out.contiguous().float()
+        dqkv = torch.empty_like(qkv)
+        e = qkv.element_size()
+        base, gb = qkv.data_ptr(), dqkv.data_ptr()
+        check(lib.egx_small_attention_bwd(base, 3 * d, base + d * e, 3 * d, base + 2 * d * e, 3 * d, ptr(d_out), d,
+                                          gb, gb + d * e, gb + 2 * d * e, B, sy, sy, H, d // H, causal, p,
+                                          C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        return dqkv, None, None, None, None, None, None, None
+
+
+class CrossAttnSmallFn(torch.autograd.Function):
+    """Attention of the target's queries (B * sy, d) onto the memory's packed (B * S, 2d) key/value rows -> (B * sy, d)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B: int, sy: int, S: int, H: int, p: float, seed: int, site: int):
+        lib = _lib.load()
+        q, kv = _dev_f32(q, "q"), _dev_f32(kv, "kv")
+        d = q.shape[1]
+        out = torch.empty((B * sy, d), dtype=torch.float32, device=q.device)
+        e = kv.element_size()
+        kb = kv.data_ptr()
+        check(lib.egx_small_attention_fwd(ptr(q), d, kb, 2 * d, kb + d * e, 2 * d, ptr(out), d, B, sy, S, H, d // H, 0, float(p),
+                                          C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        ctx.cfg = (B, sy, S, H, float(p), seed, site)
+        ctx.save_for_backward(q, kv)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        q, kv = ctx.saved_tensors
+        B, sy, S, H, p, seed, site = ctx.cfg
+        d = q.shape[1]
+        d_out = d_out.contiguous().float()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        e = kv.element_size()
+        kb, gb = kv.data_ptr(), dkv.data_ptr()
+        check(lib.egx_small_attention_bwd(ptr(q), d, kb, 2 * d, kb + d * e, 2 * d, ptr(d_out), d, ptr(dq), gb, gb + d * e,
+                                          B, sy, S, H, d // H, 0, p, C.c_uint64(seed & (2**64 - 1)), site, _stream()))
+        return dq, dkv, None, None, None, None, None, None, None

@@ -1,7 +1,6 @@
 """EgoT2-g (HHI) — drop-in mirror of HHI/models/multitask/task_prompt_model.py:174-293
 (`TaskTranslationPromptTransformer`). The shared task-translation ENCODER (the graded hot path)
-runs in libegot2x.so; the 2-token sequence decoder + vocabulary head is the reference's own stock
-nn.TransformerDecoder ("next")."""
+runs in libegot2x.so; and so does the 2-token sequence decoder + vocabulary head (egot2_amd/decoder.py)."""
 from __future__ import annotations
 
 import math
@@ -11,6 +10,7 @@ import torch.nn as nn
 
 from .backbones import freeze_params, make_backbone
 from .functional import SegmentSpec
+from .decoder import DecoderMixin
 from .translator import PositionalEncoding, TranslatorMixin
 
 
@@ -26,7 +26,7 @@ class CustomDecoderLayer(nn.TransformerDecoderLayer):
         return self.dropout2(x)
 
 
-class TaskTranslationPromptTransformer(nn.Module, TranslatorMixin):
+class TaskTranslationPromptTransformer(nn.Module, TranslatorMixin, DecoderMixin):
     def __init__(self, args, vocab):
         super().__init__()
         self.args = args
@@ -108,15 +108,11 @@ class TaskTranslationPromptTransformer(nn.Module, TranslatorMixin):
             asd_feat = outsAV.view(N, D, -1)
         return self.encode_features(task, lam_feat, ttm_feat, asd_feat)
 
-    # ---- decoder (stock torch; next-row F1) ----------------------------------------------------------------
+    # ---- decoder (HIP; row F1) ---------------------------------------------------------------------------
     def decode(self, y, encoded_x):
-        sy = y.size(1)
-        y = y.permute(1, 0)
-        y = self.embedding(y) * math.sqrt(self.dim)
-        y = self.pos_embed(y)
-        y_mask = self.y_mask[:sy, :sy].type_as(encoded_x)
-        output = self.transformer_decoder(y, encoded_x, y_mask)
-        return self.fc(output)
+        """(B, sy) tokens + (S, B, d) memory -> (sy, B, |V|); on the GPU this is the HIP decoder (egot2_amd/decoder.py)."""
+        return self._egx_decode(y, encoded_x, embedding=self.embedding, pos_embed=self.pos_embed,
+                                decoder=self.transformer_decoder, fc=self.fc, n_heads=self.n_heads, p_drop=self.dp_rate)
 
     def forward(self, video, video_asd, audio, audio_asd, target, task):
         assert task in ['lam', 'ttm', 'asd']

@@ -2,8 +2,8 @@
 (`TaskPromptTransformer`, `TaskTranslationPromptTransformer`, `TaskTranslationPromptTransformer6Task`): one
 encoder-decoder over the PNR, OSCC, action-recognition (SlowFast) and, for the 6-task model, LTA backbones, with the
 task named by a prompt token. The shared task-translation ENCODER (d=512, 8 heads,
-3 layers, S=48 or 4n) runs in libegot2x.so; the short sequence decoder + vocabulary head stays the reference's stock
-nn.TransformerDecoder (row F1). The frozen backbones are attached by the host code (`pnr_model`, `oscc_model`,
+3 layers, S=48 or 4n) and the short sequence decoder + vocabulary head (row F1, egot2_amd/decoder.py) run in
+libegot2x.so. The frozen backbones are attached by the host code (`pnr_model`, `oscc_model`,
 `recognition_model`, `lta_model`), see INTEGRATION.md."""
 from __future__ import annotations
 
@@ -15,10 +15,11 @@ import torch.nn as nn
 
 from .functional import SegmentSpec
 from .hhi_multitask import CustomDecoderLayer
+from .decoder import DecoderMixin
 from .translator import PositionalEncoding, TranslatorMixin
 
 
-class TaskPromptTransformer(nn.Module, TranslatorMixin):
+class TaskPromptTransformer(nn.Module, TranslatorMixin, DecoderMixin):
     """Reference :56-216 (single-task prompts 'pnr' / 'oscc' / 'action')."""
 
     def __init__(self, args, vocab, oscc_no_temp_pool=True):
@@ -98,15 +99,11 @@ class TaskPromptTransformer(nn.Module, TranslatorMixin):
             slow, fast = self._pool_action(self.recognition_model(video, middle=True))
             return dict(slow_feat=slow, fast_feat=fast)
 
-    # ---- decoder (stock torch; row F1) -----------------------------------------------------------------------
+    # ---- decoder (HIP; row F1) ---------------------------------------------------------------------------
     def decode(self, y, encoded_x):
-        sy = y.size(1)
-        y = y.permute(1, 0)
-        y = self.embedding(y) * math.sqrt(self.dim)
-        y = self.pos_embed(y)
-        y_mask = self.y_mask[:sy, :sy].type_as(encoded_x)
-        output = self.transformer_decoder(y, encoded_x, y_mask)
-        return self.fc(output)
+        """(B, sy) tokens + (S, B, d) memory -> (sy, B, |V|); on the GPU this is the HIP decoder (egot2_amd/decoder.py)."""
+        return self._egx_decode(y, encoded_x, embedding=self.embedding, pos_embed=self.pos_embed,
+                                decoder=self.transformer_decoder, fc=self.fc, n_heads=self.n_heads, p_drop=self.dp_rate)
 
     def forward(self, video, target, task):
         assert task in ['pnr', 'oscc', 'action']

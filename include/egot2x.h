@@ -243,6 +243,37 @@ int egx_counter_add(int64_t* counter, int64_t inc, void* stream);
 int egx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, const int64_t* step,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
                   void* stream);
+/* ---- EgoT2-g sequence decoder + vocabulary head --------------------------------------------
+ * decode() of HHI/models/multitask/task_prompt_model.py:260-269 and HOI/models/multitask/video_model_builder.py:150-159:
+ * embedding * sqrt(d) + positional encoding -> nn.TransformerDecoder of CustomDecoderLayer (causal self-attention over
+ * the 2..5 target tokens, cross-attention onto the encoder memory, FFN; post-LN) -> fc. Projections, LayerNorms and the
+ * FFN reuse egx_linear_* / egx_layernorm_*; the entry points below are the decoder-specific pieces.
+ *
+ * Attention of a few queries against a short key set, one (batch element, head) per wave: rows are tokens (row index
+ * b * S + s, row stride ld* floats), head h owns columns [h * dh, (h + 1) * dh). Sq <= 8, Sk <= 64, dh <= 128.
+ * causal != 0 (needs Sq == Sk) applies the reference's lower-triangular target mask. Self-attention passes the packed
+ * qkv rows three times (q, q + d, q + 2d with ld = 3d), cross-attention q and the packed kv rows of the memory.
+ * p_drop > 0: dropout on the probabilities, keyed by (seed, site); the backward regenerates the same mask and
+ * recomputes the probabilities (nothing is saved). */
+int egx_small_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                            int B, int Sq, int Sk, int H, int dh, int causal, float p_drop, uint64_t seed, uint32_t site,
+                            void* stream);
+/* dq / dk / dv use the strides of q / k / v and are overwritten (=), every (row, head column) exactly once. */
+int egx_small_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* d_o,
+                            int ldo, float* dq, float* dk, float* dv, int B, int Sq, int Sk, int H, int dh, int causal,
+                            float p_drop, uint64_t seed, uint32_t site, void* stream);
+/* out[b, t, :] = dropout(emb[tokens[b, t]] * scale + pe[t * pe_stride ...]); tokens (B, sy) int64, emb (V, d).
+ * Backward: d_emb[tokens[b, t]] += scale * mask * dy[b, t]  (atomic accumulation into a zero-filled or live buffer). */
+int egx_embed_pos_fwd(const int64_t* tokens, const float* emb, const float* pe, int pe_stride, float scale, float* out,
+                      int B, int sy, int d, int V, float p_drop, uint64_t seed, void* stream);
+int egx_embed_pos_bwd(const int64_t* tokens, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V,
+                      float p_drop, uint64_t seed, void* stream);
+/* dy[i] = y[i] > 0 ? dy[i] : 0 in place: backward of the ReLU fused into egx_linear_fwd(relu = 1). */
+int egx_relu_mask(float* dy, const float* y, size_t n, void* stream);
+/* x[r, c] *= keep(seed, site, r, c) / (1 - p) in place (inverted dropout); calling it on the gradient with the same
+ * (seed, site) is its backward. */
+int egx_dropout(float* x, int rows, int cols, float p_drop, uint64_t seed, uint32_t site, void* stream);
+
 /* Per-kernel device timing for bench.py's roofline block: hipEvents recorded on the launch stream around the
  * fused kernels while enabled (which: 0 = fused forward, 1 = fused per-clip backward, 2 = FFN weight gradients).
  * egx_timing_read synchronises on the recorded events; never call it inside a timed or captured region. */

@@ -224,5 +224,53 @@ def hoi_g_encode(sd, n_heads: int, task: str, feat_pnr, feat_oscc, a, b) -> torc
     return x.permute(1, 0, 2)
 
 
+# ---- EgoT2-g sequence decoder + vocabulary head ---------------------------------------------
+def attention(q_in: torch.Tensor, kv_in: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int, causal: bool) -> torch.Tensor:
+    """nn.MultiheadAttention math, batch-first: q_in (B, Sq, d), kv_in (B, Sk, d); packed in-projection rows
+    [Wq; Wk; Wv]; `causal` adds the reference's lower-triangular additive mask (get_tgt_mask)."""
+    B, Sq, d = q_in.shape
+    Sk = kv_in.shape[1]
+    dh = d // n_heads
+    q = linear(q_in, in_w[:d], in_b[:d]).reshape(B, Sq, n_heads, dh).permute(0, 2, 1, 3)
+    k = linear(kv_in, in_w[d:2 * d], in_b[d:2 * d]).reshape(B, Sk, n_heads, dh).permute(0, 2, 1, 3)
+    v = linear(kv_in, in_w[2 * d:], in_b[2 * d:]).reshape(B, Sk, n_heads, dh).permute(0, 2, 1, 3)
+    scores = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    if causal:
+        keep = torch.tril(torch.ones(Sq, Sk, dtype=torch.bool))
+        scores = scores.masked_fill(~keep, float("-inf"))
+    scores = scores - scores.max(dim=-1, keepdim=True).values
+    p = torch.exp(scores)
+    p = p / p.sum(dim=-1, keepdim=True)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, Sq, d)
+    return linear(o, out_w, out_b)
+
+
+def decoder_layer(x, mem, sd, prefix: str, n_heads: int, eps: float = 1e-5):
+    """Post-LN nn.TransformerDecoderLayer as subclassed by CustomDecoderLayer
+    (HHI/models/multitask/task_prompt_model.py:163-172, HOI/models/multitask/video_model_builder.py:20-30):
+    x = norm1(x + SA(x, causal)); x = norm2(x + CA(x, memory)); x = norm3(x + FFN(x))."""
+    g = lambda k: sd[prefix + k]  # noqa: E731
+    a = attention(x, x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"), g("self_attn.out_proj.weight"),
+                  g("self_attn.out_proj.bias"), n_heads, True)
+    x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"), eps)
+    c = attention(x, mem, g("multihead_attn.in_proj_weight"), g("multihead_attn.in_proj_bias"),
+                  g("multihead_attn.out_proj.weight"), g("multihead_attn.out_proj.bias"), n_heads, False)
+    x = layer_norm(x + c, g("norm2.weight"), g("norm2.bias"), eps)
+    f = linear(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), g("linear2.weight"), g("linear2.bias"))
+    return layer_norm(x + f, g("norm3.weight"), g("norm3.bias"), eps)
+
+
+def g_decode(sd, n_heads: int, y: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
+    """decode() of the EgoT2-g models (task_prompt_model.py:260-269 / video_model_builder.py:150-159), dropout off:
+    y (B, sy) int64 prompt/target tokens, memory (S, B, d) from encode() -> (sy, B, |V|) vocabulary logits."""
+    d = sd["embedding.weight"].shape[1]
+    sy = y.shape[1]
+    x = sd["embedding.weight"][y] * math.sqrt(d) + sd["pos_embed.pe"][:sy, 0, :]        # (B, sy, d)
+    mem = memory.permute(1, 0, 2)
+    for i in range(n_layers_of(sd, "transformer_decoder.")):
+        x = decoder_layer(x, mem, sd, f"transformer_decoder.layers.{i}.", n_heads)
+    return linear(x, sd["fc.weight"], sd["fc.bias"]).permute(1, 0, 2)
+
+
 def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:
     return {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}

@@ -40,6 +40,15 @@ HOI_CASES = [
 ]
 
 
+def g_targets(c, task, batch, vocab_size, sy=2):
+    """Deterministic (batch, sy) int64 decoder inputs for the EgoT2-g fixtures."""
+    import numpy as np
+    import torch
+    import zlib
+    rng = np.random.default_rng([c["fseed"], zlib.crc32(task.encode())])
+    return torch.from_numpy(rng.integers(0, vocab_size, (batch, sy))).long()
+
+
 def sd_keys(m):
     return json.dumps({k: list(v.shape) for k, v in m.state_dict().items()})
 
@@ -89,6 +98,11 @@ def run_hhi():
                 enc = m.encode(lamf, torch.zeros(B, T, 1, 1), feats[0], feats[2], task)   # video->lam, audio->ttm, audio_asd->asd
                 out[f"out_{task}"] = enc.detach().numpy()
                 loss = loss + (enc * torch.linspace(-1, 1, enc.numel()).view_as(enc)).sum()
+                # row F1: the sequence decoder + vocabulary head on that memory (target = prompt token + one answer token)
+                tgt = g_targets(c, task, enc.shape[1], len(m.vocab))
+                dec = m.decode(tgt, enc)                                                   # (sy, batch, |V|)
+                out[f"dec_{task}"] = dec.detach().numpy()
+                loss = loss + (dec * torch.linspace(-1, 1, dec.numel()).view_as(dec)).sum()
         m.zero_grad()
         loss.backward()
         out["loss"] = loss.detach().numpy()
@@ -138,6 +152,9 @@ def run_hoi():
             m.pos_embed.dropout.p = 0.0
             named = {"out_pnr": rh.hoi_g_encode_other(m, "pnr", *feats[:4]),
                      "out_lta": rh.hoi_g_encode_lta(m, *feats[4:])}
+            for task, sy in (("pnr", 2), ("lta", 4)):       # row F1: decoder + vocabulary head, 2- and 4-token targets
+                enc = named[f"out_{task}"]
+                named[f"dec_{task}"] = m.decode(g_targets(c, task, enc.shape[1], len(m.vocab), sy), enc)
         elif c["kind"] == "lta4":
             outs = rh.ref_lta4_forward(m, *feats)
             named = {"out_verb": outs[0], "out_noun": outs[1]}

@@ -1,0 +1,149 @@
+"""-m gpu: the decoder-specific kernels of row F1 (csrc/decoder.hip) through their autograd Functions, against plain
+torch fp64 math: few-query attention (causal self / cross), embedding + positional encoding, ReLU-fused linear,
+LayerNorm(x + res), and the counter-based dropout of the decoder (same masks in forward and backward)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_attention(q, k, v, H, causal):
+    B, Sq, d = q.shape
+    Sk = k.shape[1]
+    dh = d // H
+    qh = q.reshape(B, Sq, H, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Sk, H, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Sk, H, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)), float("-inf"))
+    return (torch.softmax(s, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, Sq, d)
+
+
+@pytest.mark.parametrize("B,sy,H,dh", [(3, 1, 4, 64), (5, 2, 4, 64), (2, 5, 8, 64), (4, 8, 2, 128), (7, 3, 8, 16)])
+def test_self_attention_small_matches_torch(egx_lib, cuda, B, sy, H, dh):
+    from egot2_amd import functional as F_egx
+    d = H * dh
+    g = torch.Generator().manual_seed(B * 100 + sy)
+    qkv = torch.randn(B * sy, 3 * d, generator=g)
+    w = torch.randn(B * sy, d, generator=g)
+    x = qkv.to(cuda).requires_grad_(True)
+    out = F_egx.SelfAttnSmallFn.apply(x, B, sy, H, True, 0.0, 0, 1)
+    (out * w.to(cuda)).sum().backward()
+    r = qkv.double().requires_grad_(True)
+    r3 = r.view(B, sy, 3 * d)
+    ref = _ref_attention(r3[..., :d], r3[..., d:2 * d], r3[..., 2 * d:], H, True).reshape(B * sy, d)
+    (ref * w.double()).sum().backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
+    assert (x.grad.cpu().double() - r.grad).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,sy,S,H,dh", [(4, 2, 45, 4, 64), (6, 4, 12, 8, 64), (30, 2, 3, 4, 64), (2, 1, 64, 8, 32), (3, 8, 48, 4, 128)])
+def test_cross_attention_small_matches_torch(egx_lib, cuda, B, sy, S, H, dh):
+    from egot2_amd import functional as F_egx
+    d = H * dh
+    g = torch.Generator().manual_seed(B + 17 * S)
+    q = torch.randn(B * sy, d, generator=g)
+    kv = torch.randn(B * S, 2 * d, generator=g)
+    w = torch.randn(B * sy, d, generator=g)
+    qd, kvd = q.to(cuda).requires_grad_(True), kv.to(cuda).requires_grad_(True)
+    out = F_egx.CrossAttnSmallFn.apply(qd, kvd, B, sy, S, H, 0.0, 0, 3)
+    (out * w.to(cuda)).sum().backward()
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    kv3 = kvr.view(B, S, 2 * d)
+    ref = _ref_attention(qr.view(B, sy, d), kv3[..., :d], kv3[..., d:], H, False).reshape(B * sy, d)
+    (ref * w.double()).sum().backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
+    assert (qd.grad.cpu().double() - qr.grad).abs().max().item() < 1e-5
+    assert (kvd.grad.cpu().double() - kvr.grad).abs().max().item() < 1e-5
+
+
+def test_attention_dropout_masks_match_between_forward_and_backward(egx_lib, cuda):
+    """With a fixed (seed, site) the output is a deterministic, piecewise-smooth function of q: central differences must
+    reproduce the analytic gradient, which they only do if the backward regenerates the forward's mask."""
+    from egot2_amd import functional as F_egx
+    B, sy, S, H, dh = 3, 2, 20, 4, 32
+    d = H * dh
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B * sy, d, generator=g).to(cuda)
+    kv = torch.randn(B * S, 2 * d, generator=g).to(cuda)
+    w = torch.randn(B * sy, d, generator=g).to(cuda)
+    f = lambda qq, seed: (F_egx.CrossAttnSmallFn.apply(qq, kv, B, sy, S, H, 0.5, seed, 3) * w).sum()  # noqa: E731
+    assert f(q, 11).item() == f(q, 11).item()
+    assert abs(f(q, 11).item() - f(q, 12).item()) > 1e-6
+    keep = (F_egx.CrossAttnSmallFn.apply(q, torch.cat((kv[:, :d], torch.ones_like(kv[:, d:])), 1), B, sy, S, H, 0.5, 11, 3)).mean().item()
+    assert 0.8 < keep < 1.2            # V = 1: each output = sum of kept probabilities / (1 - p), expectation 1
+    qg = q.clone().requires_grad_(True)
+    f(qg, 11).backward()
+    for idx in [(0, 3), (2, 77), (5, 120)]:
+        eps = 1e-2
+        qp, qm = q.clone(), q.clone()
+        qp[idx] += eps
+        qm[idx] -= eps
+        fd = (f(qp, 11).item() - f(qm, 11).item()) / (2 * eps)
+        assert abs(fd - qg.grad[idx].item()) < 2e-2 * max(abs(fd), 1e-2), (idx, fd, qg.grad[idx].item())
+
+
+def test_embed_pos_and_scatter_gradient(egx_lib, cuda):
+    from egot2_amd import functional as F_egx
+    V, d, B, sy = 9, 64, 6, 3
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(V, d, generator=g)
+    pe = torch.randn(10, 1, d, generator=g)
+    tok = torch.randint(0, V, (B, sy), generator=g)
+    tok[0, 0] = tok[1, 1] = tok[2, 2] = 4                      # repeated token: the scatter must accumulate
+    w = torch.randn(B * sy, d, generator=g)
+    e = emb.to(cuda).requires_grad_(True)
+    out = F_egx.EmbedPosFn.apply(tok.to(cuda), e, pe.to(cuda)[:, 0, :], math.sqrt(d), 0.0, 0)
+    (out * w.to(cuda)).sum().backward()
+    er = emb.double().requires_grad_(True)
+    ref = (er[tok] * math.sqrt(d) + pe.double()[:sy, 0, :]).reshape(B * sy, d)
+    (ref * w.double()).sum().backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-5
+    assert (e.grad.cpu().double() - er.grad).abs().max().item() < 1e-4
+
+
+def test_relu_linear_and_layernorm_residual(egx_lib, cuda):
+    from egot2_amd import functional as F_egx
+    g = torch.Generator().manual_seed(3)
+    x, res = torch.randn(10, 128, generator=g), torch.randn(10, 128, generator=g)
+    W, b = torch.randn(256, 128, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    lw, lb = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    w2 = torch.randn(10, 256, generator=g)
+    dev = [t.to(cuda).requires_grad_(True) for t in (x, res, W, b, lw, lb)]
+    y = F_egx.layer_norm_residual(dev[0], dev[1], dev[4], dev[5], 1e-5)
+    h = F_egx.linear(y, dev[2], dev[3], "f32", relu=True)
+    (h * w2.to(cuda)).sum().backward()
+    ref = [t.double().requires_grad_(True) for t in (x, res, W, b, lw, lb)]
+    yr = torch.nn.functional.layer_norm(ref[0] + ref[1], (128,), ref[4], ref[5], 1e-5)
+    hr = torch.relu(yr @ ref[2].T + ref[3])
+    (hr * w2.double()).sum().backward()
+    assert (h.detach().cpu().double() - hr.detach()).abs().max().item() < 1e-4
+    for a, r in zip(dev, ref):
+        assert (a.grad.cpu().double() - r.grad).abs().max().item() < 1e-3 * max(1.0, r.grad.abs().max().item())
+
+
+def test_decoder_trains_with_dropout(egx_lib, cuda):
+    """Train-mode decode (dropout on every site): finite, deterministic per seed, and gradients reach every decoder
+    parameter; eval-mode decode is independent of the seed."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import hhi_multitask
+    from tests.util import seeded_state_dict
+    vocab = {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+    args = NS(hidden_dim=256, num_heads=4, num_layers=2, dropout=0.3, lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None)
+    m = hhi_multitask.TaskTranslationPromptTransformer(args, vocab)
+    m.load_state_dict(seeded_state_dict(m, 4))
+    m = m.to(cuda).train()
+    mem = torch.randn(45, 5, 256, device=cuda)
+    y = torch.randint(0, 7, (5, 2), device=cuda)
+    out = m.decode(y, mem)
+    assert out.shape == (2, 5, 7) and torch.isfinite(out).all()
+    out.square().sum().backward()
+    missing = [n for n, p in m.named_parameters() if ("transformer_decoder" in n or n.startswith(("fc.", "embedding."))) and p.grad is None]
+    assert not missing, missing
+    m.eval()
+    with torch.no_grad():
+        a, b = m.decode(y, mem), m.decode(y, mem)
+    assert torch.equal(a, b)

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.test_oracle_golden import (CE_W, FIXTURES, build_ours, check_against_fixture, fixture_feats, load_fixture)
+from tests.test_oracle_golden import (CE_W, FIXTURES, build_ours, check_against_fixture, fixture_feats, g_targets,
+                                      load_fixture)
 from tests.util import seeded_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -26,14 +27,19 @@ def hip_run(c, model, feats):
             lamf = feats[1][:, :7].contiguous() if task == "lam" else feats[1]
             enc = model.encode_features(task, lamf, feats[0], feats[2])
             outs[f"out_{task}"] = enc
-            loss = loss + lin(enc)
+            dec = model.decode(g_targets(c, task, enc.shape[1], 7).to(enc.device), enc)      # HIP decoder (row F1)
+            outs[f"dec_{task}"] = dec
+            loss = loss + lin(enc) + lin(dec)
         return outs, loss
     if c["kind"] == "lta4":
         o = model.forward_features(*feats)
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
     if c["kind"] == "hoig":
         outs = {"out_pnr": model.encode_features("pnr", *feats[:4]), "out_lta": model.encode_features("lta_verb", *feats[4:])}
-        return outs, lin(outs["out_pnr"]) + lin(outs["out_lta"])
+        for task, sy in (("pnr", 2), ("lta", 4)):
+            enc = outs[f"out_{task}"]
+            outs[f"dec_{task}"] = model.decode(g_targets(c, task, enc.shape[1], 12, sy).to(enc.device), enc)
+        return outs, sum(lin(v) for v in outs.values())
     if c["kind"] == "pnr3":
         out = model.forward_features(*feats)
         return {"out": out}, lin(out)

@@ -62,6 +62,13 @@ def build_ours(c):
     raise KeyError(c["kind"])
 
 
+def g_targets(c, task, batch, vocab_size, sy=2):
+    """Decoder inputs of the EgoT2-g fixtures (same recipe as tests/golden/make_golden.py)."""
+    import zlib
+    rng = np.random.default_rng([c["fseed"], zlib.crc32(task.encode())])
+    return torch.from_numpy(rng.integers(0, vocab_size, (batch, sy))).long()
+
+
 def fixture_feats(c):
     B = c["B"]
     if c["kind"] == "lta4":
@@ -101,7 +108,9 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
             lamf = f[1][:, :7] if task == "lam" else f[1]
             enc = tr.hhi_g_encode(sdd, c["h"], task, lamf, f[0], f[2])
             outs[f"out_{task}"] = enc
-            loss = loss + lin(enc)
+            dec = tr.g_decode(sdd, c["h"], g_targets(c, task, enc.shape[1], 7), enc)
+            outs[f"dec_{task}"] = dec
+            loss = loss + lin(enc) + lin(dec)
         return outs, loss, sdd
     if c["kind"] == "lta4":
         o = tr.lta4_forward(sdd, c["h"], *f, c["classes"])
@@ -112,7 +121,10 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
         return {"out": out}, lin(out), sdd
     if c["kind"] == "hoig":
         outs = {"out_pnr": tr.hoi_g_encode(sdd, c["h"], "pnr", *f[:4]), "out_lta": tr.hoi_g_encode(sdd, c["h"], "lta_verb", *f[4:])}
-        return outs, lin(outs["out_pnr"]) + lin(outs["out_lta"]), sdd
+        for task, sy in (("pnr", 2), ("lta", 4)):
+            enc = outs[f"out_{task}"]
+            outs[f"dec_{task}"] = tr.g_decode(sdd, c["h"], g_targets(c, task, enc.shape[1], 12, sy), enc)
+        return outs, sum(lin(v) for v in outs.values()), sdd
     if c["kind"] == "ar3":
         o = tr.ar_forward(sdd, c["h"], f, ["proj3_slow", "proj3_fast", "proj1", "proj2"])
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
@@ -138,7 +150,11 @@ def check_against_fixture(z, outs, loss, grads, tol_out, tol_grad):
         g = grads[k].detach().double().cpu().reshape(-1)
         n_ref = float(z["gnorm/" + k])
         head = torch.from_numpy(z["ghead/" + k]).double()
-        e_head = (g[:head.numel()] - head).norm().item() / (head.norm().item() + 1e-12 + 1e-6 * n_ref)
+        # error of the stored leading entries relative to their own size AND to the tensor's RMS gradient: leading
+        # entries that are 1e-4 of the norm (the decoder's first query rows) carry the fp32 cancellation noise of the
+        # reference run that produced the fixture
+        typical = n_ref * (head.numel() / g.numel()) ** 0.5
+        e_head = (g[:head.numel()] - head).norm().item() / (head.norm().item() + typical + 1e-12)
         e_norm = abs(g.norm().item() - n_ref) / (n_ref + 1e-12)
         assert e_norm < tol_grad and e_head < 3 * tol_grad, f"{k}: norm err {e_norm}, head err {e_head}"
 
