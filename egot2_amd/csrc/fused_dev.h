@@ -141,17 +141,17 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-// afterwards v[j] of quad-lane l holds what v[l] of quad-lane j held
+// afterwards v[j] of quad-lane l holds what v[l] of quad-lane j held. Every register travels through the DPP network
+// and the per-lane choice is made afterwards: 4 + 4 selects whose DPP operand the compiler folds into
+// v_cndmask_b32_dpp, instead of the select / move / select chains it builds when only the "needed" registers move.
 __device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
     const bool h2 = (lane & 2) != 0, h1 = (lane & 1) != 0;
-    float a = h2 ? v[0] : v[2], b = h2 ? v[1] : v[3];
-    a = dpp_quad<0x4E>(a);      // quad_perm [2,3,0,1]
-    b = dpp_quad<0x4E>(b);
-    if (h2) { v[0] = a; v[1] = b; } else { v[2] = a; v[3] = b; }
-    float c = h1 ? v[0] : v[1], d = h1 ? v[2] : v[3];
-    c = dpp_quad<0xB1>(c);      // quad_perm [1,0,3,2]
-    d = dpp_quad<0xB1>(d);
-    if (h1) { v[0] = c; v[2] = d; } else { v[1] = c; v[3] = d; }
+    const float t0 = dpp_quad<0x4E>(v[0]), t1 = dpp_quad<0x4E>(v[1]);      // quad_perm [2,3,0,1]: partner lane ^ 2
+    const float t2 = dpp_quad<0x4E>(v[2]), t3 = dpp_quad<0x4E>(v[3]);
+    const float w0 = h2 ? t2 : v[0], w1 = h2 ? t3 : v[1], w2 = h2 ? v[2] : t0, w3 = h2 ? v[3] : t1;
+    const float u0 = dpp_quad<0xB1>(w0), u1 = dpp_quad<0xB1>(w1);          // quad_perm [1,0,3,2]: partner lane ^ 1
+    const float u2 = dpp_quad<0xB1>(w2), u3 = dpp_quad<0xB1>(w3);
+    v[0] = h1 ? u1 : w0; v[1] = h1 ? w1 : u0; v[2] = h1 ? u3 : w2; v[3] = h1 ? w3 : u2;
 }
 constexpr int HTILE_ELEMS = 256;   // one (16 tokens x 16 hidden units) tile
 // `tile` = start of the (token tile, hidden tile) block; tokens >= n_valid (within this 16-token tile) are stored as 0
@@ -161,7 +161,8 @@ __device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int l
     quad_transpose(v, lane);
     const int r = lane & 15, q = lane >> 4;
     const int t0 = 4 * (r >> 2);
-    if (t0 + 4 > n_valid) {
+    if (__builtin_amdgcn_readfirstlane(n_valid) < 16) {      // wave-uniform: only a clip's last (partial) tile pays for it
+        asm volatile("" ::: "memory");                         // keep it a branch (hipcc otherwise if-converts it into 8 selects per tile)
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (t0 + j < n_valid) ? v[j] : 0.f;
     }
