@@ -493,19 +493,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 if (it + 1 < nit) issue_w1(hb_of(it + 1));  // in flight while GEMM2 runs
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(w2r);
-                uint32_t bits = 0;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = hacc[i][t][e] + bv[i][e];
-                            bits |= (v > 0.f ? 1u : 0u) << ((i * NT + t) * 4 + e);
-                            hacc[i][t][e] = fmaxf(v, 0.f);
-                        }
-                // ReLU sign bits for the backward (saves it one of its three FFN GEMMs): 256 B per wave, coalesced
-                p.relu_bits[(((size_t)l * p.B + clip) * nhb + hb) * 64 + lane] = bits;
+                        for (int e = 0; e < 4; ++e) hacc[i][t][e] = fmaxf(hacc[i][t][e] + bv[i][e], 0.f);
                 if (w.ffn_thresh) {     // one wave-uniform branch per hidden block
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -519,6 +512,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         }
                     }
                 }
+                // "Alive" bits for the backward: ReLU active AND kept by the dropout, i.e. H != 0. The backward then
+                // needs neither the H GEMM nor the dropout RNG: dH = alive ? dY W2 / (1 - p) : 0. 256 B per wave, coalesced.
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bits |= (hacc[i][t][e] > 0.f ? 1u : 0u) << ((i * NT + t) * 4 + e);
+                p.relu_bits[(((size_t)l * p.B + clip) * nhb + hb) * 64 + lane] = bits;
                 Frag<BF16> hbq[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<BF16>(hacc[0][t], hacc[1][t]);

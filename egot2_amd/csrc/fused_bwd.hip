@@ -725,7 +725,6 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const FusedBwdLayer& w = p.layer[l];
         const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
         const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
-        const uint64_t k_ffn = dev_seed ? site_key(seed_dev, l, SITE_FFN) : w.ffn_key;
         const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
         const float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
         const float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
@@ -830,25 +829,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 issue_b(hb);
                 __builtin_amdgcn_sched_barrier(0);
+                // alive bits = ReLU active AND kept by the forward's dropout: no RNG here
+                const float dscale = w.ffn_thresh ? w.drop_inv : 1.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = ((bits >> ((i * NT + t) * 4 + e)) & 1u) ? dacc[i][t][e] : 0.f;
-                if (w.ffn_thresh) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        int h0 = hb * 32 + i * 16 + 4 * q;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            float ds[4];
-                            drop_scale4(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)h0, w.ffn_thresh, w.drop_inv, ds);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) dacc[i][t][e] *= ds[e];
-                        }
-                    }
-                }
+                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = ((bits >> ((i * NT + t) * 4 + e)) & 1u) ? dacc[i][t][e] * dscale : 0.f;
                 Frag<BF16> dq_[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<BF16>(dacc[0][t], dacc[1][t]);
