@@ -216,10 +216,11 @@ def pmc_traffic(dtype, B, T, L, kernel):
 
 
 def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
-    """Dominant kernel = fused_bwd_kernel (the per-clip backward: LayerNorm/attention/projection input gradients and the
-    FFN input gradient with H recomputed). Its ALGORITHMIC FLOPs per launch are the dX-type GEMMs of the backward
-    (BASELINE.md §2 accounting, recompute NOT counted): L * (2N d 3d + 2N d^2 + 4N d d_ff + 8 B S^2 d).
-    Average launch duration is measured live with hipEvents recorded on the launch stream (egx_timing_*)."""
+    """Dominant kernel = fused_bwd_kernel (the per-clip backward: head, LayerNorm, attention and projection input
+    gradients and the FFN input gradient dH = (W2^T g) .* alive, dX1 = W1^T dH). Its ALGORITHMIC FLOPs per launch are the
+    dX-type GEMMs of the backward (BASELINE.md §2 accounting; the QKV / attention-probability recompute is NOT counted):
+    L * (2N d 3d + 2N d^2 + 4N d d_ff + 8 B S^2 d). Average launch duration is measured live with hipEvents recorded on
+    the launch stream (egx_timing_*), over eager launches of the same step."""
     import ctypes as C
     S = K * T
     N = B * S
