@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-line", action="store_true", help="skip the separate fwd+bwd+Adam measurement")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -63,8 +64,14 @@ def main():
         raise SystemExit("bench.py needs a GPU: the translator has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist          # take the distributed code path
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
@@ -97,7 +104,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -112,7 +119,8 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        # thread_local: with world > 1 the RCCL watchdog thread may touch the HIP runtime while this thread records
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
             fn()
         torch.cuda.synchronize()
         return gr
@@ -126,7 +134,7 @@ def main():
             step_fn()
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
@@ -139,7 +147,7 @@ def main():
 
     def make_step(with_opt):
         """fwd + weighted CE + bwd (+ gradient all-reduce over RCCL when world > 1) (+ Adam)."""
-        if with_opt and world == 1:
+        if with_opt and not multi:
             def body():
                 fwd_bwd()
                 with_opt.step()
@@ -152,7 +160,7 @@ def main():
                 gr.replay()
             else:
                 fwd_bwd()
-            ddp.allreduce_gradients(params)
+            ddp.allreduce_gradients(params, force=args.force_dist)
             if with_opt:
                 with_opt.step()
         return step
@@ -193,7 +201,7 @@ def main():
         out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,25 +50,29 @@ def _flat_groups(params: Iterable[torch.nn.Parameter]):
 
 
 @torch.no_grad()
-def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = True) -> int:
-    """All-reduce every .grad in place; returns the number of collectives issued."""
+def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, force: bool = False) -> int:
+    """All-reduce every .grad in place; returns the number of collectives issued. `force` issues the collectives even in
+    a one-rank group (used to exercise the RCCL path on a single GPU)."""
     if not dist.is_available() or not dist.is_initialized():
         return 0
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return 0
     params = [p for p in params if p.grad is not None]
     flats, loose = _flat_groups(params)
     n = 0
+    # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the explicit scale
+    fused_avg = average and dist.get_backend(group) == "nccl"
+    op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
     for buf in flats:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        if average:
+        dist.all_reduce(buf, op=op, group=group)
+        if average and not fused_avg:
             buf.mul_(1.0 / world)
         n += 1
     if loose:
         flat = torch.cat([g.reshape(-1) for g in loose])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
+        dist.all_reduce(flat, op=op, group=group)
+        if average and not fused_avg:
             flat.mul_(1.0 / world)
         off = 0
         for g in loose:
