@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-line", action="store_true", help="skip the separate fwd+bwd+Adam measurement")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="world > 1: start the all-reduce of all but the late gradients while the backward's tail (grouped small weight gradients) still runs; default: one all-reduce after the backward")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
     args = ap.parse_args()
 
@@ -145,8 +146,58 @@ def main():
         model.enable_device_seed()
     opt = FusedAdam(params, lr=5e-4) if args.optimizer else None     # Adam(lr=5e-4): video_task_2loader.py:62-64
 
+    from egot2_amd import functional as F_egx
+
+    def staged_backward_ok():
+        """The overlapped exchange needs the staged backward (fused path): check it against the one-shot backward."""
+        if not use_graph:
+            return False
+        try:
+            grads = []
+            for defer in (False, True):
+                model._egx_seed_dev.fill_(12345)
+                model.egx_defer_small = defer
+                fwd_bwd()
+                F_egx.run_deferred()
+                grads.append([p.grad.detach().clone() for p in params])
+            torch.cuda.synchronize()
+            ok = F_egx.last_grad_layout.get("late_floats", 0) > 0 and all(
+                torch.allclose(a, b, rtol=1e-3, atol=1e-5) for a, b in zip(*grads))
+        except Exception as e:          # noqa: BLE001  (any failure -> the plain path)
+            print(f"[bench] staged backward unavailable ({e}); using the plain all-reduce", file=sys.stderr)
+            ok = False
+        model.egx_defer_small = False
+        return ok
+
+    overlap = multi and args.overlap and staged_backward_ok()
+
     def make_step(with_opt):
         """fwd + weighted CE + bwd (+ gradient all-reduce over RCCL when world > 1) (+ Adam)."""
+        if overlap:
+            # graph 1: forward + loss + backward up to the grouped small weight gradients; graph 2: those. The all-reduce
+            # of everything else runs on RCCL's stream while graph 2 executes, then the late region follows.
+            model.egx_defer_small = True
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd()
+                    F_egx.run_deferred()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                fwd_bwd()
+            with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                F_egx.run_deferred()
+            torch.cuda.synchronize()
+
+            def step_overlapped():
+                g1.replay()
+                ddp.allreduce_gradients_overlapped(g2.replay, force=args.force_dist)
+                if with_opt:
+                    with_opt.step()
+            return step_overlapped
         if with_opt and not multi:
             def body():
                 fwd_bwd()
@@ -180,7 +231,7 @@ def main():
         "config": {"workload": f"configs[1]: TTM 3-task translator (LAM+TTM+ASD), {L} layer d=128 h=4 d_ff=2048, "
                                f"B={B}/GPU T={T} S={K * T}, synthetic N(0,1) features, random-init weights, "
                                f"train mode dropout={args.dropout} (+0.1 on PE), weighted CE, fwd+bwd"
-                               + (" + FusedAdam" if opt else "") + (" + RCCL grad all-reduce" if world > 1 else ""),
+                               + (" + FusedAdam" if opt else "") + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
                    "launch": "one hipGraph replay per step" if graph else "eager"},
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,

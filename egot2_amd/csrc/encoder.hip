@@ -514,7 +514,10 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
             bp.seed_ptr = cfg->seed_ptr;
-            if (fused_backward(bp, comp, st)) return 1;
+            const int stage = cfg->bwd_stage;
+            EGX_CHECK(stage >= 0 && stage <= 2, "bwd_stage=%d", stage);
+            if (stage == 2) bp.zero_buf = nullptr;
+            if (stage != 2 && fused_backward(bp, comp, st)) return 1;
 
             // small parameter gradients: sum the per-clip partials
             ReducePartialsParams rp;
@@ -543,9 +546,9 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(head_grads->W, oh + 256 + FUSED_HEAD_MAX_OUT, head->n_out * 128);
             }
             // the partial-row reduction rides in the slab-reduction launch of the first FFN weight gradient
-            bool rp_pending = true;
+            bool rp_pending = stage != 2;
             void* slab = (char*)scratch + SC.slabs;
-            for (int l = 0; l < pl.L; ++l) {
+            for (int l = 0; l < pl.L && stage != 2; ++l) {
                 const egx_layer& w = layers[l];
                 const egx_layer_grads& gw = layer_grads[l];
                 if (gw.lin1_w || gw.lin1_b || gw.lin2_w) {
@@ -568,7 +571,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             }
             if (rp_pending && reduce_partials(rp, st)) return 1;
             // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches
-            {
+            if (stage != 1) {
                 SmallDwParams sp;
                 memset(&sp, 0, sizeof(sp));
                 auto flush = [&]() -> int { int rc = sp.n ? small_dw(sp, comp, st) : 0; memset(&sp, 0, sizeof(sp)); return rc; };
@@ -593,6 +596,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         if (ferr) return 1;
     }
     EGX_CHECK(pl.L == 0 || (layers && layer_grads), "null layers / layer_grads");
+    if (cfg->bwd_stage == 2) return 0;      // the generic path has no deferred part
     hipStream_t st = (hipStream_t)stream;
     const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;
     const int N = (int)pl.N;

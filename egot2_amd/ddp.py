@@ -90,3 +90,36 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+@torch.no_grad()
+def allreduce_gradients_overlapped(finish_backward, group=None, average: bool = True, force: bool = False) -> int:
+    """Gradient exchange overlapped with the tail of the backward (BASELINE.json north_star). Use with a model whose
+    `egx_defer_small` is set: its backward then stops before the grouped small weight gradients (dW_proj, dW_in, dW_o),
+    which sit FIRST in the flat gradient buffer. This call starts the all-reduce of everything behind them on RCCL's
+    stream, runs `finish_backward()` (functional.run_deferred, or the replay of a graph that captured it) on the compute
+    stream meanwhile, then all-reduces the late region. Returns the number of collectives issued."""
+    from . import functional as F_egx
+    lay = F_egx.last_grad_layout
+    flat, late = lay.get("flat"), int(lay.get("late_floats", 0))
+    if not dist.is_available() or not dist.is_initialized() or flat is None:
+        finish_backward()
+        return 0
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        finish_backward()
+        return 0
+    fused_avg = average and dist.get_backend(group) == "nccl"
+    op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
+    early_buf, late_buf = flat[late:], flat[:late]
+    work = dist.all_reduce(early_buf, op=op, group=group, async_op=True) if early_buf.numel() else None
+    finish_backward()                       # overlaps the collective
+    n = 1 if work is not None else 0
+    if late_buf.numel():
+        dist.all_reduce(late_buf, op=op, group=group)
+        n += 1
+    if work is not None:
+        work.wait()
+    if average and not fused_avg:
+        flat.mul_(1.0 / world)
+    return n

@@ -46,11 +46,12 @@ class EncoderSpec:
     seed_ptr: int = 0      # device address of a uint64 seed (hipGraph-replayable dropout), 0 = use `seed`
     head_n_out: int = 0    # > 0: pooled head (mean -> LN -> Linear) evaluated with the encoder; output = logits
     advance_seed: bool = False   # with seed_ptr: the training forward advances the device seed in its first kernel
+    defer_small: bool = False    # backward: leave the grouped small weight gradients to run_deferred() (all-reduce overlap)
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
                       COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
-                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0)
+                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0, 0)
 
 
 _scratch_cache = {}
@@ -84,37 +85,56 @@ def _elem_ptr(t: torch.Tensor, row: int, row_elems: int) -> int:
 
 
 class _GradPacker:
-    """Allocates every requested gradient as a 16-byte-aligned view of one zero-filled flat buffer."""
+    """Allocates every requested gradient as a 16-byte-aligned view of one flat buffer. Entries marked `late` (the
+    weight gradients the backward finishes last: dW_proj, dW_in, dW_o) are placed first, so that everything behind
+    `late_floats` can be all-reduced while they are still being computed (ddp.allreduce_gradients_overlapped)."""
 
     def __init__(self):
-        self.shapes = []
+        self.entries = []
         self.total = 0
+        self.late_floats = 0
 
-    def add(self, t: Optional[torch.Tensor], want: bool) -> int:
+    def add(self, t: Optional[torch.Tensor], want: bool, late: bool = False) -> int:
         if t is None or not want:
-            self.shapes.append(None)
+            self.entries.append(None)
             return -1
-        off = self.total
-        self.shapes.append((off, t.shape))
-        self.total += (t.numel() + 3) // 4 * 4
-        return len(self.shapes) - 1
+        self.entries.append((t.shape, (t.numel() + 3) // 4 * 4, late))
+        return len(self.entries) - 1
 
     def materialise(self, device, zero: bool = True) -> List[Optional[torch.Tensor]]:
         """zero=False: the caller hands `self.flat` to the library, whose backward zero-fills it (egx_config.zero_buf)."""
-        n = max(self.total, 4)
+        offs, cur = {}, 0
+        for want_late in (True, False):
+            for i, e in enumerate(self.entries):
+                if e is not None and e[2] == want_late:
+                    offs[i] = cur
+                    cur += e[1]
+            if want_late:
+                self.late_floats = cur
+        self.total = cur
+        n = max(cur, 4)
         flat = torch.zeros(n, dtype=torch.float32, device=device) if zero else torch.empty(n, dtype=torch.float32, device=device)
         self.flat = flat
         out = []
-        for s in self.shapes:
-            if s is None:
+        for i, e in enumerate(self.entries):
+            if e is None:
                 out.append(None)
             else:
-                off, shape = s
-                n = 1
-                for k in shape:
-                    n *= k
-                out.append(flat[off:off + n].view(shape))
+                numel = 1
+                for k in e[0]:
+                    numel *= k
+                out.append(flat[offs[i]:offs[i] + numel].view(e[0]))
         return out
+
+
+_deferred = []          # closures that finish a staged backward (EncoderSpec.defer_small)
+last_grad_layout = {}   # {"flat": flat gradient buffer of the latest encoder backward, "late_floats": size of its late region}
+
+
+def run_deferred():
+    """Launch the grouped small weight gradients that a backward with EncoderSpec.defer_small left out."""
+    while _deferred:
+        _deferred.pop(0)()
 
 
 def flat_storage_view(t: torch.Tensor) -> torch.Tensor:
@@ -240,8 +260,9 @@ class EncoderFn(torch.autograd.Function):
         i_lnw = pk.add(ln_w, need[3])
         i_lnb = pk.add(ln_b, need[4])
         i_feat = [pk.add(f, need[5 + i]) for i, f in enumerate(feats)]
-        i_proj = [pk.add(t, need[5 + nseg + i]) for i, t in enumerate(proj)]
-        i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i]) for i, t in enumerate(layer_t)]
+        # proj: (w, b) pairs; layer: 12 tensors in _LAYER_FIELDS order, in_proj_w / out_proj_w are indices 0 and 2
+        i_proj = [pk.add(t, need[5 + nseg + i], late=(i % 2 == 0)) for i, t in enumerate(proj)]
+        i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i], late=(i % 12 in (0, 2))) for i, t in enumerate(layer_t)]
         i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i]) for i, t in enumerate(head_t)]
         grads = pk.materialise(device, zero=False)      # zero-filled by the library's backward (saves a fill launch)
 
@@ -278,24 +299,46 @@ class EncoderFn(torch.autograd.Function):
 
         cfg = spec.config()
         cfg.zero_buf, cfg.zero_bytes = ptr(pk.flat), pk.flat.numel() * 4
+        defer = bool(spec.defer_small) and ctx.fused_path
+        cfg.bwd_stage = 1 if defer else 0
         scratch = _workspace("scratch", device, ctx.scratch_bytes)
         seed = C.c_uint64(spec.seed & (2**64 - 1))
+        saved_buf = ctx.saved_buf
+        # raw addresses only inside `launch`: a closure that kept the gradient VIEW tensors alive would make autograd
+        # clone them instead of adopting them as .grad (they must stay views of the flat buffer)
+        p_lnw, p_lnb, flat_buf = ptr(g(i_lnw)), ptr(g(i_lnb)), pk.flat
         if nhead:
             head = Head(ptr(head_t[0]), ptr(head_t[1]), ptr(head_t[2]), ptr(head_t[3]), spec.head_n_out)
             hg = HeadGrads(ptr(g(i_head[0])), ptr(g(i_head[1])), ptr(g(i_head[2])), ptr(g(i_head[3])))
-            dlog = d_tokens.float().contiguous()
-            check(lib.egx_translator_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(dlog),
-                                         ptr(ctx.saved_buf), ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr,
-                                         C.byref(hg), int(spec.training), seed, _stream()))
+            dtok = d_tokens.float().contiguous()
+
+            def launch(c):
+                check(lib.egx_translator_bwd(C.byref(c), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(dtok),
+                                             ptr(saved_buf), ptr(scratch), sgr, p_lnw, p_lnb, lgr,
+                                             C.byref(hg), int(spec.training), seed, _stream()))
         else:
             # the generic backward overwrites d_tokens (needs a private copy); the fused kernels only read it
             dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
             dtok = dtok.contiguous()
             if dtok.data_ptr() == d_tokens.data_ptr() and not ctx.fused_path:
                 dtok = dtok.clone()
-            check(lib.egx_encoder_bwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(ctx.saved_buf),
-                                      ptr(scratch), sgr, ptr(g(i_lnw)), ptr(g(i_lnb)), lgr, int(spec.training), seed,
-                                      _stream()))
+
+            def launch(c):
+                check(lib.egx_encoder_bwd(C.byref(c), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(saved_buf),
+                                          ptr(scratch), sgr, p_lnw, p_lnb, lgr, int(spec.training), seed,
+                                          _stream()))
+        launch(cfg)
+        last_grad_layout.update(flat=pk.flat, late_floats=pk.late_floats if defer else 0)
+        if defer:
+            # stage 2 (dW_proj, dW_in, dW_o) on request: same arguments, kept alive by this closure; the shared scratch
+            # workspace must not be reused by another encoder call before run_deferred()
+            cfg2 = spec.config()
+            cfg2.bwd_stage = 2
+            keep = (flat_buf, sv, dtok, scratch, saved_buf)   # noqa: F841  (referenced by `finish`: keeps the buffers alive)
+
+            def finish(_keep=keep):
+                launch(cfg2)
+            _deferred.append(finish)
         out = [None, g(i_te), g(i_pos), g(i_lnw), g(i_lnb)]
         out += [g(i) for i in i_feat] + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
         return tuple(out)

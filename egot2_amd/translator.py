@@ -57,6 +57,7 @@ class TranslatorMixin:
 
     egx_compute: str = "f32"
     egx_impl: str = "auto"
+    egx_defer_small: bool = False      # staged backward for the all-reduce overlap (ddp.allreduce_gradients_overlapped)
     _egx_step: int = 0
 
     def set_compute(self, compute: str = "f32", impl: str = "auto"):
@@ -94,7 +95,8 @@ class TranslatorMixin:
                            training=bool(self.training), seed=self._egx_seed() if self.training else 0,
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
                            head_n_out=head[1].out_features if head is not None else 0,
-                           advance_seed=seed_dev is not None and bool(self.training))   # fresh masks per (replayed) step
+                           advance_seed=seed_dev is not None and bool(self.training),   # fresh masks per (replayed) step
+                           defer_small=bool(self.egx_defer_small))
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:

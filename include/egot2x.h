@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 3
+#define EGX_ABI_VERSION 4
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
@@ -127,6 +127,10 @@ typedef struct egx_config {
                                  advanced value. */
     void* zero_buf;           /* optional: a device buffer the BACKWARD zero-fills before any gradient is accumulated */
     size_t zero_bytes;        /* (the caller's flat gradient buffer: saves a separate fill launch); multiple of 16 */
+    int bwd_stage;            /* backward only: 0 = everything; 1 = all but the grouped small weight gradients (dW_proj,
+                                 dW_in, dW_o); 2 = only those (same arguments, zero_buf ignored). Lets the caller start the
+                                 all-reduce of every other gradient while stage 2 still runs (fused path; the generic
+                                 path does all its work in stage 1). */
 } egx_config;
 
 int egx_abi_version(void);

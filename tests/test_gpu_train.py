@@ -151,3 +151,32 @@ def test_whole_training_step_in_one_graph(egx_lib, cuda):
         assert (pa - pb).abs().max().item() <= 2.0 * 5e-4 * 4, n
         assert (pa - pb).abs().median().item() < 1e-5, n
     assert int(opt._step_dev.item()) == 4 and torch.isfinite(loss).item()
+
+
+def test_staged_backward_and_overlapped_allreduce_layout(egx_lib, cuda):
+    """egx_defer_small: the backward stops before the grouped small weight gradients, run_deferred() finishes it, and the
+    result equals the one-shot backward; the late gradients (dW_proj, dW_in, dW_o) sit first in the flat buffer so that
+    ddp.allreduce_gradients_overlapped can exchange the rest while they are still being computed."""
+    from egot2_amd import ddp, functional as F_egx
+    a, b = _ttm(cuda, 8), _ttm(cuda, 8)
+    feats = [f.to(cuda) for f in seeded_feats(31, [(6, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (6,), generator=torch.Generator().manual_seed(3)).to(cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    torch.nn.functional.cross_entropy(a.forward_features(*feats), target, weight=w).backward()
+    b.egx_defer_small = True
+    torch.nn.functional.cross_entropy(b.forward_features(*feats), target, weight=w).backward()
+    late_names = ("proj_lam.weight", "proj_ttm.weight", "proj_asd.weight", "transformer_encoder.layers.0.self_attn.in_proj_weight",
+                  "transformer_encoder.layers.0.self_attn.out_proj.weight")
+    nb = dict(b.named_parameters())
+    lay = F_egx.last_grad_layout
+    assert lay["late_floats"] == sum(nb[n].numel() for n in late_names)
+    for n in late_names:                       # not computed yet: still the zero fill of stage 1
+        assert nb[n].grad.abs().max().item() == 0.0
+        assert nb[n].grad.untyped_storage().data_ptr() == lay["flat"].untyped_storage().data_ptr()
+        assert nb[n].grad.storage_offset() < lay["late_floats"]
+    assert nb["ln.weight"].grad.storage_offset() >= lay["late_floats"]
+    calls = []
+    n_coll = ddp.allreduce_gradients_overlapped(lambda: (calls.append(1), F_egx.run_deferred()))   # no process group: just finishes
+    assert calls == [1] and n_coll == 0
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa.grad, pb.grad, rtol=1e-4, atol=1e-6), n
