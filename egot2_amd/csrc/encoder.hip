@@ -37,6 +37,9 @@ struct Plan {
     size_t scratch_bytes = 0;
 };
 
+// NOT ::max: in hipcc host code the unqualified call resolves to max(int, int) and truncates sizes above 2 GiB
+static inline size_t size_max(size_t a, size_t b) { return a > b ? a : b; }
+
 static size_t take(size_t& cur, size_t bytes) {
     size_t o = cur;
     cur = align_up(cur + bytes, 256);
@@ -91,7 +94,7 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
     pl.s_dqkv = take(sc, N * 3 * d * 4);
     pl.s_dhid = take(sc, N * (size_t)pl.dff * 4);
     size_t slab = 0;
-    auto upd = [&](int M, int Nn, int K) { slab = max(slab, gemm_scratch_bytes(2, M, Nn, K)); };
+    auto upd = [&](int M, int Nn, int K) { slab = size_max(slab, gemm_scratch_bytes(2, M, Nn, K)); };
     upd(3 * pl.d, pl.d, (int)N);
     upd(pl.d, pl.d, (int)N);
     upd(pl.dff, pl.d, (int)N);
@@ -184,9 +187,9 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     s.P = fused_partial_len(pl.L, pl.nseg) + fused_head_partial_len(head_n_out);
     s.partials = take(cur, (size_t)pl.B * s.P * 4);
     size_t slab = ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr);
-    slab = max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
-    slab = max(slab, gemm_scratch_bytes(2, pl.d, pl.d, (int)pl.N));
-    for (int i = 0; i < pl.nseg; ++i) slab = max(slab, gemm_scratch_bytes(2, pl.d, segs[i].d_in, pl.B * segs[i].T));
+    slab = size_max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
+    slab = size_max(slab, gemm_scratch_bytes(2, pl.d, pl.d, (int)pl.N));
+    for (int i = 0; i < pl.nseg; ++i) slab = size_max(slab, gemm_scratch_bytes(2, pl.d, segs[i].d_in, pl.B * segs[i].T));
     s.slab_bytes = slab;
     s.slabs = take(cur, slab);
     s.dhid = take(cur, fused_hid_total(cfg, pl));
@@ -301,8 +304,8 @@ const char* egx_last_error(void) { return g_err; }
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    if (saved_bytes) *saved_bytes = max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
+    if (saved_bytes) *saved_bytes = size_max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
+    if (scratch_bytes) *scratch_bytes = size_max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
     return 0;
 }
 
@@ -724,8 +727,8 @@ int egx_translator_workspace(const egx_config* cfg, const egx_segment* segs, int
     // generic path extras: tokens + pooled behind `saved`, d_tokens behind `scratch`
     size_t extra_sv = align_up(pl.saved_bytes, 256) + (pl.N + (size_t)B) * pl.d * 4 + 256;
     size_t extra_sc = align_up(pl.scratch_bytes, 256) + pl.N * pl.d * 4 + 256;
-    if (saved_bytes) *saved_bytes = max(sv, extra_sv);
-    if (scratch_bytes) *scratch_bytes = max(sc, extra_sc);
+    if (saved_bytes) *saved_bytes = size_max(sv, extra_sv);
+    if (scratch_bytes) *scratch_bytes = size_max(sc, extra_sc);
     return 0;
 }
 

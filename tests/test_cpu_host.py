@@ -40,6 +40,25 @@ def test_workspace_query_and_config_errors(egx_lib):
     assert egx_lib.egx_encoder_workspace(C.byref(cfg), segs, 0, C.byref(sv), C.byref(sc)) != 0   # empty batch
 
 
+def test_workspace_sizes_above_2_gib_are_not_truncated(egx_lib):
+    """C4 at B=256 (HOI LTA 4-task, S=128, d=768, 4 layers) keeps > 4 GiB of intermediates: the size must come back
+    intact (an unqualified max() in hipcc host code resolves to max(int, int) and used to return 0 here)."""
+    import ctypes as C
+    from egot2_amd._lib import Config, Segment
+    cfg = Config(768, 8, 2048, 4, 4, 1e-5, 0, 0, 0.1, 0.0, 0.0)
+    segs = (Segment * 4)()
+    for s, k in zip(segs, (8192, 8192, 768, 2048)):
+        s.T, s.d_in, s.proj_w = 32, k, (0 if k == 768 else 1)
+    sv, sc = C.c_size_t(), C.c_size_t()
+    assert egx_lib.egx_encoder_workspace(C.byref(cfg), segs, 256, C.byref(sv), C.byref(sc)) == 0
+    N = 256 * 128
+    assert sv.value > 4 * N * (2048 + 7 * 768) * 4 > 2**31      # per layer: hidden + x_in, qkv (3), attn_o, res1, x1 (+ res2)
+    assert sc.value > N * 2048 * 4
+    sv2, sc2 = C.c_size_t(), C.c_size_t()
+    assert egx_lib.egx_translator_workspace(C.byref(cfg), segs, 256, C.byref(sv2), C.byref(sc2)) == 0
+    assert sv2.value >= sv.value and sc2.value >= sc.value
+
+
 def test_cpu_tensors_raise_not_fallback(egx_lib):
     from egot2_amd import _lib, hhi_ttm
     from tests.util import hhi_args, seeded_feats
