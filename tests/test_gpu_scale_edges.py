@@ -1,0 +1,61 @@
+"""-m gpu: size extremes. Long sequences (T = 150 per task as in validation, S = 450) on the shape-generic kernels against
+the oracle; very large clip batches on the fused kernels (intermediates above 2 GiB) against the same clips run in
+small batches."""
+import pytest
+import torch
+
+from oracle import translator_ref as tr
+from tests.util import hhi_args, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+CE_W = [0.266, 0.734]
+
+
+def test_long_validation_sequence_matches_oracle(egx_lib, cuda):
+    """batch_size = 1, T = 150: S = 450 tokens, far beyond the fused kernels' 48."""
+    from egot2_amd import hhi_ttm
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=1))
+    sd = seeded_state_dict(m, 21)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    m.pos_embed.dropout.p = 0.0
+    feats = seeded_feats(22, [(1, 150, 256)] * 3)
+    target = torch.tensor([1])
+    logits = m.forward_features(*[f.to(cuda) for f in feats])
+    torch.nn.functional.cross_entropy(logits, target.to(cuda), weight=torch.tensor(CE_W, device=cuda)).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats])
+    tr.weighted_ce(ref, target, CE_W).backward()
+    assert (logits.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-3
+    for k, p in m.named_parameters():
+        g, r = p.grad.detach().cpu().double(), sd64[k].grad
+        assert (g - r).norm().item() <= 1e-2 * r.norm().item() + 1e-6, k
+
+
+@pytest.mark.parametrize("B", [6144])
+def test_huge_batch_on_fused_kernels(egx_lib, cuda, B):
+    """B = 6144 clips: H tiles 2.4 GB + dH tiles 2.4 GB (size_t arithmetic everywhere). Logits of the big batch must
+    equal the logits of the same clips in batches of 256 (clips are independent), gradients must equal the sum."""
+    from egot2_amd import hhi_ttm
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=1))
+    m.load_state_dict(seeded_state_dict(m, 23))
+    m = m.to(cuda).train()
+    m.pos_embed.dropout.p = 0.0
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(B, 15, 256, generator=g).to(cuda) for _ in range(3)]
+    w = torch.randn(B, 2, generator=g).to(cuda)
+    big = m.forward_features(*feats)
+    (big * w).sum().backward()
+    big_grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    outs = []
+    for i in range(0, B, 768):
+        o = m.forward_features(*[f[i:i + 768] for f in feats])
+        (o * w[i:i + 768]).sum().backward()           # accumulates into .grad
+        outs.append(o.detach())
+    small = torch.cat(outs)
+    assert torch.isfinite(big).all()
+    assert (big.detach() - small).abs().max().item() < 1e-5
+    for k, p in m.named_parameters():
+        a, b = big_grads[k], p.grad
+        assert (a - b).norm().item() <= 2e-3 * b.norm().item() + 1e-4, k
