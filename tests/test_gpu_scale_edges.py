@@ -59,3 +59,36 @@ def test_huge_batch_on_fused_kernels(egx_lib, cuda, B):
     for k, p in m.named_parameters():
         a, b = big_grads[k], p.grad
         assert (a - b).norm().item() <= 2e-3 * b.norm().item() + 1e-4, k
+
+
+def test_c4_real_dimensions_match_oracle(egx_lib, cuda):
+    """BASELINE.json configs[3] at its real sizes (n = 32 clips per task -> S = 128, d = 768, 8 heads of 96, 4 layers,
+    8192-wide PNR/OSCC features), B = 2: the shape-generic kernels (head dim 96, chunked attention) against the oracle."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import hoi_lta
+    cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=32, NUM_ACTIONS_TO_PREDICT=3),
+             MODEL=NS(TRANSLATION_HEADS=8, TRANSLATION_LAYERS=4, TRANSLATION_INPUT_FEATURES=768, TRANSLATION_DROPOUT=0.0,
+                      NUM_CLASSES=[5, 7], DROPOUT_RATE=0.0, HEAD_ACT="softmax"), TEST=NS(NO_ACT=False))
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+    sd = seeded_state_dict(m, 33)
+    m.load_state_dict(sd)
+    m = m.to(cuda).train()
+    B = 2
+    feats = seeded_feats(34, [(B, 32, 8192), (B, 32, 8192), (B, 32, 768), (B, 32, 2048)])
+    outs = m.forward_features(*[f.to(cuda) for f in feats])
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    (lin(outs[0]) + lin(outs[1])).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = tr.lta4_forward(sd64, 8, *[f.double() for f in feats], [5, 7])
+    (lin(ref[0]) + lin(ref[1])).backward()
+    for o, r in zip(outs, ref):
+        assert (o.detach().cpu().double() - r.detach()).abs().max().item() < 1e-3 * max(1.0, r.abs().max().item())
+    worst = 0.0
+    for k, p in m.named_parameters():
+        r = sd64[k].grad
+        if r is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        err = (p.grad.detach().cpu().double() - r).norm().item() / (r.norm().item() + 1e-9)
+        worst = max(worst, err)
+        assert err < 1e-2, f"{k}: {err}"
