@@ -288,6 +288,10 @@ static int pick_splits(int tiles, int K) {
 static void choose_tiles(int layout, int M, int N, int K, bool& big, int& splits) {
     long tiles_big = (long)cdiv(M, 128) * cdiv(N, 128);
     big = tiles_big >= 200;
+    // weight gradients split K (tokens) across blockIdx.z: the grid fills the chip through the splits, so prefer the
+    // 128 x 128 tile (4x the MFMA work per staged byte and per barrier of the 64 x 64 one) whenever splits can supply
+    // >= 256 workgroups
+    if (layout == 2 && M >= 128 && N >= 128 && tiles_big * (long)min(64, max(1, K / (BK * 8))) >= 256) big = true;
     int bm = big ? 128 : 64;
     int tiles = cdiv(M, bm) * cdiv(N, bm);
     splits = (layout == 2) ? pick_splits(tiles, K) : 1;
