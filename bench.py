@@ -251,6 +251,13 @@ def main():
         from oracle.stock_module import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)
     if rank == 0:
+        # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION is exported on the GPU boxes); push it out
+        # first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
