@@ -84,7 +84,8 @@ def main():
     feats = [torch.randn(B, 15, 256, device=dev) for _ in range(3)]
     for comp in ("bf16", "f32"):
         run("C5 EgoT2-g HHI encoder L=3 d=256 S=45", m, feats, lambda mm, f: mm.encode_features("ttm", *f), [(15, 256, True)] * 3, 256, 2048, 3, B, comp)
-    from oracle.ref_harness import HOI_G_VOCAB
+    HOI_G_VOCAB = {'</s>': 0, '<unk>': 1, 'pnr': 2, 'oscc': 3, 'action_verb': 4, 'action_noun': 5, 'lta_verb': 6, 'lta_noun': 7,
+                   '0': 8, '1': 9, '2': 10, '3': 11}
     m = hoi_multitask.TaskTranslationPromptTransformer6Task(NS(hidden_dim=512, num_heads=8, num_layers=3, dropout=0.1), HOI_G_VOCAB)
     feats = [torch.randn(B, 16, 8192, device=dev), torch.randn(B, 16, 8192, device=dev), torch.randn(B, 8, 2048, device=dev),
              torch.randn(B, 8, 256, device=dev)]
