@@ -1,6 +1,8 @@
 """CPU suite for the host side: C-ABI surface, registry semantics, error behaviour, data-parallel gradient exchange
 (gloo, world_size 2), bench arithmetic."""
 import os
+
+import numpy as np
 import re
 import sys
 
@@ -151,3 +153,45 @@ def test_two_rank_gradient_allreduce_equals_single_process():
     torch.nn.functional.cross_entropy(m(*feats), y).backward()
     for k, p in m.named_parameters():
         assert torch.allclose(p.grad, torch.from_numpy(grads[k]), rtol=1e-4, atol=1e-6), k
+
+
+def _overlap_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from egot2_amd import ddp, functional as F_egx
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(40, dtype=torch.float32) * (rank + 1)        # rank 0: i, rank 1: 2i -> average 1.5 i
+    late = 12
+    flat[:late] = -1.0                                              # "not computed yet": finish_backward fills them in
+    F_egx.last_grad_layout.clear()
+    F_egx.last_grad_layout.update(flat=flat, late_floats=late)
+    order = []
+
+    def finish():
+        order.append("finish")
+        flat[:late] = torch.arange(late, dtype=torch.float32) * 10 * (rank + 1)
+    n = ddp.allreduce_gradients_overlapped(finish)
+    if rank == 0:
+        q.put((n, order, flat.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_allreduce():
+    """The overlapped exchange on gloo: the early region is reduced while `finish_backward` produces the late one, the
+    late region follows, and both come out averaged over the ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, order, flat = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n == 2 and order == ["finish"]
+    i = np.arange(40, dtype=np.float32)
+    assert np.allclose(flat[12:], 1.5 * i[12:])
+    assert np.allclose(flat[:12], 15.0 * i[:12])
