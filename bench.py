@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: clips/s, forward+backward, 3-task TTM translator (B=256 per GPU, T=15, d=128, h=4, L=1,
-d_ff=2048) on synthetic backbone features — BASELINE.json configs[1].
+d_ff=2048) on synthetic backbone features — BASELINE.json configs[1]. `--config c1|c3|c4|c5hhi|c5hoi` times the other
+BASELINE configurations the same way (each with its own roofline block); the default line stays configs[1], fp32.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-A step = token preparation + encoder + pooled head + weighted CE + full backward (+ one RCCL all-reduce of the
-flat gradient buffer when N > 1) over one batch of 256 clips per GPU (weak scaling). Inputs are resident in HBM
-before the timed region. Rank 0 prints ONE JSON line.
+With N > 1 and no WORLD_SIZE in the environment the script launches its own ranks — `python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` on this same file, as a CHILD process started before anything
+touches the GPU (the reference does the same through Lightning's `strategy="ddp"`, HOI/scripts/multitask/run.py:41-50)
+— relays their output and exits with their code; launched under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
+
+A step = token preparation + encoder + task head + loss + full backward (+ one RCCL all-reduce of the flat gradient
+buffer when N > 1) over one batch of 256 clips per GPU (weak scaling). Inputs are resident in HBM before the timed
+region. Each trial times EXACTLY --steps steps between barrier + synchronize pairs (max over ranks); `ms_per_step` is
+the median trial, p10 / p90 are reported next to it. Rank 0 prints ONE JSON line (the last line of stdout).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,26 +43,120 @@ def algorithmic_flops(B, K, T, d_in, d, h, L, d_ff, n_out=2):
     return fwd, bwd
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--trials", type=int, default=0, help="timed repetitions of --steps (0 = auto: >= 5 and >= 0.3 s of timed region)")
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi"],
+                    help="BASELINE.json configuration (default c2 = configs[1], the metric)")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=15)
-    ap.add_argument("--layers", type=int, default=1)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
-    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused"])
-    ap.add_argument("--dropout", type=float, default=0.5, help="encoder dropout (reference recipe README.md:84 uses 0.5)")
+    ap.add_argument("--layers", type=int, default=0, help="0 = the configuration's own depth")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="default: f32 for c1/c2, bf16 for c3..c5 (BASELINE.json)")
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide"])
+    ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-line", action="store_true", help="skip the separate fwd+bwd+Adam measurement")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="world > 1: start the all-reduce of all but the late gradients while the backward's tail (grouped small weight gradients) still runs; default: one all-reduce after the backward")
+    ap.add_argument("--no-overlap", action="store_true", help="world > 1: one all-reduce after the whole backward instead of the exchange overlapped with the backward's tail")
+    ap.add_argument("--overlap", action="store_true", help="(default for world > 1; kept for compatibility)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="exercise only the launcher plumbing (rank spawn, process group on --backend, barrier, max-over-ranks timing, JSON relay) without the model; CPU-runnable")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo only for --launch-selftest)")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
 
+
+# ---- N > 1 without torchrun: launch the ranks ourselves ---------------------------------------------------------------
+def self_launch(args, argv) -> int:
+    """Start `args.gpus` ranks of this script under torch.distributed.run as a child process. This process has made no
+    HIP call (torch is not even imported), so nothing is re-exec'd after GPU initialisation. The child's stdout is relayed;
+    the JSON line of rank 0 is re-printed LAST. Returns the child's exit code."""
+    port = args.master_port or (29600 + os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith("{") and s.endswith("}") and '"metric"' in s:
+            last_json = s
+        else:
+            sys.stdout.write(line)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if rc != 0:
+        print(f"[bench] rank launch failed with exit code {rc}", file=sys.stderr)
+        return rc
+    if last_json is None:
+        print("[bench] the ranks produced no JSON line", file=sys.stderr)
+        return 1
+    print(last_json, flush=True)
+    return 0
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    if len(xs) == 1:
+        return xs[0]
+    pos = q * (len(xs) - 1)
+    lo = int(pos)
+    hi = min(lo + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (pos - lo)
+
+
+def launch_selftest(args):
+    """The distributed plumbing of bench.py without the model: process group, barrier-bracketed timing with max over
+    ranks, one JSON line from rank 0. Runs on CPU with --backend gloo (tests/test_cpu_host.py)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(args.backend)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest", "value": None, "n_gpus": world, "rank_sum": t.item(),
+                          "max_rank_seconds": dt.item(), "config": {"parallelism": f"dp{world}"}, "selftest": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return self_launch(args, argv)                  # before ANY torch / HIP call in this process
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with a matching world size", file=sys.stderr)
+        return 2
+    if args.launch_selftest:
+        return launch_selftest(args)
+    return run(args)
+
+
+def run(args) -> int:
     import torch
     import torch.distributed as dist
 
@@ -70,36 +172,28 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(args.master_port or 29533))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
-    from egot2_amd import ddp, hhi_ttm, _lib
-    from tests.util import hhi_args
+    from egot2_amd import ddp, synth, _lib
+    from egot2_amd import functional as F_egx
+    from egot2_amd.train import FusedAdam
     lib = _lib.load()
 
-    B, T, K, d, h, L, dff = args.batch, args.frames, 3, 128, 4, args.layers, 2048
-    torch.manual_seed(0)
-    model = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(hidden_dim=d, num_heads=h, dropout=args.dropout, num_layers=L))
-    model = model.to(dev).set_compute(args.dtype, args.impl).train()
+    wl = synth.make_workload(args.config, dev, batch=args.batch, frames=args.frames, layers=args.layers or None,
+                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank)
+    model, params, B = wl["model"], wl["params"], wl["B"]
+    dtype = wl["compute"]
     ddp.broadcast_parameters(model)
-    params = [p for p in model.parameters() if p.requires_grad]
-
-    from egot2_amd.train import CrossEntropyLoss, FusedAdam
-    g = torch.Generator().manual_seed(1234 + rank)
-    feats = [torch.randn(B, T, 256, generator=g).to(dev) for _ in range(K)]
-    target = torch.randint(0, 2, (B,), generator=g).to(dev)
-    criterion = CrossEntropyLoss(torch.FloatTensor([0.266, 0.734])).to(dev)   # video_task_2loader.py:21-22
-    from egot2_amd.functional import unit_grad
-    one = unit_grad(dev)
+    one = F_egx.unit_grad(dev)
+    loss_fn = wl["loss_fn"]
 
     def fwd_bwd():
         for p in params:
             p.grad = None
-        loss = criterion(model.forward_features(*feats), target)
+        loss = loss_fn()
         loss.backward(gradient=one)     # persistent 1.0: no ones-fill, and the fused CE skips the multiply by it
         return loss
 
@@ -109,13 +203,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def capture(fn):
+    def capture(fn, warm=3):
         """One hipGraph for `fn`: the library only enqueues kernels on the current stream and the dropout seed / Adam
         step count live in device memory (advanced inside the graph), so a replay is exact training work."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):
+            for _ in range(warm):
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -126,27 +220,47 @@ def main():
         torch.cuda.synchronize()
         return gr
 
-    def timed(step_fn, warmup, steps):
+    def time_trials(step_fn, warmup, steps, trials):
+        """`trials` timed regions of exactly `steps` steps each, barrier + synchronize on both sides, max over ranks."""
         for _ in range(warmup):
             step_fn()
+        out = []
+        for _ in range(trials):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            sync()
+            dt = time.perf_counter() - t0
+            if multi:
+                t = torch.tensor([dt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = t.item()
+            out.append(dt)
+        return out
+
+    def auto_trials(step_fn, steps):
+        if args.trials > 0:
+            return args.trials
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(3):
             step_fn()
         sync()
-        dt = time.perf_counter() - t0
-        if multi:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        est = (time.perf_counter() - t0) / 3 * steps
+        n = max(5, int(0.3 / max(est, 1e-6)) + 1)
+        n = min(n, 200)
+        if multi:       # every rank must run the same number of trials
+            t = torch.tensor([n], device=dev, dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt
+            n = int(t.item())
+        return n
 
-    use_graph = not args.no_graph
+    fused_graph_ok = wl["name"] in ("c1", "c2", "c3")        # device-resident dropout seed: fused kernels only
+    use_graph = not args.no_graph and fused_graph_ok
     if use_graph:
         model.enable_device_seed()
     opt = FusedAdam(params, lr=5e-4) if args.optimizer else None     # Adam(lr=5e-4): video_task_2loader.py:62-64
-
-    from egot2_amd import functional as F_egx
 
     def staged_backward_ok():
         """The overlapped exchange needs the staged backward (fused path): check it against the one-shot backward."""
@@ -169,10 +283,29 @@ def main():
         model.egx_defer_small = False
         return ok
 
-    overlap = multi and args.overlap and staged_backward_ok()
+    overlap = multi and not args.no_overlap and staged_backward_ok()
+    ar_time = {"s": 0.0, "n": 0}
+
+    def place_optimizer(with_opt):
+        """FusedAdam re-points the parameters into its flat buffer on its FIRST step; a graph captured before that would
+        keep reading the old (freed) parameter storage. Run one eager step first so that the capture sees the final
+        addresses, and assert they no longer move."""
+        if with_opt is None:
+            return
+        fwd_bwd()
+        F_egx.run_deferred()
+        ddp.allreduce_gradients(params, force=args.force_dist)
+        with_opt.step()
+        before = [p.data_ptr() for p in params]
+        fwd_bwd()
+        F_egx.run_deferred()
+        with_opt.step()
+        torch.cuda.synchronize()
+        assert before == [p.data_ptr() for p in params], "FusedAdam moved a parameter after its first step"
 
     def make_step(with_opt):
-        """fwd + weighted CE + bwd (+ gradient all-reduce over RCCL when world > 1) (+ Adam)."""
+        """fwd + loss + bwd (+ gradient all-reduce over RCCL when world > 1) (+ Adam)."""
+        place_optimizer(with_opt)
         if overlap:
             # graph 1: forward + loss + backward up to the grouped small weight gradients; graph 2: those. The all-reduce
             # of everything else runs on RCCL's stream while graph 2 executes, then the late region follows.
@@ -194,10 +327,11 @@ def main():
 
             def step_overlapped():
                 g1.replay()
-                ddp.allreduce_gradients_overlapped(g2.replay, force=args.force_dist)
+                ddp.allreduce_gradients_overlapped(g2.replay, params, force=args.force_dist)
                 if with_opt:
                     with_opt.step()
             return step_overlapped
+        model.egx_defer_small = False
         if with_opt and not multi:
             def body():
                 fwd_bwd()
@@ -217,39 +351,63 @@ def main():
         return step
 
     step = make_step(opt)
-    dt = timed(step, args.warmup, args.steps)
-    graph = use_graph
-    ms_per_step = dt / args.steps * 1e3
-    value = B * world * args.steps / dt
-    fwd_f, bwd_f = algorithmic_flops(B, K, T, 256, d, h, L, dff)
+    trials = auto_trials(step, args.steps)
+    dts = time_trials(step, args.warmup, args.steps, trials)
+    dt_med = percentile(dts, 0.5)
+    ms = [d / args.steps * 1e3 for d in dts]
+    ms_per_step = dt_med / args.steps * 1e3
+    value = B * world / (ms_per_step * 1e-3)
+    fwd_f, bwd_f = wl["flops"]
 
+    # the exchange on its own (same buffers, same stream order), for the `allreduce_us` field
+    allreduce_us = None
+    if multi:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ddp.allreduce_gradients(params, force=args.force_dist)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t0) / 20 * 1e6
+        t = torch.tensor([allreduce_us], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_us = t.item()
+        for p in params:        # 20 averaged copies later the gradients are still finite; nothing reads them again
+            p.grad = None
+
+    metric = ("clips/sec fwd+bwd, 3-task TTM translator (B=256,T=15,d=128)" if wl["name"] == "c2"
+              else f"clips/sec fwd+bwd, {wl['name']}")
     out = {
-        "metric": "clips/sec fwd+bwd, 3-task TTM translator (B=256,T=15,d=128)",
+        "metric": metric,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"configs[1]: TTM 3-task translator (LAM+TTM+ASD), {L} layer d=128 h=4 d_ff=2048, "
-                               f"B={B}/GPU T={T} S={K * T}, synthetic N(0,1) features, random-init weights, "
-                               f"train mode dropout={args.dropout} (+0.1 on PE), weighted CE, fwd+bwd"
-                               + (" + FusedAdam" if opt else "") + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else "")) if multi else ""),
+        "dtype": dtype, "data": "synthetic",
+        "trials": trials, "ms_per_step_p10": percentile(ms, 0.1), "ms_per_step_p90": percentile(ms, 0.9),
+        "ms_per_step_min": min(ms), "timed_seconds": sum(dts),
+        "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
+                               + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
-                   "launch": "one hipGraph replay per step" if graph else "eager"},
+                   "launch": "one hipGraph replay per step" if use_graph else "eager"},
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
-        "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype],
+        "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
     }
+    if allreduce_us is not None:
+        out["allreduce_us"] = allreduce_us
 
     if not args.optimizer and not args.no_optimizer_line:
         # "+ optimizer step reported separately" (SURVEY.md 8d): the same step with the Adam update inside
         opt2 = FusedAdam(params, lr=5e-4)
         step2 = make_step(opt2)
-        dt2 = timed(step2, max(3, args.warmup // 2), args.steps)
+        d2 = time_trials(step2, max(3, args.warmup // 2), args.steps, max(3, trials // 2))
+        m2 = percentile(d2, 0.5) / args.steps * 1e3
         out["with_optimizer"] = {"optimizer": "FusedAdam(lr=5e-4), one launch over the flat parameter buffer",
-                                 "ms_per_step": dt2 / args.steps * 1e3, "value": B * world * args.steps / dt2, "unit": "clips/s"}
+                                 "ms_per_step": m2, "value": B * world / (m2 * 1e-3), "unit": "clips/s"}
     if rank == 0 and not args.no_roofline:
-        out["roofline"] = measure_roofline(torch, lib, fwd_bwd, B, K, T, d, h, L, dff, args.dtype)
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        model.egx_defer_small = False
+        out["roofline"] = measure_roofline(torch, lib, fwd_bwd, wl, dtype)
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and wl["name"] in ("c1", "c2"):
         from oracle.stock_module import time_cpu_baseline
-        out["cpu_baseline"] = time_cpu_baseline(B=B, T=T, n_tasks=K, dim=d, n_heads=h, num_layers=L, dropout=args.dropout)
+        out["cpu_baseline"] = time_cpu_baseline(B=B, T=args.frames, n_tasks=len(wl["feats"]), dim=128, n_heads=4,
+                                                num_layers=wl["L"], dropout=0.5 if args.dropout is None else args.dropout)
     if rank == 0:
         # RCCL prints its version banner through C stdio (NCCL_DEBUG=VERSION is exported on the GPU boxes); push it out
         # first so that the JSON line is the LAST line of stdout
@@ -262,12 +420,14 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 def pmc_traffic(dtype, B, T, L, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
     WRITE_SIZE in separate runs, KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes). PMC
-    collection needs the profiler, so the number is read from profiles/ and only when it was taken on this workload."""
+    collection needs the profiler, so the number is read from profiles/ (a builder-side measurement) and only when it
+    was taken on this workload."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
     for f in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_{dtype}.json")), reverse=True):
@@ -281,53 +441,81 @@ def pmc_traffic(dtype, B, T, L, kernel):
     return None, None
 
 
-def measure_roofline(torch, lib, step, B, K, T, d, h, L, dff, dtype):
-    """Dominant kernel = fused_bwd_kernel (the per-clip backward: head, LayerNorm, attention and projection input
+TIMED_KERNELS = ("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel",
+                 "wide_gemm_kernel", "wide_attn_fwd_kernel", "wide_attn_bwd_kernel")
+
+
+def measure_roofline(torch, lib, step, wl, dtype):
+    """Roofline block of the dominant kernel of the workload. Average launch durations are measured live with hipEvents
+    recorded by the library on the launch stream (egx_timing_*), over eager launches of the same step.
+
+    Fused per-clip path (c1..c3): dominant kernel = fused_bwd_kernel (head, LayerNorm, attention and projection input
     gradients and the FFN input gradient dH = (W2^T g) .* alive, dX1 = W1^T dH). Its ALGORITHMIC FLOPs per launch are the
-    dX-type GEMMs of the backward (BASELINE.md §2 accounting; the QKV / attention-probability recompute is NOT counted):
-    L * (2N d 3d + 2N d^2 + 4N d d_ff + 8 B S^2 d). Average launch duration is measured live with hipEvents recorded on
-    the launch stream (egx_timing_*), over eager launches of the same step."""
+    dX-type GEMMs of the backward (BASELINE.md §2 accounting; the QKV / probability recompute is NOT counted):
+    L * (2N d 3d + 2N d^2 + 4N d d_ff + 8 B S^2 d).
+    Wide path (c4, c5): dominant kernel = wide_gemm_kernel; its algorithmic FLOPs are ALL dense-layer GEMMs of the step
+    (forward, dX and dW: 3 x forward GEMM FLOPs minus the feature-projection dX) summed over its launches."""
     import ctypes as C
-    S = K * T
+    B, S, d, L, segs = wl["B"], wl["S"], wl["d"], wl["L"], wl["segs"]
+    dff = 2048
     N = B * S
     ffn = L * 4.0 * N * d * dff
-    attn_fwd = K * 2.0 * B * T * 256 * d + L * (2.0 * N * d * 3 * d + 4.0 * B * S * S * d + 2.0 * N * d * d)
+    proj = sum(2.0 * B * t * k * d for t, k, pj in segs if pj)
+    attn_fwd = proj + L * (2.0 * N * d * 3 * d + 4.0 * B * S * S * d + 2.0 * N * d * d)
     flops = {
         "fused_bwd_kernel": L * (2.0 * N * d * 3 * d + 2.0 * N * d * d + 8.0 * B * S * S * d) + ffn,
         "fused_fwd_kernel": attn_fwd + ffn,
         "ffn_dw_kernel": ffn,
         "ffn_fwd_kernel": ffn,
         "ffn_bwd_kernel": ffn,
+        "wide_gemm_kernel": 3.0 * (proj + L * (2.0 * N * d * 3 * d + 2.0 * N * d * d) + ffn) - 2.0 * proj + proj,
+        "wide_attn_fwd_kernel": L * 4.0 * B * S * S * d,
+        "wide_attn_bwd_kernel": L * 8.0 * B * S * S * d,
     }
     lib.egx_timing_enable(1)
-    reps = 16
+    reps = 16 if wl["name"] in ("c1", "c2", "c3") else 4
     for _ in range(reps):
         step()
     torch.cuda.synchronize()
-    res = {}
-    for which, name in enumerate(("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel")):
+    res, tot_ms, counts = {}, {}, {}
+    for which, name in enumerate(TIMED_KERNELS):
         tot, cnt = C.c_double(0), C.c_int(0)
         if lib.egx_timing_read(which, C.byref(tot), C.byref(cnt)) == 0 and cnt.value:
             res[name] = tot.value / cnt.value * 1e-3
+            tot_ms[name], counts[name] = tot.value, cnt.value
     # split mode: the FFN halves run as their own launches; the per-clip kernels then hold only the attention halves
     if "ffn_fwd_kernel" in res:
         flops["fused_fwd_kernel"] -= ffn
     if "ffn_bwd_kernel" in res:
         flops["fused_bwd_kernel"] -= ffn
     lib.egx_timing_enable(0)
-    if "fused_bwd_kernel" not in res:   # generic path (shape outside the fused kernels)
-        return {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                "frac": None, "traffic": None}
-    t = res["fused_bwd_kernel"]
-    ach = flops["fused_bwd_kernel"] / t / 1e12
-    traffic, traffic_src = pmc_traffic(dtype, B, T, L, "egx::fused_bwd_kernel")
-    return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": PEAK_TFLOPS[dtype],
-            "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[dtype], "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": traffic_src,
-            "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
-            "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
-                                  "frac": flops[k] / v / 1e12 / PEAK_TFLOPS[dtype]} for k, v in res.items() if k != "fused_bwd_kernel"}}
+    peak = PEAK_TFLOPS[dtype]
+    if "fused_bwd_kernel" in res:
+        t = res["fused_bwd_kernel"]
+        ach = flops["fused_bwd_kernel"] / t / 1e12
+        traffic, traffic_src = pmc_traffic(dtype, B, wl["S"] // max(len(wl["feats"]), 1), L, "egx::fused_bwd_kernel")
+        return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
+                "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
+                "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
+                                      "frac": flops[k] / v / 1e12 / peak} for k, v in res.items() if k != "fused_bwd_kernel"}}
+    if "wide_gemm_kernel" in res:
+        # many launches of different shapes per step: achieved = all GEMM FLOPs of one step / all GEMM time of one step
+        t_step = tot_ms["wide_gemm_kernel"] * 1e-3 / reps
+        ach = flops["wide_gemm_kernel"] / t_step / 1e12
+        others = {}
+        for k in ("wide_attn_fwd_kernel", "wide_attn_bwd_kernel"):
+            if k in res:
+                ts = tot_ms[k] * 1e-3 / reps
+                others[k] = {"us_per_step": ts * 1e6, "launches_per_step": counts[k] / reps,
+                             "achieved_tflops": flops[k] / ts / 1e12, "frac": flops[k] / ts / 1e12 / peak}
+        return {"bound": "mfma", "kernel": "egx::wide_gemm_kernel", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None, "flops_per_step": flops["wide_gemm_kernel"],
+                "us_per_step": t_step * 1e6, "launches_per_step": counts["wide_gemm_kernel"] / reps,
+                "avg_launch_us": res["wide_gemm_kernel"] * 1e6, "other_kernels": others}
+    return {"bound": "mfma", "kernel": None, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(1024) void weighted_ce_kernel(const float* __restri
         for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += __expf(z[c] - m);
-        int y = (int)target[i];
+        const int64_t y = target[i];
+        if (y < 0 || y >= C) continue;      // ignore_index (-100) / out-of-range label: no loss, no weight, no gradient
         float wy = weight ? weight[y] : 1.f;
         sw += wy;
         sl += wy * (m + __logf(s) - z[y]);
@@ -51,9 +52,13 @@ __global__ __launch_bounds__(1024) void weighted_ce_kernel(const float* __restri
         for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += __expf(z[c] - m);
-        int y = (int)target[i];
+        const int64_t y = target[i];
+        if (y < 0 || y >= C) {
+            for (int c = 0; c < C; ++c) dlogits[(size_t)i * C + c] = 0.f;
+            continue;
+        }
         float k = (weight ? weight[y] : 1.f) * inv, rs = 1.f / s;
-        for (int c = 0; c < C; ++c) dlogits[(size_t)i * C + c] = k * (__expf(z[c] - m) * rs - (c == y ? 1.f : 0.f));
+        for (int c = 0; c < C; ++c) dlogits[(size_t)i * C + c] = k * (__expf(z[c] - m) * rs - (c == (int)y ? 1.f : 0.f));
     }
 }
 

@@ -93,22 +93,37 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None):
 
 
 @torch.no_grad()
-def allreduce_gradients_overlapped(finish_backward, group=None, average: bool = True, force: bool = False) -> int:
+def allreduce_gradients_overlapped(finish_backward, params: Iterable[torch.nn.Parameter] = None, group=None,
+                                   average: bool = True, force: bool = False) -> int:
     """Gradient exchange overlapped with the tail of the backward (BASELINE.json north_star). Use with a model whose
     `egx_defer_small` is set: its backward then stops before the grouped small weight gradients (dW_proj, dW_in, dW_o),
     which sit FIRST in the flat gradient buffer. This call starts the all-reduce of everything behind them on RCCL's
     stream, runs `finish_backward()` (functional.run_deferred, or the replay of a graph that captured it) on the compute
-    stream meanwhile, then all-reduces the late region. Returns the number of collectives issued."""
+    stream meanwhile, then all-reduces the late region, and finally every gradient of `params` that does NOT live in
+    that flat buffer (task heads run through PoolHeadFn / LinearFn, decoder parameters, a second encoder call) the way
+    allreduce_gradients does. The recorded flat buffer must be the storage of gradients of `params`: a layout left
+    behind by some other backward raises instead of silently exchanging the wrong buffer. Returns the number of
+    collectives issued."""
     from . import functional as F_egx
     lay = F_egx.last_grad_layout
     flat, late = lay.get("flat"), int(lay.get("late_floats", 0))
-    if not dist.is_available() or not dist.is_initialized() or flat is None:
+    active = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if active else 1
+    if not active or (world == 1 and not force):
         finish_backward()
         return 0
-    world = dist.get_world_size(group)
-    if world == 1 and not force:
+    params = [p for p in params if p.grad is not None] if params is not None else None
+    if flat is None:
         finish_backward()
-        return 0
+        return allreduce_gradients(params, group, average, force) if params is not None else 0
+    rest = []
+    if params is not None:
+        key = flat.untyped_storage().data_ptr()
+        inside = [p for p in params if p.grad.untyped_storage().data_ptr() == key]
+        rest = [p for p in params if p.grad.untyped_storage().data_ptr() != key]
+        if not inside:
+            raise RuntimeError("allreduce_gradients_overlapped: the recorded flat gradient buffer does not hold any gradient of "
+                               "`params` (another backward ran in between?)")
     fused_avg = average and dist.get_backend(group) == "nccl"
     op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
     early_buf, late_buf = flat[late:], flat[:late]
@@ -122,4 +137,6 @@ def allreduce_gradients_overlapped(finish_backward, group=None, average: bool = 
         work.wait()
     if average and not fused_avg:
         flat.mul_(1.0 / world)
+    if rest:
+        n += allreduce_gradients(rest, group, average, force)
     return n

@@ -485,14 +485,16 @@ class WeightedCEFn(torch.autograd.Function):
         dl = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         check(lib.egx_weighted_ce(ptr(z), ptr(tgt), ptr(w) if w is not None else None, z.shape[0], z.shape[1],
                                   ptr(loss), ptr(dl) if dl is not None else None, _stream()))
-        ctx.dl = dl
-        return loss
+        ctx.has_dl = dl is not None
+        if dl is not None:
+            ctx.save_for_backward(dl)       # autograd owns it: a second backward (retain_graph) sees the same gradient,
+        return loss                         # a backward after the buffers were freed raises as for any other op
 
     @staticmethod
     def backward(ctx, grad_out):
-        dl, ctx.dl = ctx.dl, None
-        if dl is None:
+        if not ctx.has_dl:
             return None, None, None
+        (dl,) = ctx.saved_tensors
         u = _UNIT_GRAD.get(dl.device.index)
         if u is not None and grad_out.data_ptr() == u.data_ptr():
             return dl, None, None
@@ -500,7 +502,9 @@ class WeightedCEFn(torch.autograd.Function):
 
 
 def weighted_cross_entropy(logits, target, weight=None):
-    """F.cross_entropy(logits, target, weight=weight) with mean reduction (HHI/tasks/ttm/video_task_2loader.py:21-22,34)."""
+    """F.cross_entropy(logits, target, weight=weight) with mean reduction (HHI/tasks/ttm/video_task_2loader.py:21-22,34).
+    Labels outside [0, C) - including F.cross_entropy's default ignore_index = -100 - contribute neither loss, weight nor
+    gradient."""
     return WeightedCEFn.apply(logits, target, weight)
 
 

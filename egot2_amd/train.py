@@ -30,7 +30,7 @@ class CrossEntropyLoss(nn.Module):
 
 
 class _Bucket:
-    __slots__ = ("sig", "param", "exp_avg", "exp_avg_sq", "numel")
+    __slots__ = ("sig", "param", "exp_avg", "exp_avg_sq", "numel", "members")
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -43,6 +43,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw))
         self._buckets: Dict[tuple, _Bucket] = {}
         self._step_dev: Optional[torch.Tensor] = None
+        self._resume_step = 0          # step count restored by load_state_dict before the device counter exists
 
     def _make_bucket(self, sig, base: torch.Tensor, members) -> _Bucket:
         b = _Bucket()
@@ -58,11 +59,38 @@ class FusedAdam(torch.optim.Optimizer):
                 p.data = b.param[off:off + n].view(p.shape)
         b.exp_avg = torch.zeros_like(b.param)
         b.exp_avg_sq = torch.zeros_like(b.param)
-        for p, off in members:
+        b.members = list(members)
+        self._adopt_state(b)
+        return b
+
+    def _adopt_state(self, b: _Bucket):
+        """Make self.state[p] views of the bucket's moment buffers. Moments that are already there (restored by
+        load_state_dict, or carried over from a bucket that had to be rebuilt) are copied in first, so a resumed run
+        continues from the saved exp_avg / exp_avg_sq instead of restarting them from zero."""
+        for p, off in b.members:
             n = p.numel()
+            old = self.state.get(p)
+            for key, buf in (("exp_avg", b.exp_avg), ("exp_avg_sq", b.exp_avg_sq)):
+                view = buf[off:off + n]
+                if old is not None and torch.is_tensor(old.get(key)) and old[key].numel() == n \
+                        and old[key].data_ptr() != view.data_ptr():
+                    view.copy_(old[key].reshape(-1).to(view.device, view.dtype))
             self.state[p] = {"step": self._step_dev, "exp_avg": b.exp_avg[off:off + n].view(p.shape),
                              "exp_avg_sq": b.exp_avg_sq[off:off + n].view(p.shape)}
-        return b
+
+    def load_state_dict(self, state_dict):
+        """torch's Optimizer.load_state_dict replaces self.state with fresh copies; the real moments and the step count
+        live in the bucket buffers / the device counter, so push the loaded values back into them (buckets that do not
+        exist yet pick them up in _make_bucket). Mirrors the optimizer resume of the reference's Lightning trainer
+        (`trainer.fit(ckpt_path=...)`, HOI/scripts/pnr/train.py:57)."""
+        super().load_state_dict(state_dict)
+        steps = [st["step"] for st in self.state.values() if st.get("step") is not None]
+        step = max((int(s.item()) if torch.is_tensor(s) else int(s)) for s in steps) if steps else 0
+        self._resume_step = step
+        if self._step_dev is not None:
+            self._step_dev.fill_(step)
+        for b in self._buckets.values():
+            self._adopt_state(b)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -85,7 +113,7 @@ class FusedAdam(torch.optim.Optimizer):
                 by_base.setdefault(base.data_ptr(), (base, []))[1].append((p, g.storage_offset()))
             for base, members in by_base.values():
                 if self._step_dev is None:
-                    self._step_dev = torch.zeros((), dtype=torch.int64, device=base.device)
+                    self._step_dev = torch.full((), self._resume_step, dtype=torch.int64, device=base.device)
                 if not bumped:
                     check(lib.egx_counter_add(ptr(self._step_dev), 1, stream))
                     bumped = True

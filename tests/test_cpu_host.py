@@ -195,3 +195,137 @@ def test_two_rank_overlapped_allreduce():
     i = np.arange(40, dtype=np.float32)
     assert np.allclose(flat[12:], 1.5 * i[12:])
     assert np.allclose(flat[:12], 15.0 * i[:12])
+
+
+def test_bench_self_launches_ranks_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks by itself (the round-1 script
+    silently ran one). The launcher plumbing is exercised on CPU through --launch-selftest --backend gloo: both ranks
+    join the process group (rank_sum = 1 + 2), the timing is the max over ranks, `n_gpus` and `parallelism` say 2, and
+    the JSON line is the last line of stdout."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    port = 33500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest", "--backend", "gloo",
+                        "--master-port", str(port)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["rank_sum"] == 3.0
+    assert out["max_rank_seconds"] >= 0.02          # rank 1 sleeps 20 ms: the max over ranks, not rank 0's 10 ms
+
+
+def test_bench_rejects_mismatched_world_size():
+    """--gpus N under a launcher that set a different WORLD_SIZE is an error, not a silently relabelled run."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def _ddp_weighted_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from egot2_amd import ddp
+    from oracle.stock_module import StockTTMTranslator
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    m = StockTTMTranslator(3, 128, 4, dropout=0.0, num_layers=1).train()
+    m.pos_embed.dropout.p = 0.0
+    g = torch.Generator().manual_seed(6)
+    feats = [torch.randn(8, 15, 256, generator=g) for _ in range(3)]
+    y = torch.tensor([0, 0, 0, 1, 1, 1, 1, 0])             # rank 0 holds classes {0,0,0,1}, rank 1 {1,1,1,0}: unequal weight sums
+    w = torch.tensor([0.266, 0.734])
+    sf = ddp.shard_batch(feats, rank, world)
+    sy = ddp.shard_batch([y], rank, world)[0]
+    loss = torch.nn.functional.cross_entropy(m(*sf), sy, weight=w)       # bench.py's per-rank weighted loss
+    loss.backward()
+    ddp.allreduce_gradients(list(m.parameters()))
+    wsum = w[sy].sum().item()
+    if rank == 0:
+        q.put(({k: p.grad.numpy().copy() for k, p in m.named_parameters()},
+               {k: v.numpy().copy() for k, v in m.state_dict().items()}, wsum))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_weighted_ce_normalisation_effect():
+    """SURVEY.md §8e caveat, pinned: CrossEntropyLoss(weight) divides by the sum of the target weights of the LOCAL batch,
+    so averaging per-rank gradients (what DDP and bench.py do, as the reference silently does) equals the single-process
+    gradient of  0.5 * (L_0 + L_1)  with each L_r normalised by its own rank's weight sum - NOT the gradient of the
+    weighted CE over the concatenated batch unless both ranks hold the same class mix."""
+    import torch.multiprocessing as mp
+    from oracle.stock_module import StockTTMTranslator
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_weighted_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    grads, sd, wsum0 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = StockTTMTranslator(3, 128, 4, dropout=0.0, num_layers=1).train()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.pos_embed.dropout.p = 0.0
+    g = torch.Generator().manual_seed(6)
+    feats = [torch.randn(8, 15, 256, generator=g) for _ in range(3)]
+    y = torch.tensor([0, 0, 0, 1, 1, 1, 1, 0])
+    w = torch.tensor([0.266, 0.734])
+    ce = torch.nn.functional.cross_entropy
+    # (a) what the exchange computes: the mean of the two per-rank weighted losses
+    out = m(*feats)
+    (0.5 * (ce(out[:4], y[:4], weight=w) + ce(out[4:], y[4:], weight=w))).backward()
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, torch.from_numpy(grads[k]), rtol=1e-4, atol=1e-6), k
+    # (b) the concatenated-batch weighted CE differs, by exactly the per-rank weight-sum ratio
+    assert abs(wsum0 - (3 * 0.266 + 0.734)) < 1e-6
+    m.zero_grad()
+    ce(m(*feats), y, weight=w).backward()
+    gk = "linear_head.1.bias"
+    assert not torch.allclose(m.get_parameter(gk).grad, torch.from_numpy(grads[gk]), rtol=1e-3, atol=1e-7)
+
+
+def test_overlapped_allreduce_also_exchanges_gradients_outside_the_flat_buffer():
+    """allreduce_gradients_overlapped used to reduce only the recorded flat buffer. With `params` it must
+    also exchange gradients living elsewhere (heads, decoder) and refuse a flat buffer that belongs to other params."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_overlap_params_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, a, b, raised = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert n == 3 and raised           # early + late regions of the flat buffer, then one coalesced loose buffer
+    assert np.allclose(a, 1.5 * np.arange(8)) and np.allclose(b, 1.5 * np.ones(5))
+
+
+def _overlap_params_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from egot2_amd import ddp, functional as F_egx
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(8, dtype=torch.float32) * (rank + 1)
+    pa = torch.nn.Parameter(torch.zeros(8))
+    pa.grad = flat[0:8].view(8)
+    pb = torch.nn.Parameter(torch.zeros(5))
+    pb.grad = torch.ones(5) * (rank + 1)                # lives outside the flat buffer (a head / decoder parameter)
+    F_egx.last_grad_layout.clear()
+    F_egx.last_grad_layout.update(flat=flat, late_floats=4)
+    n = ddp.allreduce_gradients_overlapped(lambda: None, [pa, pb])
+    raised = False
+    F_egx.last_grad_layout.update(flat=torch.zeros(4), late_floats=0)      # a buffer none of the params' grads live in
+    try:
+        ddp.allreduce_gradients_overlapped(lambda: None, [pa, pb])
+    except RuntimeError:
+        raised = True
+    if rank == 0:
+        q.put((n, pa.grad.numpy().copy(), pb.grad.numpy().copy(), raised))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,13 +1,8 @@
 """Shared helpers for the parity tests."""
-from argparse import Namespace
+from egot2_amd.synth import hhi_args  # noqa: F401  (re-exported for the tests)
 
 import numpy as np
 import torch
-
-
-def hhi_args(hidden_dim=128, num_heads=4, dropout=0.0, num_layers=1):
-    return Namespace(lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None, nofreeze=True,
-                     hidden_dim=hidden_dim, num_heads=num_heads, dropout=dropout, num_layers=num_layers, hidden_dim2=512)
 
 
 def seeded_feats(seed, shapes):

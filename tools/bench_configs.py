@@ -11,7 +11,7 @@ from types import SimpleNamespace as NS
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from tests.util import hhi_args  # noqa: E402
+from egot2_amd.synth import hhi_args  # noqa: E402
 
 
 def flops(B, segs, d, dff, L, proj):

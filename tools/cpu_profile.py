@@ -3,7 +3,7 @@ import cProfile, pstats, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from egot2_amd import hhi_ttm
-from tests.util import hhi_args
+from egot2_amd.synth import hhi_args
 dev = torch.device("cuda:0")
 m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5)).to(dev).set_compute("bf16").train()
 feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]

@@ -3,7 +3,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from egot2_amd import hhi_ttm, _lib
-from tests.util import hhi_args
+from egot2_amd.synth import hhi_args
 lib = _lib.load()
 dev = torch.device("cuda:0")
 names = ["load+LN2bwd", "colsum+LN1fwd", "FFN dX", "xwave-sum", "LN1bwd", "colsum+outproj", "x_in", "QKV", "attn", "inb+inproj", "tokprep"]
