@@ -10,10 +10,10 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 4
+EGX_ABI_VERSION = 5
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16 = 0, 1
-EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED = 0, 1, 2
+EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
 
 _fp = C.c_void_p  # all device pointers travel as raw addresses
 
@@ -61,6 +61,11 @@ SIGNATURES = {
     "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "egx_encoder_uses_fused": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
+    "egx_encoder_impl": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
+    "egx_wide_gemm_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "egx_wide_gemm": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
+    "egx_wide_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_wide_attention_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
     "egx_encoder_fwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
                                   _fp, _fp, _fp, C.c_int, C.c_uint64, _fp]),
     "egx_encoder_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,

@@ -9,6 +9,8 @@
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
+#include "wide.h"
+#include "wide_host.h"
 
 namespace egx {
 
@@ -207,6 +209,17 @@ static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan
     return cfg->impl == EGX_IMPL_AUTO && ok;   // auto: fused per-clip kernels whenever the shape allows
 }
 
+// wide bf16 path (wide_host.hip): bf16 compute outside the fused kernels' shape, whenever its alignment rules hold
+static bool use_wide(const egx_config* cfg, const egx_segment* segs, const Plan& pl, bool* err) {
+    *err = false;
+    const bool ok = wide_ok(cfg, segs, pl.B);
+    if (cfg->impl == EGX_IMPL_WIDE) {
+        if (!ok) { set_error("wide implementation does not support this configuration (needs compute = bf16, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128)"); *err = true; }
+        return ok;
+    }
+    return cfg->impl == EGX_IMPL_AUTO && ok && !fused_ok(cfg, segs, pl);
+}
+
 static inline float* fptr(void* base, size_t off) { return (float*)((char*)base + off); }
 static inline const float* cfptr(const void* base, size_t off) { return (const float*)((const char*)base + off); }
 
@@ -301,11 +314,45 @@ int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1
 }
 const char* egx_last_error(void) { return g_err; }
 
+// ---- unit hooks of the wide bf16 path ----------------------------------------------------------------------------
+size_t egx_wide_gemm_scratch(int layout, int M, int N, int K) { return 1024 + (layout == 2 ? wide_gemm_tn_scratch(M, N, K) : 0); }
+int egx_wide_gemm(int layout, const void* A, const void* B, float* Cf, void* Cb, int M, int N, int K, const float* bias,
+                  int relu, const float* residual, void* scratch, void* stream) {
+    EGX_CHECK(layout == 0 || layout == 2, "egx_wide_gemm: layout %d (0 = NT, 2 = TN)", layout);
+    EGX_CHECK(scratch, "egx_wide_gemm: null scratch");
+    hipStream_t st = (hipStream_t)stream;
+    EGX_HIP(hipMemsetAsync(scratch, 0, 1024, st));
+    WideGemmParams g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.M = M; g.N = N; g.K = K;
+    g.Cf = Cf; g.Cb = (bf16_t*)Cb; g.ldc = N; g.bias = bias; g.relu = relu; g.residual = residual; g.ldr = N;
+    g.zero_page = scratch;
+    if (layout == 0) { g.lda = K; g.ldb = K; return wide_gemm_nt(g, st); }
+    g.lda = M; g.ldb = N;
+    return wide_gemm_tn(g, (char*)scratch + 1024, st);
+}
+static int wide_attn_hook(const void* qkv, void* out, float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
+                          float p_drop, uint64_t seed, void* stream, bool bwd) {
+    WideAttnParams a;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.lse = lse; a.d_out = (const bf16_t*)d_out; a.d_qkv = (bf16_t*)d_qkv;
+    a.B = B; a.S = S; a.H = H; a.d = d;
+    if (p_drop > 0.f) { a.drop_key = site_key(seed, 0, SITE_ATTN); a.drop_thresh = drop_threshold(p_drop); a.drop_inv = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f; }
+    return bwd ? wide_attn_bwd(a, (hipStream_t)stream) : wide_attn_fwd(a, (hipStream_t)stream);
+}
+int egx_wide_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int d, float p_drop, uint64_t seed, void* stream) {
+    return wide_attn_hook(qkv, out, lse, nullptr, nullptr, B, S, H, d, p_drop, seed, stream, false);
+}
+int egx_wide_attention_bwd(const void* qkv, const float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
+                           float p_drop, uint64_t seed, void* stream) {
+    return wide_attn_hook(qkv, nullptr, const_cast<float*>(lse), d_out, d_qkv, B, S, H, d, p_drop, seed, stream, true);
+}
+
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
-    if (saved_bytes) *saved_bytes = size_max(pl.saved_bytes, fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = size_max(pl.scratch_bytes, fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
+    size_t wsv = 0, wsc = 0;
+    if (wide_ok(cfg, segs, B)) wide_workspace(cfg, segs, B, &wsv, &wsc);
+    if (saved_bytes) *saved_bytes = size_max(size_max(pl.saved_bytes, wsv), fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
+    if (scratch_bytes) *scratch_bytes = size_max(size_max(pl.scratch_bytes, wsc), fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
     return 0;
 }
 
@@ -314,6 +361,17 @@ int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B
     if (make_plan(cfg, segs, B, pl)) return 0;
     bool ferr;
     return use_fused(cfg, segs, pl, &ferr) ? 1 : 0;
+}
+
+int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B) {
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return -1;
+    bool ferr;
+    if (use_fused(cfg, segs, pl, &ferr)) return EGX_IMPL_FUSED;
+    if (ferr) return -1;
+    if (use_wide(cfg, segs, pl, &ferr)) return EGX_IMPL_WIDE;
+    if (ferr) return -1;
+    return EGX_IMPL_GENERIC;
 }
 
 }  // extern "C"
@@ -394,6 +452,25 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         return fused_forward(fp, comp, st);
     }
     if (ferr) return 1;
+    {
+        bool werr;
+        if (use_wide(cfg, segs, pl, &werr)) {
+            size_t wsv = 0, wsc = 0;
+            wide_workspace(cfg, segs, B, &wsv, &wsc);
+            float* tk = tokens_out;
+            float* pooled = nullptr;
+            if (with_head) {        // tokens and the pooled vector live behind the wide path's saved block
+                float* extra = fptr(saved, align_up(wsv, 256));
+                pooled = extra + (size_t)N * d;
+                if (!tk) tk = extra;
+            }
+            if (wide_encoder_fwd(cfg, segs, ln_w, ln_b, layers, B, tk, saved, training, seed, st)) return 1;
+            if (with_head)
+                return pool_head_fwd(tk, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, pooled, logits_out, st);
+            return 0;
+        }
+        if (werr) return 1;
+    }
     EGX_CHECK(!(cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)),
               "device-resident dropout seed (seed_ptr) is only supported by the fused kernels");
 
@@ -598,6 +675,32 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         }
         if (ferr) return 1;
     }
+    {
+        bool werr;
+        if (use_wide(cfg, segs, pl, &werr)) {
+            EGX_CHECK(layers && layer_grads, "null layers / layer_grads");
+            if (cfg->bwd_stage == 2) return 0;      // no deferred part
+            hipStream_t st = (hipStream_t)stream;
+            size_t wsv = 0, wsc = 0;
+            wide_workspace(cfg, segs, B, &wsv, &wsc);
+            const float* dtok = d_tokens;
+            bool zeroed = false;
+            if (with_head) {
+                const float* extra = cfptr(saved, align_up(wsv, 256));
+                const float* pooled = extra + (size_t)pl.N * pl.d;
+                float* dt = fptr(scratch, align_up(wsc, 256));
+                if (cfg->zero_buf && cfg->zero_bytes) { EGX_HIP(hipMemsetAsync(cfg->zero_buf, 0, cfg->zero_bytes, st)); zeroed = true; }
+                if (pool_head_bwd(d_logits, pooled, B, pl.S, pl.d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->n_out, dt,
+                                  head_grads ? head_grads->ln_w : nullptr, head_grads ? head_grads->ln_b : nullptr,
+                                  head_grads ? head_grads->W : nullptr, head_grads ? head_grads->b : nullptr, st)) return 1;
+                dtok = dt;
+            }
+            egx_config c2 = *cfg;
+            if (zeroed) { c2.zero_buf = nullptr; c2.zero_bytes = 0; }
+            return wide_encoder_bwd(&c2, segs, ln_w, layers, B, dtok, saved, scratch, seg_grads, d_ln_w, d_ln_b, layer_grads, training, seed, st);
+        }
+        if (werr) return 1;
+    }
     EGX_CHECK(pl.L == 0 || (layers && layer_grads), "null layers / layer_grads");
     if (cfg->bwd_stage == 2) return 0;      // the generic path has no deferred part
     hipStream_t st = (hipStream_t)stream;
@@ -725,8 +828,10 @@ int egx_translator_workspace(const egx_config* cfg, const egx_segment* segs, int
     size_t sv = 0, sc = 0;
     if (egx_encoder_workspace(cfg, segs, B, &sv, &sc)) return 1;
     // generic path extras: tokens + pooled behind `saved`, d_tokens behind `scratch`
-    size_t extra_sv = align_up(pl.saved_bytes, 256) + (pl.N + (size_t)B) * pl.d * 4 + 256;
-    size_t extra_sc = align_up(pl.scratch_bytes, 256) + pl.N * pl.d * 4 + 256;
+    size_t wsv = 0, wsc = 0;
+    if (wide_ok(cfg, segs, B)) wide_workspace(cfg, segs, B, &wsv, &wsc);
+    size_t extra_sv = align_up(size_max(pl.saved_bytes, wsv), 256) + (pl.N + (size_t)B) * pl.d * 4 + 256;
+    size_t extra_sc = align_up(size_max(pl.scratch_bytes, wsc), 256) + pl.N * pl.d * 4 + 256;
     if (saved_bytes) *saved_bytes = size_max(sv, extra_sv);
     if (scratch_bytes) *scratch_bytes = size_max(sc, extra_sc);
     return 0;

@@ -158,7 +158,8 @@ struct ReducePartialsParams {
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st);
 
 // Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.
-enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_COUNT = 3 };
+enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_FFN_FWD = 3, TIMER_FFN_BWD = 4, TIMER_WIDE_GEMM = 5,
+       TIMER_WIDE_ATTN_FWD = 6, TIMER_WIDE_ATTN_BWD = 7, TIMER_COUNT = 8 };
 void timing_enable(int on);
 void timing_begin(int which, hipStream_t st);
 void timing_end(int which, hipStream_t st);

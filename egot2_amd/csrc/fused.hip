@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "fused.h"
 #include "fused_dev.h"
+#include <vector>
 
 namespace egx {
 
@@ -619,9 +620,11 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
 // ---- optional device timing ----------------------------------------------------------------------------
 namespace {
-struct TimerSlot { hipEvent_t a[64], b[64]; int n = 0; bool made = false; };
+// events are created on demand: a wide-path step records a few hundred GEMM launches per timer
+struct TimerSlot { std::vector<hipEvent_t> a, b; int n = 0; };
 TimerSlot g_timers[TIMER_COUNT];
 int g_timing_on = 0;
+constexpr int TIMER_MAX_EVENTS = 4096;
 }
 void timing_enable(int on) {
     g_timing_on = on;
@@ -630,13 +633,18 @@ void timing_enable(int on) {
 void timing_begin(int which, hipStream_t st) {
     if (!g_timing_on) return;
     TimerSlot& t = g_timers[which];
-    if (!t.made) { for (int i = 0; i < 64; ++i) { (void)hipEventCreate(&t.a[i]); (void)hipEventCreate(&t.b[i]); } t.made = true; }
-    if (t.n < 64) (void)hipEventRecord(t.a[t.n], st);
+    if (t.n >= TIMER_MAX_EVENTS) return;
+    if ((int)t.a.size() <= t.n) {
+        hipEvent_t ea, eb;
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        t.a.push_back(ea); t.b.push_back(eb);
+    }
+    (void)hipEventRecord(t.a[t.n], st);
 }
 void timing_end(int which, hipStream_t st) {
     if (!g_timing_on) return;
     TimerSlot& t = g_timers[which];
-    if (t.n < 64) { (void)hipEventRecord(t.b[t.n], st); ++t.n; }
+    if (t.n < (int)t.a.size() && t.n < TIMER_MAX_EVENTS) { (void)hipEventRecord(t.b[t.n], st); ++t.n; }
 }
 int timing_read(int which, double* total_ms, int* count) {
     if (which < 0 || which >= TIMER_COUNT) return 1;

@@ -1,0 +1,83 @@
+// "Wide" bf16 path of the translator: d_model >= 256 configurations (BASELINE.json configs[3] HOI LTA 4-task d = 768,
+// configs[4] EgoT2-g encoders d = 256 / 512) where the dense layers are large GEMMs over all B*S tokens.
+//
+// Storage: GEMM operands (layer inputs, qkv, attention output, FFN hidden, upstream gradients) live in HBM as bf16;
+// the residual stream, LayerNorm inputs and statistics, biases and all parameter gradients stay fp32. Weights are cast
+// to bf16 once per forward (W for the forward, W^T for the input gradients).
+#pragma once
+#include "common.h"
+
+namespace egx {
+
+typedef unsigned short bf16_t;
+
+struct WideGemmParams {
+    // NT:  C[m][n] = sum_k A[m][k] * B[n][k]      A: activations (M, lda), B: weights (N, ldb), both k-contiguous
+    // TN:  C[m][n] = sum_k A[k][m] * B[k][n]      A: (K, lda) upstream gradient dY, B: (K, ldb) layer input (K = tokens)
+    const bf16_t* A = nullptr; const bf16_t* B = nullptr;
+    int M = 0, N = 0, K = 0, lda = 0, ldb = 0;
+    float* Cf = nullptr; bf16_t* Cb = nullptr; int ldc = 0;      // fp32 and / or bf16 output
+    const float* bias = nullptr;                                 // [N]
+    int relu = 0;
+    uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;   // inverted dropout keyed by (m, n)
+    const float* residual = nullptr; int ldr = 0;                // fp32 (M, ldr), added last
+    const bf16_t* mask = nullptr; int ldm = 0; float mask_scale = 1.f;       // C = mask[m][n] != 0 ? C * mask_scale : 0
+    float* colsum = nullptr;      // optional [ceil(M / 128)][N]: per row-tile column sums of the stored value (bias gradients)
+    int accumulate = 0;           // TN: C += result (parameter gradients)
+    const void* zero_page = nullptr;   // >= 256 zero bytes in device memory (source of out-of-range operand rows)
+};
+
+// scratch for the TN split-K slabs
+size_t wide_gemm_tn_scratch(int M, int N, int K);
+int wide_gemm_nt(const WideGemmParams& p, hipStream_t st);
+int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st);
+
+// dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32
+int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st);
+
+// Row kernels with bf16 side outputs --------------------------------------------------------------------------------
+// y[orow] = dropout(LN(x[row]) * w + b + add_vec + pos[t]); y32 and / or y16 written; stats (mean, rstd) saved.
+struct WideLnFwdParams {
+    const float* x = nullptr; const float* w = nullptr; const float* b = nullptr; float eps = 1e-5f;
+    float* stats = nullptr; float* y32 = nullptr; bf16_t* y16 = nullptr;
+    int rows = 0, d = 0, T = 1, S = 1, off = 0;
+    const float* add_vec = nullptr; const float* pos = nullptr; int pos_stride = 0;
+    uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;
+};
+int wide_ln_fwd(const WideLnFwdParams& p, hipStream_t st);
+
+// dx[row] = LN backward of (mask .* dy[orow]); dx32 = d(pre-LN sum) fp32; dx16 = out-mask .* dx as bf16 (the upstream
+// gradient of the GEMM that produced the branch; out-mask = the dropout applied to that branch in the forward, keyed by
+// (row, col)). Per-block partial sums of d(gamma), d(beta) [and of dx16's columns = the branch's bias gradient] go to
+// `partials` ([blocks][3][d]) and are reduced in fixed order by wide_reduce_partials (deterministic).
+struct WideLnBwdParams {
+    const float* dy = nullptr; const float* pre = nullptr; const float* stats = nullptr; const float* w = nullptr;
+    float* dx32 = nullptr; bf16_t* dx16 = nullptr;
+    int rows = 0, d = 0, T = 1, S = 1, off = 0;
+    uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;           // mask on dy (dropout after LN)
+    uint64_t out_key = 0; uint32_t out_thresh = 0; float out_inv = 1.f;              // mask on dx16 / dx32_masked
+    int mask_dx32 = 0;            // 1: dx32 also gets the out-mask (feature dropout before the shared LN)
+    float* partials = nullptr; int blocks = 0;   // set by wide_ln_bwd
+    float* dw = nullptr; float* db = nullptr; float* dbias = nullptr; float* dadd = nullptr;   // += targets (any may be null)
+};
+size_t wide_ln_bwd_scratch(int rows, int d);
+int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st);
+
+// out[c] += sum_r x[r][c] over a bf16 (rows, ld) matrix, deterministic two-stage reduction; scratch >= wide_colsum_scratch
+size_t wide_colsum_scratch(int rows, int cols);
+int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st);
+// out[c] += sum_t part[t][c], t < nt (fixed order)
+int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st);
+
+// Attention over packed bf16 qkv rows (B*S, 3d): out (B*S, d) bf16, lse (B, H, S) fp32. S <= 128, head dim in {32, 64, 96, 128}.
+struct WideAttnParams {
+    const bf16_t* qkv = nullptr; bf16_t* out = nullptr; float* lse = nullptr;
+    const bf16_t* d_out = nullptr; bf16_t* d_qkv = nullptr;
+    int B = 0, S = 0, H = 0, d = 0;
+    uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;
+};
+bool wide_attn_supported(int S, int dh);
+int wide_attn_fwd(const WideAttnParams& p, hipStream_t st);
+int wide_attn_bwd(const WideAttnParams& p, hipStream_t st);
+
+}  // namespace egx

@@ -13,10 +13,10 @@ import torch
 
 from . import _lib
 from ._lib import (Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
-                   EGX_F32, EGX_BF16, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED)
+                   EGX_F32, EGX_BF16, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE)
 
 COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16}
-IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED}
+IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED, "wide": EGX_IMPL_WIDE}
 
 
 @dataclass

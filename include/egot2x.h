@@ -45,11 +45,11 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 4
+#define EGX_ABI_VERSION 5
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
-enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2 };
+enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2, EGX_IMPL_WIDE = 3 };
 
 /* One contiguous run of tokens of the packed sequence, produced from one frozen-backbone feature
  * tensor: tokens[b, off + t, :] = LN(feat[b, t, :] @ proj_w^T + proj_b) + add_vec + pos[t * pos_stride + :]
@@ -143,6 +143,11 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
 /* 1 when this configuration runs on the fused per-clip kernels (which leave d_tokens untouched in backward),
  * 0 for the shape-generic kernels (which consume d_tokens). */
 int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B);
+/* Which kernels this configuration runs on: EGX_IMPL_FUSED (per-clip kernels: d = 128, h = 4, S <= 48), EGX_IMPL_WIDE
+ * (compute = bf16 with d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128: all B*S tokens
+ * through bf16-storage MFMA GEMMs and MFMA attention - BASELINE.json configs[3], configs[4]) or EGX_IMPL_GENERIC; -1 on an
+ * invalid configuration. */
+int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B);
 
 /* tokens_out: (B, S, d). `saved` is written in forward and read in backward.
  * training != 0 applies dropout with masks derived from (seed, site, element). */
@@ -218,6 +223,20 @@ int egx_attention_fwd(const float* qkv, float* out, float* lse, int B, int S, in
 int egx_attention_bwd(const float* qkv, const float* out, const float* lse, const float* d_out,
                       float* d_qkv, int B, int S, int H, int d,
                       float p_drop, uint64_t seed, void* stream);
+
+/* --- unit hooks of the wide bf16 path (operands are bf16 in device memory, passed as void*) ---
+ * layout 0 (NT): C[M,N] = A[M,K] B[N,K]^T (+ bias) (ReLU) (+ residual[M,N] fp32): the nn.Linear forward / input gradient.
+ * layout 2 (TN): C[M,N] = A[K,M]^T B[K,N]: the nn.Linear weight gradient over K = B*S tokens (M, N multiples of 128).
+ * Cf (fp32) and / or Cb (bf16) receive the result (TN: Cf only). K %% 64 == 0 for NT. scratch: egx_wide_gemm_scratch() bytes. */
+size_t egx_wide_gemm_scratch(int layout, int M, int N, int K);
+int egx_wide_gemm(int layout, const void* A, const void* B, float* Cf, void* Cb, int M, int N, int K, const float* bias,
+                  int relu, const float* residual, void* scratch, void* stream);
+/* qkv: (B*S, 3d) packed bf16 in-projection rows; out: (B*S, d) bf16; lse: (B, H, S) fp32. S <= 128, head dim 32/64/96/128.
+ * Backward: d_out (B*S, d) bf16 -> d_qkv (B*S, 3d) bf16 (probabilities recomputed from lse; every element written once). */
+int egx_wide_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int d, float p_drop, uint64_t seed,
+                           void* stream);
+int egx_wide_attention_bwd(const void* qkv, const float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
+                           float p_drop, uint64_t seed, void* stream);
 
 /* Fused FFN weight gradients (d_model = 128): dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H where
  * H = dropout(relu(x1 W1^T + b1)) and dH = (g W2) .* mask are recomputed on chip. x1, g: (N, 128); S = tokens per
