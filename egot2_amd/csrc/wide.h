@@ -22,7 +22,7 @@ struct WideGemmParams {
     uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;   // inverted dropout keyed by (m, n)
     const float* residual = nullptr; int ldr = 0;                // fp32 (M, ldr), added last
     const bf16_t* mask = nullptr; int ldm = 0; float mask_scale = 1.f;       // C = mask[m][n] != 0 ? C * mask_scale : 0
-    float* colsum = nullptr;      // optional [ceil(M / 128)][N]: per row-tile column sums of the stored value (bias gradients)
+    float* colsum = nullptr;      // optional [wide_gemm_nt_colsum_rows(M, N)][N]: column sums per 64 output rows (bias gradients)
     int accumulate = 0;           // TN: C += result (parameter gradients)
     const void* zero_page = nullptr;   // >= 256 zero bytes in device memory (source of out-of-range operand rows)
 };
@@ -30,6 +30,7 @@ struct WideGemmParams {
 // scratch for the TN split-K slabs
 size_t wide_gemm_tn_scratch(int M, int N, int K);
 int wide_gemm_nt(const WideGemmParams& p, hipStream_t st);
+int wide_gemm_nt_colsum_rows(int M, int N);     // rows of WideGemmParams::colsum written for an (M, N) output
 int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st);
 
 // dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32
@@ -68,6 +69,11 @@ size_t wide_colsum_scratch(int rows, int cols);
 int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st);
 // out[c] += sum_t part[t][c], t < nt (fixed order)
 int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st);
+
+// dpos[t * pos_stride + c] += sum_b mask .* dtok[(b * S + off + t) * d + c] (learned positional table), fixed-order chunk sums
+size_t wide_pos_grad_scratch(int B, int T, int d);
+int wide_pos_grad(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride, uint64_t key, uint32_t thresh,
+                  float inv, void* scratch, hipStream_t st);
 
 // Attention over packed bf16 qkv rows (B*S, 3d): out (B*S, d) bf16, lse (B, H, S) fp32. S <= 128, head dim in {32, 64, 96, 128}.
 struct WideAttnParams {

@@ -41,15 +41,29 @@ __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f3
 }
 
 // copy `rows` token rows of one head (dh bf16 each, global row stride ld elements) into an LDS image with row stride RS
-// bytes; rows [rows, SP) are zero-filled
-template <int DH>
-__device__ __forceinline__ void load_image(unsigned char* img, const bf16_t* src, int ld, int rows, int SP) {
-    constexpr int RS = DH * 2 + 32, CH = DH / 8;      // 16-byte chunks per row
-    for (int i = threadIdx.x; i < SP * CH; i += 256) {
-        int row = i / CH, c = i % CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < rows) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
-        *reinterpret_cast<uint4*>(img + row * RS + c * 16) = v;
+// bytes; rows [rows, SP) are zero-filled. All of a thread's loads are issued before its first LDS store (one exposed
+// memory latency per image set instead of one per 16-byte chunk).
+template <int DH, int SP>
+struct ImageRegs { uint4 v[(SP * (DH / 8) + 255) / 256]; };
+template <int DH, int SP>
+__device__ __forceinline__ void image_fetch(ImageRegs<DH, SP>& R, const bf16_t* src, int ld, int rows) {
+    constexpr int CH = DH / 8, NIT = (SP * CH + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int row = i / CH, c = i % CH;
+        R.v[it] = make_uint4(0, 0, 0, 0);
+        if (i < SP * CH && row < rows) R.v[it] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
+    }
+}
+template <int DH, int SP>
+__device__ __forceinline__ void image_store(const ImageRegs<DH, SP>& R, unsigned char* img) {
+    constexpr int RS = DH * 2 + 32, CH = DH / 8, NIT = (SP * CH + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int row = i / CH, c = i % CH;
+        if (i < SP * CH) *reinterpret_cast<uint4*>(img + row * RS + c * 16) = R.v[it];
     }
 }
 
@@ -66,8 +80,13 @@ __global__ __launch_bounds__(256) void wide_attn_fwd_kernel(WideAttnParams p) {
     const int S = p.S, d = p.d, ld = 3 * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (size_t)b * S * ld + h * DH;
-    load_image<DH>(Kimg, base + d, ld, S, SP);
-    load_image<DH>(Vimg, base + 2 * d, ld, S, SP);
+    {
+        ImageRegs<DH, SP> rk, rv;
+        image_fetch<DH, SP>(rk, base + d, ld, S);
+        image_fetch<DH, SP>(rv, base + 2 * d, ld, S);
+        image_store<DH, SP>(rk, Kimg);
+        image_store<DH, SP>(rv, Vimg);
+    }
     __syncthreads();
     const float scale = rsqrtf((float)DH);
     const int nqt = (S + 15) / 16;
@@ -148,10 +167,17 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
     const int S = p.S, d = p.d, ld = 3 * d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (size_t)b * S * ld + h * DH;
-    load_image<DH>(Qimg, base, ld, S, SP);
-    load_image<DH>(Kimg, base + d, ld, S, SP);
-    load_image<DH>(Vimg, base + 2 * d, ld, S, SP);
-    load_image<DH>(Dimg, p.d_out + (size_t)b * S * d + h * DH, d, S, SP);
+    {
+        ImageRegs<DH, SP> rq, rk, rv, rd;
+        image_fetch<DH, SP>(rq, base, ld, S);
+        image_fetch<DH, SP>(rk, base + d, ld, S);
+        image_fetch<DH, SP>(rv, base + 2 * d, ld, S);
+        image_fetch<DH, SP>(rd, p.d_out + (size_t)b * S * d + h * DH, d, S);
+        image_store<DH, SP>(rq, Qimg);
+        image_store<DH, SP>(rk, Kimg);
+        image_store<DH, SP>(rv, Vimg);
+        image_store<DH, SP>(rd, Dimg);
+    }
     for (int i = threadIdx.x; i < SP; i += 256) lse_s[i] = i < S ? p.lse[(size_t)bh * S + i] : 0.f;
     __syncthreads();
     const float scale = rsqrtf((float)DH);

@@ -21,13 +21,19 @@
 #include "common.h"
 #include "wide.h"
 #include "fused.h"
+#include <stdlib.h>
 
 namespace egx {
 
 namespace {
 
-constexpr int TBM = 128, TBN = 128, TBK = 64;
-constexpr int STAGE_BYTES = (TBM + TBN) * TBK * 2;     // 32 KB
+constexpr int TBM = 128, TBN = 128, TBK = 64;        // TBM: rows per 2x2-wave unit; the big variant stacks two units (256 rows)
+constexpr int STAGE_BYTES = (TBM + TBN) * TBK * 2;     // 32 KB (BM = 128); 48 KB for BM = 256
+
+#define EGX_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// workgroup barrier that does NOT drain the vector-memory counter (LDS-DMA stays in flight across it); LDS reads of the
+// previous phase are retired first
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -55,40 +61,49 @@ __device__ __forceinline__ int xcd_tile(int id, int total) {
 }  // namespace
 
 // ---- NT ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wide_gemm_nt_kernel(WideGemmParams p, int ntM, int ntN) {
+// BM x 128 output tile, BM / 64 x 2 waves. D LDS stages form a ring: stage kt + D - 1 is issued while stage kt is consumed,
+// a counted s_waitcnt leaves the newer stages in flight across the barrier (the L2 / HBM latency of a tile is several times
+// the 32 MFMAs a wave runs per K step, so a single prefetched stage leaves the matrix pipe waiting).
+template <int BM, int D>
+__global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams p, int ntM, int ntN) {
+    constexpr int NW = BM / 32;                      // waves
+    constexpr int WM = BM / 64;                      // waves along m
+    constexpr int SB = (BM + TBN) * TBK * 2;         // stage bytes
+    constexpr int NB = TBN / 8 / NW;                 // B-tile staging instructions per wave (8 rows each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, ntM * ntN);
-    const int m0 = (t / ntN) * TBM, n0 = (t % ntN) * TBN;
+    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * TBN;
 
-    // staging: wave w copies rows [32w, 32w + 32) of both operand tiles, 8 rows (1 KiB) per instruction
+    // staging: wave w copies rows [32w, 32w + 32) of the X tile and [8 NB w, + 8 NB) of the W tile, 8 rows (1 KiB) per instruction
     const int srow = lane >> 3;                       // row within the 8-row group == (row & 7)
     const int lch = (lane & 7) ^ srow;                // logical 16-byte chunk this lane fetches
     const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    const bf16_t* srcB[NB];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        int row = (wave * 4 + j) * 8 + srow;
-        int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-        int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+        int gm = m0 + (wave * 4 + j) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
         srcA[j] = p.A + (size_t)gm * p.lda + lch * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int gn = n0 + (wave * NB + j) * 8 + srow; gn = gn < p.N ? gn : p.N - 1;
         srcB[j] = p.B + (size_t)gn * p.ldb + lch * 8;
     }
     auto stage = [&](int kt, int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 4096;
-        unsigned char* sb = sa + TBM * TBK * 2;
+        unsigned char* sa = smem + buf * SB + wave * 4096;
+        unsigned char* sb = smem + buf * SB + BM * TBK * 2 + wave * NB * 1024;
         const int k0 = kt * TBK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(srcA[j] + k0, sa + j * 1024);
-            glds16(srcB[j] + k0, sb + j * 1024);
-        }
+        for (int j = 0; j < 4; ++j) glds16(srcA[j] + k0, sa + j * 1024);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) glds16(srcB[j] + k0, sb + j * 1024);
     };
 
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     // fragment byte offsets inside a stage: rows of X (m) / W (n); chunk (s * 4 + g) ^ (row & 7), row & 7 == r & 7
-    const int offX = (wm * 64 + r) * 128, offW = TBM * TBK * 2 + (wn * 64 + r) * 128;
+    const int offX = (wm * 64 + r) * 128, offW = BM * TBK * 2 + (wn * 64 + r) * 128;
     const int c0 = ((0 * 4 + g) ^ (r & 7)) * 16, c1 = ((1 * 4 + g) ^ (r & 7)) * 16;
 
     f32x4 acc[4][4];
@@ -98,12 +113,20 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_nt_kernel(WideGemmParams p, 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     const int nk = p.K / TBK;
-    stage(0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < D - 1; ++s0)
+        if (s0 < nk) stage(s0, s0);
+    int buf = 0, nbuf = D - 1;                       // buffer of stage kt / of stage kt + D - 1
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
+        // stage kt must have landed; the (up to D - 2) stages issued after it may stay in flight
+        if (D >= 4 && kt + 2 < nk) { if (NB == 4) EGX_WAIT_VM(16); else EGX_WAIT_VM(12); }
+        else if (D >= 3 && kt + 1 < nk) { if (NB == 4) EGX_WAIT_VM(8); else EGX_WAIT_VM(6); }
+        else EGX_WAIT_VM(0);
+        ring_barrier();
+        if (kt + D - 1 < nk) stage(kt + D - 1, nbuf);
+        const unsigned char* st = smem + buf * SB;
+        buf = buf + 1 == D ? 0 : buf + 1;
+        nbuf = nbuf + 1 == D ? 0 : nbuf + 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int cs = s ? c1 : c0;
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_nt_kernel(WideGemmParams p, 
             }
         }
     }
-    if (p.colsum) {      // one partial row per (row tile, wave row half): [ntM * 2][N]
+    if (p.colsum) {      // one partial row per 64 output rows: [ceil(M / 64)][N]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_nt_kernel(WideGemmParams p, 
                 cs_part[i][e] = s;
             }
         if (r == 0) {
-            const int prow = (m0 / TBM) * 2 + wm;
+            const int prow = m0 / 64 + wm;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + wn * 64 + i * 16 + 4 * g;
@@ -194,63 +217,87 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_nt_kernel(WideGemmParams p, 
     }
 }
 
-int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
-    EGX_CHECK(p.A && p.B && (p.Cf || p.Cb), "wide_gemm_nt: null operand");
-    EGX_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "wide_gemm_nt: empty problem %dx%dx%d", p.M, p.N, p.K);
-    EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
-              "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
+template <int BM, int D>
+static int launch_nt(const WideGemmParams& p, hipStream_t st) {
+    constexpr int LDS = D * (BM + TBN) * TBK * 2;
     static bool attr = false;
     if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_kernel<BM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int ntM = cdiv(p.M, TBM), ntN = cdiv(p.N, TBN);
+    const int ntM = cdiv(p.M, BM), ntN = cdiv(p.N, TBN);
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL(wide_gemm_nt_kernel, dim3(ntM * ntN), dim3(256), 2 * STAGE_BYTES, st, p, ntM, ntN);
+    hipLaunchKernelGGL((wide_gemm_nt_kernel<BM, D>), dim3(ntM * ntN), dim3(BM * 2), LDS, st, p, ntM, ntN);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
 }
 
+static bool nt_big(int M, int N) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("EGX_WIDE_TILE"); force = e ? atoi(e) : 0; }
+    return force ? force == 256 : (long)cdiv(M, 256) * cdiv(N, TBN) >= 512;
+}
+// rows of the `colsum` partial buffer written by wide_gemm_nt for an (M, N) output: one per 64 output rows of every tile
+int wide_gemm_nt_colsum_rows(int M, int N) { return nt_big(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }
+
+int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
+    EGX_CHECK(p.A && p.B && (p.Cf || p.Cb), "wide_gemm_nt: null operand");
+    EGX_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "wide_gemm_nt: empty problem %dx%dx%d", p.M, p.N, p.K);
+    EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
+              "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
+    // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves, 4-stage ring) below
+    return nt_big(p.M, p.N) ? launch_nt<256, 3>(p, st) : launch_nt<128, 4>(p, st);
+}
+
 // ---- TN ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
+// BM x 128 output tile (BM = 128 / 256 columns of dY against 128 columns of X), BM / 64 x 2 waves, ring of D stages as above.
+// A stage holds BM / 128 dY images and one X image, each [64 tokens][128 columns] (256-byte rows).
+template <int BM, int D>
+__global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
+    constexpr int NW = BM / 32, WM = BM / 64, NI = BM / 128 + 1;     // waves, waves along m, images per stage
+    constexpr int IMG = TBK * 128 * 2;                              // 16 KB
+    constexpr int SB = NI * IMG;
+    constexpr int PER = NI * 16 / NW;                               // staging instructions per wave per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, ntM * ntN);
-    const int m0 = (t / ntN) * TBM, n0 = (t % ntN) * TBN;
+    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * TBN;
     const int split = blockIdx.y;
     const int kbeg = split * kps, kend = min(p.K, kbeg + kps);
 
-    // staging: 4 token rows (256 B each) per instruction; wave w copies rows [16w, 16w + 16) of both tiles
+    // staging: 4 token rows (256 B each) of one image per instruction
     const int slot = lane & 15, half = slot & 1, pch = slot >> 1;
-    int rowS[4], colS[4];
+    int rowS[PER], colS[PER], ldS[PER];
+    const bf16_t* baseS[PER];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int row = (wave * 4 + j) * 4 + (lane >> 4);
-        int sw = (row & 3) | (((row >> 3) & 1) << 2);
+    for (int j = 0; j < PER; ++j) {
+        const int q = wave * PER + j, img = q >> 4, ii = q & 15;
+        const int row = ii * 4 + (lane >> 4);
+        const int sw = (row & 3) | (((row >> 3) & 1) << 2);
         rowS[j] = row;
-        colS[j] = ((pch ^ sw) * 16 + half * 8);
+        colS[j] = (pch ^ sw) * 16 + half * 8;
+        const bool isx = img == NI - 1;
+        baseS[j] = isx ? p.B + n0 : p.A + m0 + img * 128;
+        ldS[j] = isx ? p.ldb : p.lda;
     }
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero_page) + slot * 16;
     auto stage = [&](int k0, int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 4096;
-        unsigned char* sb = sa + TBK * TBM * 2;
+        unsigned char* dst = smem + buf * SB + wave * PER * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PER; ++j) {
             const int tok = k0 + rowS[j];
-            const bool ok = tok < kend;
-            const void* a = ok ? (const void*)(p.A + (size_t)tok * p.lda + m0 + colS[j]) : (const void*)zero;
-            const void* b = ok ? (const void*)(p.B + (size_t)tok * p.ldb + n0 + colS[j]) : (const void*)zero;
-            glds16(a, sa + j * 1024);
-            glds16(b, sb + j * 1024);
+            const void* a = tok < kend ? (const void*)(baseS[j] + (size_t)tok * ldS[j] + colS[j]) : (const void*)zero;
+            glds16(a, dst + j * 1024);
         }
     };
 
     const int r = lane & 15, g = lane >> 4;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     // transposed reads: lane supplies row 8g + (r >> 2) (+4) of the 32-token slice, 4 columns 4 * (r & 3) of its 16-wide tile
     const int swz = (r >> 2) | ((g & 1) << 2);
     const int rowoff = (8 * g + (r >> 2)) * 256 + 8 * (r & 3);
+    const int imgY = (wm >> 1) * IMG, cY = (wm & 1) * 4, imgX = (NI - 1) * IMG;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -259,24 +306,31 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_tn_kernel(WideGemmParams p, 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     const int nk = (kend - kbeg + TBK - 1) / TBK;
-    if (nk > 0) stage(kbeg, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < D - 1; ++s0)
+        if (s0 < nk) stage(kbeg + s0 * TBK, s0);
+    int buf = 0, nbuf = D - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kbeg + (kt + 1) * TBK, (kt + 1) & 1);
-        const unsigned char* sa = smem + (kt & 1) * STAGE_BYTES;      // dY tile: [64 tokens][128 m]
-        const unsigned char* sb = sa + TBK * TBM * 2;                  // X  tile: [64 tokens][128 n]
+        if (D >= 4 && kt + 2 < nk) { if (PER == 8) EGX_WAIT_VM(16); else EGX_WAIT_VM(12); }
+        else if (D >= 3 && kt + 1 < nk) { if (PER == 8) EGX_WAIT_VM(8); else EGX_WAIT_VM(6); }
+        else EGX_WAIT_VM(0);
+        ring_barrier();
+        if (kt + D - 1 < nk) stage(kbeg + (kt + D - 1) * TBK, nbuf);
+        const unsigned char* sy = smem + buf * SB + imgY;              // dY image: [64 tokens][128 m]
+        const unsigned char* sx = smem + buf * SB + imgX;              // X  image: [64 tokens][128 n]
+        buf = buf + 1 == D ? 0 : buf + 1;
+        nbuf = nbuf + 1 == D ? 0 : nbuf + 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 fx[4], fy[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // MFMA A operand: X^T rows n = wn*64 + i*16 + r
-                const unsigned char* q0 = sb + s * 32 * 256 + rowoff + (((wn * 4 + i) ^ swz) * 32);
+                const unsigned char* q0 = sx + s * 32 * 256 + rowoff + (((wn * 4 + i) ^ swz) * 32);
                 fx[i] = lds_read_tr2(q0, q0 + 4 * 256);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {       // MFMA B operand: dY columns m = wm*64 + j*16 + r
-                const unsigned char* q0 = sa + s * 32 * 256 + rowoff + (((wm * 4 + j) ^ swz) * 32);
+                const unsigned char* q0 = sy + s * 32 * 256 + rowoff + (((cY + j) ^ swz) * 32);
                 fy[j] = lds_read_tr2(q0, q0 + 4 * 256);
             }
 #pragma unroll
@@ -315,16 +369,26 @@ __global__ __launch_bounds__(256) void wide_slab_reduce_kernel(const float* __re
     }
 }
 
+static bool tn_big(int M) { return M % 256 == 0; }
+// Split count over the token axis: one workgroup per CU is resident (ring of 3 x 48 KB), so the kernel runs in
+// ceil(tiles * splits / 256) rounds of K / splits tokens each; more splits also mean more fp32 slab traffic
+// (2 x 4 bytes per output element per split against ~6 TB/s). Pick the cheapest count under that model.
 static int tn_splits(int M, int N, int K, int* kps_out) {
-    const int tiles = (M / TBM) * (N / TBN);
-    int splits = cdiv(768, tiles);                     // ~3 workgroups per CU slot pair
-    int max_splits = cdiv(K, 256);                     // at least 4 K steps per workgroup
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int kps = cdiv(cdiv(K, splits), TBK) * TBK;
-    splits = cdiv(K, kps);
+    const int tiles = (M / (tn_big(M) ? 256 : 128)) * (N / TBN);
+    const double step_us = 0.9;                         // one 64-token K step of a resident workgroup, measured
+    const double slab_us = 8.0 * M * N / 6.0e6;         // write + read of one slab
+    int best = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 64; ++sp) {
+        int kps = cdiv(cdiv(K, sp), TBK) * TBK;
+        if (kps < 256 && sp > 1) break;
+        int real = cdiv(K, kps);
+        double t = (double)cdiv(tiles * real, 256) * (kps / TBK) * step_us + (real > 1 ? real * slab_us : 0.0);
+        if (t < best_t - 1e-9) { best_t = t; best = real; }
+    }
+    int kps = cdiv(cdiv(K, best), TBK) * TBK;
     if (kps_out) *kps_out = kps;
-    return splits;
+    return cdiv(K, kps);
 }
 
 size_t wide_gemm_tn_scratch(int M, int N, int K) {
@@ -332,23 +396,31 @@ size_t wide_gemm_tn_scratch(int M, int N, int K) {
     return (size_t)tn_splits(M, N, K, nullptr) * M * N * sizeof(float);
 }
 
+template <int BM, int D>
+static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs, size_t slab_stride, hipStream_t st) {
+    constexpr int LDS = D * (BM / 128 + 1) * TBK * 128 * 2;
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_kernel<BM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int ntM = p.M / BM, ntN = p.N / TBN;
+    timing_begin(TIMER_WIDE_GEMM, st);
+    hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, D>), dim3(ntM * ntN, splits), dim3(BM * 2), LDS, st, p, ntM, ntN, kps, slabs, slab_stride);
+    timing_end(TIMER_WIDE_GEMM, st);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
 int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st) {
     EGX_CHECK(p.A && p.B && p.Cf && scratch && p.zero_page, "wide_gemm_tn: null operand");
     EGX_CHECK(p.M % TBM == 0 && p.N % TBN == 0 && p.K > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_tn: %dx%dx%d needs M, N multiples of 128 and 16-byte aligned rows", p.M, p.N, p.K);
-    static bool attr = false;
-    if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        attr = true;
-    }
     int kps = 0;
     const int splits = tn_splits(p.M, p.N, p.K, &kps);
-    const int ntM = p.M / TBM, ntN = p.N / TBN;
     const size_t slab_stride = (size_t)p.M * p.N;
-    timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL(wide_gemm_tn_kernel, dim3(ntM * ntN, splits), dim3(256), 2 * STAGE_BYTES, st, p, ntM, ntN, kps,
-                       (float*)scratch, slab_stride);
-    timing_end(TIMER_WIDE_GEMM, st);
+    if (tn_big(p.M)) { if (launch_tn<256, 3>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
+    else if (launch_tn<128, 4>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1;
     const size_t n4 = slab_stride / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;

@@ -93,7 +93,8 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
         if (segs[i].proj_w) slab = smax(slab, wide_gemm_tn_scratch(pl.d, segs[i].d_in, B * segs[i].T));
     pl.slabs = take(sc, slab);
     pl.lnpart = take(sc, wide_ln_bwd_scratch((int)N, pl.d));
-    size_t cs = smax(wide_colsum_scratch((int)N, 3 * pl.d), (size_t)2 * cdiv((int)N, 128) * pl.dff * 4);
+    size_t cs = smax(wide_colsum_scratch((int)N, 3 * pl.d), (size_t)(4 * cdiv((int)N, 256) + 4) * pl.dff * 4);
+    for (int i = 0; i < pl.nseg; ++i) cs = smax(cs, wide_pos_grad_scratch(B, segs[i].T, pl.d));
     pl.cspart = take(sc, cs);
     pl.scratch_bytes = sc;
 }
@@ -291,7 +292,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             q.mask_scale = mkdrop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN).inv;
             q.colsum = gw.lin1_b ? cspart : nullptr;
             if (wide_gemm_nt(q, st)) return 1;
-            if (gw.lin1_b && wide_reduce_rows(cspart, 2 * cdiv(N, 128), dff, gw.lin1_b, st)) return 1;
+            if (gw.lin1_b && wide_reduce_rows(cspart, wide_gemm_nt_colsum_rows(N, dff), dff, gw.lin1_b, st)) return 1;
         }
         if (dw_tn(dhid16, dff, cat<bf16_t>(saved, o.x1_16), d, gw.lin1_w, dff, d, N)) return 1;
         float* g1 = (g == gA) ? gB : gA;
@@ -347,7 +348,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
         if (seg_grads) sgr = seg_grads[i];
         EGX_CHECK(!sgr.feat, "wide path: gradients into the features are not supported (use impl = generic)");
         const int rows = B * sg.T;
-        if (sgr.pos && pos_grad_accum(g, B, S, pl.seg_off[i], sg.T, d, sgr.pos, sg.pos_stride, dp.key, dp.thresh, dp.inv, st)) return 1;
+        if (sgr.pos && wide_pos_grad(g, B, S, pl.seg_off[i], sg.T, d, sgr.pos, sg.pos_stride, dp.key, dp.thresh, dp.inv, cspart, st)) return 1;
         const bool need = (sg.proj_w && (sgr.proj_w || sgr.proj_b)) || d_ln_w || d_ln_b || sgr.add_vec;
         if (!need) continue;
         WideLnBwdParams b;

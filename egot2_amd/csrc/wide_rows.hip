@@ -177,22 +177,37 @@ __global__ __launch_bounds__(256) void wide_ln_bwd_kernel(WideLnBwdParams p, int
     }
 }
 
-// dst_k[c] += sum_b partials[b][k][c] in block order b = 0 .. blocks-1 (fixed order)
-__global__ __launch_bounds__(256) void wide_ln_bwd_reduce_kernel(const float* __restrict__ partials, int blocks, int d,
-                                                                 float* dw, float* db, float* dbias, float* dadd) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 3 * d) return;
-    const int k = i / d, c = i % d;
+// Fixed-order sum over the rows of a partial buffer: 1024 threads = 16 waves per 64 columns; wave w adds rows w, w + 16, ...
+// (four independent accumulators), the 16 wave sums are combined in wave order through LDS. Bitwise reproducible.
+__device__ __forceinline__ float reduce_rows_1024(const float* __restrict__ part, int nt, size_t ld, int col, bool valid, float (*red)[64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < blocks; b += 4) {
-        s0 += partials[(size_t)(b + 0) * 3 * d + i];
-        s1 += partials[(size_t)(b + 1) * 3 * d + i];
-        s2 += partials[(size_t)(b + 2) * 3 * d + i];
-        s3 += partials[(size_t)(b + 3) * 3 * d + i];
+    if (valid) {
+        int t = wave;
+        for (; t + 48 < nt; t += 64) {
+            s0 += part[(size_t)(t + 0) * ld + col];  s1 += part[(size_t)(t + 16) * ld + col];
+            s2 += part[(size_t)(t + 32) * ld + col]; s3 += part[(size_t)(t + 48) * ld + col];
+        }
+        for (; t < nt; t += 16) s0 += part[(size_t)t * ld + col];
     }
-    for (; b < blocks; ++b) s0 += partials[(size_t)b * 3 * d + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    float s = 0.f;
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][lane];
+    }
+    return s;
+}
+
+// dst_k[c] += sum_b partials[b][k][c], k = 0 d(gamma), 1 d(beta) (+ task embedding), 2 branch bias
+__global__ __launch_bounds__(1024) void wide_ln_bwd_reduce_kernel(const float* __restrict__ partials, int blocks, int d,
+                                                                  float* dw, float* db, float* dbias, float* dadd) {
+    __shared__ float red[16][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = reduce_rows_1024(partials, blocks, (size_t)3 * d, i, i < 3 * d, red);
+    if (threadIdx.x >= 64 || i >= 3 * d) return;
+    const int k = i / d, c = i % d;
     if (k == 0) { if (dw) dw[c] += s; }
     else if (k == 1) { if (db) db[c] += s; if (dadd) dadd[c] += s; }
     else { if (dbias) dbias[c] += s; }
@@ -215,7 +230,7 @@ int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st) {
     p.blocks = cdiv(p.rows, rpb);
     hipLaunchKernelGGL(wide_ln_bwd_kernel, dim3(p.blocks), dim3(256), 0, st, p, rpb);
     if (p.dw || p.db || p.dbias || p.dadd)
-        hipLaunchKernelGGL(wide_ln_bwd_reduce_kernel, dim3(cdiv(3 * p.d, 256)), dim3(256), 0, st, (const float*)p.partials, p.blocks,
+        hipLaunchKernelGGL(wide_ln_bwd_reduce_kernel, dim3(cdiv(3 * p.d, 64)), dim3(1024), 0, st, (const float*)p.partials, p.blocks,
                            p.d, p.dw, p.db, p.dbias, p.dadd);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -247,22 +262,55 @@ __global__ __launch_bounds__(256) void wide_colsum_kernel(const bf16_t* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void wide_reduce_rows_kernel(const float* __restrict__ part, int nt, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int t = 0;
-    for (; t + 3 < nt; t += 4) {
-        s0 += part[(size_t)(t + 0) * cols + c]; s1 += part[(size_t)(t + 1) * cols + c];
-        s2 += part[(size_t)(t + 2) * cols + c]; s3 += part[(size_t)(t + 3) * cols + c];
-    }
-    for (; t < nt; ++t) s0 += part[(size_t)t * cols + c];
-    out[c] += (s0 + s1) + (s2 + s3);
+__global__ __launch_bounds__(1024) void wide_reduce_rows_kernel(const float* __restrict__ part, int nt, int cols, float* __restrict__ out, int out_ld, int row_len) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = reduce_rows_1024(part, nt, (size_t)cols, c, c < cols, red);
+    if (threadIdx.x < 64 && c < cols) out[(size_t)(c / row_len) * out_ld + c % row_len] += s;
 }
 
 int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st) {
     if (nt <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, part, nt, cols, out);
+    hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, st, part, nt, cols, out, cols, cols);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- learned positional-table gradient -------------------------------------------------------------------------------
+// dpos[t][c] += sum_b mask .* dtok[(b * S + off + t)][c]: clips are split into chunks summed by separate workgroups, the chunk
+// sums are added in fixed order (the generic path's one-thread-per-element loop over all B clips was latency-bound).
+__global__ __launch_bounds__(256) void wide_pos_grad_kernel(const float* __restrict__ dtok, int B, int S, int off, int T, int d, int bchunk,
+                                                            float* __restrict__ partial, uint64_t key, uint32_t thresh, float inv) {
+    const int i4 = blockIdx.x * 256 + threadIdx.x;           // float4 index into (T, d)
+    if (i4 * 4 >= T * d) return;
+    const int t = (i4 * 4) / d, c = (i4 * 4) % d;
+    const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int b = b0; b < b1; ++b) {
+        const int orow = b * S + off + t;
+        float4 v = *reinterpret_cast<const float4*>(dtok + (size_t)orow * d + c);
+        if (thresh) {
+            float ds[4];
+            drop_scale4(key, (uint32_t)orow, (uint32_t)c, thresh, inv, ds);
+            v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * T * d + (size_t)i4 * 4) = s;
+}
+
+size_t wide_pos_grad_scratch(int B, int T, int d) { return (size_t)cdiv(B, 8) * T * d * sizeof(float); }
+
+int wide_pos_grad(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride, uint64_t key, uint32_t thresh,
+                  float inv, void* scratch, hipStream_t st) {
+    EGX_CHECK(d % 4 == 0 && scratch, "wide_pos_grad: bad arguments");
+    int chunks = B >= 64 ? 32 : cdiv(B, 2);
+    const int bchunk = cdiv(B, chunks);
+    chunks = cdiv(B, bchunk);
+    hipLaunchKernelGGL(wide_pos_grad_kernel, dim3(cdiv(T * d / 4, 256), chunks), dim3(256), 0, st, dtok, B, S, off, T, d, bchunk,
+                       (float*)scratch, key, thresh, inv);
+    hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(T * d, 64)), dim3(1024), 0, st, (const float*)scratch, chunks, T * d, dpos,
+                       pos_stride, d);
     EGX_LAUNCH_CHECK();
     return 0;
 }

@@ -201,9 +201,16 @@ class EncoderFn(torch.autograd.Function):
         nig = ctx.needs_input_grad
         needs_grad = any(nig)
         if spec.impl == "auto" and (nig[2] or any(nig[5:5 + nseg])):
-            # the fused backward emits no positional-table / feature gradients: keep the generic kernels
             import dataclasses
-            spec = dataclasses.replace(spec, impl="generic")
+            if any(nig[5:5 + nseg]):
+                # gradients into the features: only the shape-generic backward produces them
+                spec = dataclasses.replace(spec, impl="generic")
+            else:
+                # learned positional table (HOI `pe`): the fused per-clip backward emits no gradient for it; the wide
+                # bf16 path and the generic kernels do
+                probe = spec.config()
+                if lib.egx_encoder_impl(C.byref(probe), segs, B) == EGX_IMPL_FUSED:
+                    spec = dataclasses.replace(spec, impl="generic")
         cfg = spec.config()
         sv, sc = C.c_size_t(0), C.c_size_t(0)
         ws = lib.egx_translator_workspace if nhead else lib.egx_encoder_workspace
@@ -225,7 +232,8 @@ class EncoderFn(torch.autograd.Function):
             check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
                                       ptr(scratch), int(spec.training), seed, _stream()))
         ctx.spec = spec
-        ctx.fused_path = bool(lib.egx_encoder_uses_fused(C.byref(cfg), segs, B))
+        ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
+        ctx.fused_path = ctx.impl == EGX_IMPL_FUSED
         ctx.B = B
         ctx.nseg, ctx.nproj, ctx.nhead = nseg, nproj, nhead
         ctx.saved_buf = saved
@@ -317,10 +325,10 @@ class EncoderFn(torch.autograd.Function):
                                              ptr(saved_buf), ptr(scratch), sgr, p_lnw, p_lnb, lgr,
                                              C.byref(hg), int(spec.training), seed, _stream()))
         else:
-            # the generic backward overwrites d_tokens (needs a private copy); the fused kernels only read it
+            # the generic backward overwrites d_tokens (needs a private copy); the fused and wide kernels only read it
             dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
             dtok = dtok.contiguous()
-            if dtok.data_ptr() == d_tokens.data_ptr() and not ctx.fused_path:
+            if dtok.data_ptr() == d_tokens.data_ptr() and ctx.impl == EGX_IMPL_GENERIC:
                 dtok = dtok.clone()
 
             def launch(c):

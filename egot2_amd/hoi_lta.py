@@ -46,7 +46,12 @@ class MultiTaskHead(nn.Module):
         """feat: (B, d) -> list of (B, n_classes)."""
         if hasattr(self, "dropout"):
             feat = self.dropout(feat)
-        x = [F_egx.linear(feat, p.weight, p.bias, self.egx_compute) for p in self.projections]
+        # ONE GEMM for all Z future-action heads: the 20 (593, d) projections are stacked row-wise (autograd splits the
+        # gradient back), instead of 20 launches of a 256-row problem each
+        sizes = [p.out_features for p in self.projections]
+        W = torch.cat([p.weight for p in self.projections], dim=0)
+        b = torch.cat([p.bias for p in self.projections], dim=0)
+        x = list(F_egx.linear(feat, W, b, self.egx_compute).split(sizes, dim=-1))
         if not self.training and not self.test_noact:
             x = [self.act(x_i) for x_i in x]
         return x

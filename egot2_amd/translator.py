@@ -85,9 +85,7 @@ class TranslatorMixin:
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
-        impl = self.egx_impl
-        if impl == "auto" and pos_table is not None and pos_table.requires_grad:
-            impl = "generic"       # learned positions (HOI `pe`): their gradient comes from the shape-generic backward
+        impl = self.egx_impl    # "auto": functional.EncoderFn steers around the fused kernels when a learned `pe` needs a gradient
         spec = EncoderSpec(d_model=d, n_heads=layer0.self_attn.num_heads, d_ff=layer0.linear1.out_features,
                            n_layers=len(encoder.layers), segments=segments, ln_eps=ln.eps,
                            compute=self.egx_compute, impl=impl,
