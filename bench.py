@@ -68,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--launch-selftest", action="store_true",
                     help="exercise only the launcher plumbing (rank spawn, process group on --backend, barrier, max-over-ranks timing, JSON relay) without the model; CPU-runnable")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo only for --launch-selftest)")
+    ap.add_argument("--encoder-only", action="store_true", help="c5*: time the task-translation encoder alone (loss = sum of the memory), without the sequence decoder + vocabulary CE")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -183,7 +184,7 @@ def run(args) -> int:
     lib = _lib.load()
 
     wl = synth.make_workload(args.config, dev, batch=args.batch, frames=args.frames, layers=args.layers or None,
-                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank)
+                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
     ddp.broadcast_parameters(model)

@@ -96,6 +96,9 @@ SIGNATURES = {
     "egx_pool_head_bwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, _fp, C.c_int,
                                     _fp, _fp, _fp, _fp, _fp, _fp]),
     "egx_linear_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "egx_linear_residual_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
+    "egx_gelu_fwd": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
+    "egx_gelu_bwd": (C.c_int, [_fp, _fp, _fp, C.c_size_t, _fp]),
     "egx_linear_bwd_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_linear_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "egx_gemm": (C.c_int, [C.c_int, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp,

@@ -8,6 +8,7 @@
 //                            One wave per (batch element, head); probabilities are recomputed in the backward.
 //   embed_pos_fwd/bwd        y = embedding[token] * sqrt(d) + pe[position] (+ dropout), and the scatter-add of its gradient.
 //   relu_mask                dy <- dy where y > 0 (backward of the ReLU fused into the linear1 GEMM epilogue).
+//   gelu_fwd/bwd             exact (erf) GELU of the pre-LN translator's FeedForward (HOI/models/pnr/simple_vit.py:55-65).
 #include "common.h"
 #include "kernels.h"
 
@@ -209,6 +210,40 @@ int relu_mask(float* dy, const float* y, size_t n, hipStream_t st) {
     EGX_CHECK(dy && y, "relu_mask: null pointer argument");
     if (!n) return 0;
     hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y, n);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// h = z * Phi(z); dz = dh * (Phi(z) + z * phi(z))   (nn.GELU() default: exact erf form)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ z, float* __restrict__ h, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<const float4*>(z)[i];
+    auto f = [](float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); };
+    reinterpret_cast<float4*>(h)[i] = make_float4(f(v.x), f(v.y), f(v.z), f(v.w));
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dh, float* __restrict__ dz, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = reinterpret_cast<const float4*>(z)[i], g = reinterpret_cast<const float4*>(dh)[i];
+    auto f = [](float x, float d) {
+        float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+        float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+        return d * (cdf + x * pdf);
+    };
+    reinterpret_cast<float4*>(dz)[i] = make_float4(f(v.x, g.x), f(v.y, g.y), f(v.z, g.z), f(v.w, g.w));
+}
+int gelu_fwd(const float* z, float* h, size_t n, hipStream_t st) {
+    EGX_CHECK(z && h && n % 4 == 0, "gelu_fwd: null pointer or n %% 4 != 0");
+    if (!n) return 0;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, z, h, n / 4);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+int gelu_bwd(const float* z, const float* dh, float* dz, size_t n, hipStream_t st) {
+    EGX_CHECK(z && dh && dz && n % 4 == 0, "gelu_bwd: null pointer or n %% 4 != 0");
+    if (!n) return 0;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, z, dh, dz, n / 4);
     EGX_LAUNCH_CHECK();
     return 0;
 }

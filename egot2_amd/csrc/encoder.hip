@@ -874,6 +874,14 @@ int egx_linear_fwd(const float* x, const float* W, const float* b, float* y, int
     Drop none;
     return linear_nt(x, W, b, y, M, N, K, relu, none, nullptr, compute, (hipStream_t)stream);
 }
+int egx_linear_residual_fwd(const float* x, const float* W, const float* b, const float* residual, float* y, int M, int N, int K,
+                            int compute, void* stream) {
+    EGX_CHECK(x && W && y && residual, "null pointer argument");
+    Drop none;
+    return linear_nt(x, W, b, y, M, N, K, 0, none, residual, compute, (hipStream_t)stream);
+}
+int egx_gelu_fwd(const float* z, float* h, size_t n, void* stream) { return gelu_fwd(z, h, n, (hipStream_t)stream); }
+int egx_gelu_bwd(const float* z, const float* dh, float* dz, size_t n, void* stream) { return gelu_bwd(z, dh, dz, n, (hipStream_t)stream); }
 
 size_t egx_linear_bwd_scratch(int M, int N, int K) { return gemm_scratch_bytes(2, N, K, M); }
 

@@ -116,5 +116,7 @@ int embed_pos_fwd(const int64_t* tok, const float* emb, const float* pe, int pe_
 int embed_pos_bwd(const int64_t* tok, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V, uint64_t key,
                   uint32_t thresh, float inv, hipStream_t st);
 int relu_mask(float* dy, const float* y, size_t n, hipStream_t st);
+int gelu_fwd(const float* z, float* h, size_t n, hipStream_t st);
+int gelu_bwd(const float* z, const float* dh, float* dz, size_t n, hipStream_t st);
 
 }  // namespace egx

@@ -25,7 +25,8 @@ class DecoderMixin:
         sy = y.shape[1]
         if y.shape[0] != B:
             raise ValueError(f"target batch {y.shape[0]} != memory batch {B}")
-        comp = "f32"        # (B * sy)-row GEMMs: negligible work, so the decoder always runs the exact fp32 MFMA path
+        comp = "f32"        # (B * sy)-row GEMMs: negligible work, they always run the exact fp32 MFMA path
+        comp_mem = getattr(self, "egx_compute", "f32")     # the K / V projection of the (B * S)-row memory follows the encoder's compute type
         train = bool(self.training)
         seed = self._egx_seed() if train else 0
         mem2d = encoded_x.permute(1, 0, 2).contiguous().view(B * S, d)          # batch-first rows b * S + s
@@ -42,7 +43,7 @@ class DecoderMixin:
             a = F_egx.dropout(F_egx.linear(a, sa.out_proj.weight, sa.out_proj.bias, comp), p_drop, train, seed, site(2))
             x = F_egx.layer_norm_residual(x, a, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
             q = F_egx.linear(x, ca.in_proj_weight[:d], ca.in_proj_bias[:d], comp)
-            kv = F_egx.linear(mem2d, ca.in_proj_weight[d:], ca.in_proj_bias[d:], comp)
+            kv = F_egx.linear(mem2d, ca.in_proj_weight[d:], ca.in_proj_bias[d:], comp_mem)
             c = F_egx.CrossAttnSmallFn.apply(q, kv, B, sy, S, n_heads, p, seed, site(3))
             c = F_egx.dropout(F_egx.linear(c, ca.out_proj.weight, ca.out_proj.bias, comp), p_drop, train, seed, site(4))
             x = F_egx.layer_norm_residual(x, c, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)

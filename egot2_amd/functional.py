@@ -461,6 +461,102 @@ def linear(x, W, b=None, compute: str = "f32", relu: bool = False):
     return y.view(*shp[:-1], W.shape[0])
 
 
+class LinearResidualFn(torch.autograd.Function):
+    """y = x W^T (+ b) + residual: the residual connection rides in the GEMM epilogue (pre-LN blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, residual, compute: str):
+        lib = _lib.load()
+        x, W, residual = _dev_f32(x, "x"), _dev_f32(W, "W"), _dev_f32(residual, "residual")
+        b = _dev_f32(b, "b") if b is not None else None
+        M, K = x.shape
+        N = W.shape[0]
+        if tuple(residual.shape) != (M, N):
+            raise ValueError(f"residual shape {tuple(residual.shape)} != ({M}, {N})")
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.egx_linear_residual_fwd(ptr(x), ptr(W), ptr(b), ptr(residual), ptr(y), M, N, K, COMPUTE[compute], _stream()))
+        ctx.compute, ctx.has_b = compute, b is not None
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        M, K = x.shape
+        N = W.shape[0]
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dW = torch.zeros_like(W) if need[1] else None
+        db = torch.zeros(N, dtype=torch.float32, device=dy.device) if (ctx.has_b and need[2]) else None
+        scratch = _workspace("linear", dy.device, lib.egx_linear_bwd_scratch(M, N, K))
+        check(lib.egx_linear_bwd(ptr(dy), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K, COMPUTE[ctx.compute],
+                                 ptr(scratch), _stream()))
+        return dx, dW, db, (dy if need[3] else None), None
+
+
+def linear_residual(x, W, b, residual, compute: str = "f32"):
+    return LinearResidualFn.apply(x, W, b, residual, compute)
+
+
+class GeluFn(torch.autograd.Function):
+    """Exact (erf) GELU; the pre-activation is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, z):
+        lib = _lib.load()
+        z = _dev_f32(z, "z")
+        h = torch.empty_like(z)
+        check(lib.egx_gelu_fwd(ptr(z), ptr(h), z.numel(), _stream()))
+        ctx.save_for_backward(z)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        dh = dh.contiguous().float()
+        dz = torch.empty_like(z)
+        check(lib.egx_gelu_bwd(ptr(z), ptr(dh), ptr(dz), z.numel(), _stream()))
+        return dz
+
+
+def gelu(z):
+    return GeluFn.apply(z)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(dh)) V per (clip, head) from packed (B * S, 3 * inner) qkv rows -> (B * S, inner), through the
+    shape-generic attention kernels (any S; inner = H * dh need not equal the model width)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B: int, S: int, H: int):
+        lib = _lib.load()
+        qkv = _dev_f32(qkv, "qkv")
+        inner = qkv.shape[1] // 3
+        out = torch.empty((B * S, inner), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
+        check(lib.egx_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, S, H, inner, 0.0, C.c_uint64(0), _stream()))
+        ctx.dims = (B, S, H, inner)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.load()
+        qkv, out, lse = ctx.saved_tensors
+        B, S, H, inner = ctx.dims
+        d_out = d_out.contiguous().float()
+        dqkv = torch.empty_like(qkv)
+        check(lib.egx_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(d_out), ptr(dqkv), B, S, H, inner, 0.0, C.c_uint64(0), _stream()))
+        return dqkv, None, None, None
+
+
+def attention(qkv, B: int, S: int, H: int):
+    return AttentionFn.apply(qkv, B, S, H)
+
+
 _UNIT_GRAD = {}
 
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F_egx
+from .backbones import cfg_get, freeze_backbone_params, freeze_params, make_hoi_backbone
 from .functional import SegmentSpec
 from .registry import make_registry
 from .translator import TranslatorMixin
@@ -66,6 +67,10 @@ class TaskFusionMFTransformer3Task(_ARTranslator):
         self.avg_pool_slow = nn.AdaptiveAvgPool3d((None, 1, 1))
         self.avg_pool_fast = nn.AdaptiveAvgPool3d((8, 1, 1))
         self._finish(c1, c2)
+        # frozen backbones where the reference builds them (TaskFusion3Task.__init__, video_model_transfer_3task.py:23-58)
+        from .hoi_pnr import build_task_backbones
+        build_task_backbones(self, cfg, cfg_get(cfg, "PRETRAIN.PNR_CFG"), cfg_get(cfg, "PRETRAIN.OSCC_CFG"),
+                             cfg_get(cfg, "PRETRAIN.ACTION_CFG"), oscc_no_temp_pool=True, action_with_head=False)
 
     def forward_features(self, action_feat_slow, action_feat_fast, pnr_feat, oscc_feat):
         """(B,8,2048), (B,8,256), (B,16,8192), (B,16,8192) -> [(B, n_verbs), (B, n_nouns)]; token order slow, fast,
@@ -100,6 +105,13 @@ class TaskFusionMFTransformer2TaskAR(_ARTranslator):
         self.avg_pool_fast = nn.AdaptiveAvgPool3d((8, 1, 1))
         self._finish(c1, c2)
         self._init_parameters()          # xavier on every matrix, before any backbone is attached (reference :204,222-225)
+        if cfg_get(cfg, "PRETRAIN.ACTION_CFG"):     # reference :206-212
+            self.action_model = make_hoi_backbone("slowfast", cfg_file=cfg.PRETRAIN.ACTION_CFG, num_classes=[self.feature_dim],
+                                                  with_head=False, loader="lta")
+            freeze_backbone_params(self.action_model)
+        if cfg_get(cfg, "PRETRAIN.LTA_CFG"):        # reference :214-217
+            self.lta_model = make_hoi_backbone("lta", cfg_file=cfg.PRETRAIN.LTA_CFG, build_decoder=False)
+            freeze_params(self.lta_model)
 
     def _init_parameters(self):
         for p in self.parameters():

@@ -3,8 +3,11 @@
 encoder-decoder over the PNR, OSCC, action-recognition (SlowFast) and, for the 6-task model, LTA backbones, with the
 task named by a prompt token. The shared task-translation ENCODER (d=512, 8 heads,
 3 layers, S=48 or 4n) and the short sequence decoder + vocabulary head (row F1, egot2_amd/decoder.py) run in
-libegot2x.so. The frozen backbones are attached by the host code (`pnr_model`, `oscc_model`,
-`recognition_model`, `lta_model`), see INTEGRATION.md."""
+libegot2x.so. The frozen backbones (`pnr_model`, `oscc_model`, `recognition_model`, `lta_model`) are built in the
+constructors where the reference builds them (video_model_builder.py:98-130, :284-289) from args.{pnr,oscc,action,lta}_cfg_file
+through egot2_amd.backbones.make_hoi_backbone; empty entries build none (feature-level use).
+Also: `TaskTranslationPromptTransformer2Task` (video_model_builder_2task.py:50-167) and
+`TaskTranslationPromptTransformerActionTask` (video_model_builder_action.py:21-187)."""
 from __future__ import annotations
 
 import copy
@@ -13,6 +16,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .backbones import freeze_backbone_params, freeze_params, make_hoi_backbone
 from .functional import SegmentSpec
 from .hhi_multitask import CustomDecoderLayer
 from .decoder import DecoderMixin
@@ -54,6 +58,20 @@ class TaskPromptTransformer(nn.Module, TranslatorMixin, DecoderMixin):
         self.seq_len = 5
         self.y_mask = self.get_tgt_mask(self.seq_len)   # plain attribute, not a buffer (as in the reference)
         self._init_parameters()
+        self._build_backbones(args, oscc_no_temp_pool)
+
+    def _build_backbones(self, args, oscc_no_temp_pool):
+        """Reference :98-130: PNR / OSCC frozen, SlowFast with a dim-wide trainable head."""
+        if getattr(args, "pnr_cfg_file", None):
+            self.pnr_model = make_hoi_backbone("pnr", cfg_file=args.pnr_cfg_file)
+            freeze_params(self.pnr_model)
+        if getattr(args, "oscc_cfg_file", None):
+            self.oscc_model = make_hoi_backbone("oscc", cfg_file=args.oscc_cfg_file, no_temp_pool=oscc_no_temp_pool)
+            freeze_params(self.oscc_model)
+        if getattr(args, "action_cfg_file", None):
+            self.recognition_model = make_hoi_backbone("slowfast", cfg_file=args.action_cfg_file, num_classes=[self.dim],
+                                                       with_head=True, loader="recognition")
+            freeze_backbone_params(self.recognition_model)  # do not freeze head
 
     def _init_parameters(self):
         for p in self.parameters():
@@ -173,6 +191,9 @@ class TaskTranslationPromptTransformer6Task(TaskPromptTransformer):
         super().__init__(args, vocab)
         self.task_embed = nn.Parameter(torch.randn(1, 4, self.dim), requires_grad=True)
         self.proj_lta = nn.Linear(2048, self.dim)
+        if getattr(args, "lta_cfg_file", None):      # reference :284-289
+            self.lta_model = make_hoi_backbone("lta", cfg_file=args.lta_cfg_file, build_decoder=False)
+            freeze_params(self.lta_model)
 
     def encode_clips(self, model, x):
         assert isinstance(x, list) and len(x) >= 1
@@ -228,3 +249,190 @@ class TaskTranslationPromptTransformer6Task(TaskPromptTransformer):
             return torch.stack((pred_verb[0, :], pred_noun[0, :]), dim=1)
         y = (torch.ones((batch_size, 1)) * self.vocab[task]).type_as(video_pnr[0]).long()
         return self.decode(y, encoded_x)[0, :]
+
+
+class TaskPromptTransformer2Task(TaskPromptTransformer):
+    """HOI/models/multitask/video_model_builder_2task.py:50-122: the PNR + OSCC EgoT2-g (two task embeddings, no action stream)."""
+
+    def __init__(self, args, vocab, oscc_no_temp_pool=True):
+        nn.Module.__init__(self)
+        self.args = args
+        self.vocab = vocab
+        self.dim = args.hidden_dim
+        self.n_tasks = 2
+        self.task_dict = {'pnr': 0, 'oscc': 1}
+        self.n_heads = args.num_heads
+        self.num_layers = args.num_layers
+        self.dp_rate = args.dropout
+        self.transformer_encoder = nn.TransformerEncoder(   # parameter container only
+            encoder_layer=nn.TransformerEncoderLayer(d_model=self.dim, nhead=self.n_heads, dropout=self.dp_rate),
+            num_layers=self.num_layers
+        )
+        self.transformer_decoder = nn.TransformerDecoder(
+            decoder_layer=CustomDecoderLayer(d_model=self.dim, nhead=self.n_heads, dropout=self.dp_rate),
+            num_layers=self.num_layers
+        )
+        self.proj_pnr = nn.Linear(8192, self.dim)
+        self.proj_oscc = nn.Linear(8192, self.dim)
+        self.fc = nn.Linear(self.dim, len(self.vocab))
+        self.ln = nn.LayerNorm(self.dim)
+        self.task_embed = nn.Parameter(torch.randn(1, self.n_tasks, self.dim), requires_grad=True)
+        self.pos_embed = PositionalEncoding(self.dim, dropout=0.1, max_len=200)
+        self.embedding = nn.Embedding(len(self.vocab), self.dim)
+        self.seq_len = 5
+        self.y_mask = self.get_tgt_mask(self.seq_len)
+        self._init_parameters()
+        self._build_backbones(args, oscc_no_temp_pool)
+
+    def _build_backbones(self, args, oscc_no_temp_pool):
+        """Reference :88-100: PNR and OSCC only."""
+        if getattr(args, "pnr_cfg_file", None):
+            self.pnr_model = make_hoi_backbone("pnr", cfg_file=args.pnr_cfg_file)
+            freeze_params(self.pnr_model)
+        if getattr(args, "oscc_cfg_file", None):
+            self.oscc_model = make_hoi_backbone("oscc", cfg_file=args.oscc_cfg_file, no_temp_pool=oscc_no_temp_pool)
+            freeze_params(self.oscc_model)
+
+
+class TaskTranslationPromptTransformer2Task(TaskPromptTransformer2Task):
+    """Reference :124-167."""
+
+    def encode_features(self, feat_pnr, feat_oscc):
+        return self._encode_segments([feat_pnr, feat_oscc], [self.proj_pnr, self.proj_oscc], [0, 1], [0, 0])
+
+    def encode(self, video_pnr):
+        video_oscc = video_pnr.copy()
+        with torch.no_grad():
+            feat_pnr = self.pnr_model(video_pnr, middle=True)
+            feat_oscc = self.oscc_model(video_oscc, middle=True)
+        return self.encode_features(feat_pnr, feat_oscc)
+
+    def forward(self, video_pnr, target):
+        return self.decode(target, self.encode(video_pnr)).permute(1, 2, 0)
+
+    def predict(self, video_pnr, task):
+        assert task in ['pnr', 'oscc']
+        batch_size = video_pnr[0].shape[0]
+        encoded_x = self.encode(video_pnr)
+        y = (torch.ones((batch_size, 1)) * self.vocab[task]).type_as(video_pnr[0]).long()
+        return self.decode(y, encoded_x)[0, :]
+
+
+class TaskTranslationPromptTransformerActionTask(nn.Module, TranslatorMixin, DecoderMixin):
+    """HOI/models/multitask/video_model_builder_action.py:21-187: action-recognition / LTA EgoT2-g over the SlowFast clip
+    feature and the LTA forecasting features. 'lta' prompts: tokens = ln(cat(action, lta)) + learned `pe` (1, 4, d) (both
+    streams must already be hidden_dim wide, as in the reference); other prompts: ONE token, task embedding 0 + position 0.
+    `v_idx` / `n_idx` (vocabulary index maps of utils.multitask.build_vocab.vocab_idx_to_orig) may be passed in; they are
+    only used by predict()."""
+
+    def __init__(self, args, vocab, v_idx=None, n_idx=None):
+        super().__init__()
+        self.args = args
+        self.vocab = vocab
+        if v_idx is None or n_idx is None:
+            try:
+                import importlib
+                v_idx, n_idx = importlib.import_module("utils.multitask.build_vocab").vocab_idx_to_orig()
+            except ImportError:
+                pass
+        self.v_idx, self.n_idx = v_idx, n_idx
+        self.dim = args.hidden_dim
+        self.n_tasks = 2
+        self.n_heads = args.num_heads
+        self.dim_feedforward = getattr(args, "ff_dim", 2048)
+        self.num_layers = args.num_layers
+        self.dp_rate = args.dropout
+        self.max_output_length = 500
+        self.transformer_encoder = nn.TransformerEncoder(   # parameter container only
+            encoder_layer=nn.TransformerEncoderLayer(d_model=self.dim, nhead=self.n_heads, dropout=self.dp_rate),
+            num_layers=self.num_layers
+        )
+        self.transformer_decoder = nn.TransformerDecoder(
+            decoder_layer=CustomDecoderLayer(d_model=self.dim, nhead=self.n_heads, dropout=self.dp_rate),
+            num_layers=self.num_layers
+        )
+        self.fc = nn.Linear(self.dim, len(self.vocab))
+        self.ln = nn.LayerNorm(self.dim)
+        self.task_embed = nn.Parameter(torch.randn(1, self.n_tasks, self.dim), requires_grad=True)
+        self.pos_embed = PositionalEncoding(self.dim, dropout=self.dp_rate, max_len=200)
+        self.pe = nn.Parameter(torch.randn(1, 4, self.dim), requires_grad=True)
+        self.embedding = nn.Embedding(len(self.vocab), self.dim)
+        self.seq_len = 200
+        self.y_mask = self.get_tgt_mask(self.seq_len)
+        self._init_parameters()
+        self.k = 1
+        if getattr(args, "lta_cfg_file", None):     # reference :58-73
+            import importlib
+            cfg = importlib.import_module("utils.lta.parser").load_config_from_file(args.lta_cfg_file)
+            self.k = cfg.FORECASTING.NUM_SEQUENCES_TO_PREDICT
+            self.action_model = make_hoi_backbone("slowfast", cfg=cfg, num_classes=[self.dim], with_head=True,
+                                                  ckpt=cfg.CHECKPOINT_FILE_PATH_AR, loader="lta")
+            freeze_backbone_params(self.action_model)
+            lta_cfg = copy.deepcopy(cfg)
+            lta_cfg.FORECASTING.NUM_ACTIONS_TO_PREDICT = 20
+            self.lta_model = make_hoi_backbone("lta", cfg=lta_cfg, build_decoder=True, ckpt=cfg.CHECKPOINT_FILE_PATH_LTA)
+            freeze_params(self.lta_model)
+
+    _init_parameters = TaskPromptTransformer._init_parameters
+    get_tgt_mask = TaskPromptTransformer.get_tgt_mask
+    decode = TaskPromptTransformer.decode
+
+    def encode_clips(self, model, x):
+        assert isinstance(x, list) and len(x) >= 1
+        return torch.stack([model([pathway[:, i] for pathway in x]) for i in range(x[0].shape[1])], dim=1)
+
+    def encode_features(self, task, feat_action, feat_lta=None):
+        """'lta' in task: feat_action, feat_lta (B, n, d) with 2 n == 4 -> memory (2n, B, d); else feat_action (B, 1, d) -> (1, B, d)."""
+        if 'lta' in task:
+            feats = [feat_action, feat_lta]
+            segs, off = [], 0
+            for f in feats:
+                segs.append(SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=False, add_row=None, pos_row0=off))
+                off += f.shape[1]
+            if off != self.pe.shape[1]:
+                raise ValueError(f"token count {off} != {self.pe.shape[1]} learned positions")
+            x = self._egx_encode(feats, segs, encoder=self.transformer_encoder, ln=self.ln, projs=[None, None],
+                                 task_embed=None, pos_table=self.pe[0], p_drop=self.dp_rate)
+        else:
+            segs = [SegmentSpec(T=feat_action.shape[1], d_in=feat_action.shape[2], has_proj=False, add_row=0, pos_row0=0)]
+            x = self._egx_encode([feat_action], segs, encoder=self.transformer_encoder, ln=self.ln, projs=[None],
+                                 task_embed=self.task_embed, pos_table=self.pos_embed.pe, p_drop=self.dp_rate,
+                                 p_pos=self.pos_embed.dropout.p)
+        return x.permute(1, 0, 2)
+
+    def encode(self, video, task):
+        if 'lta' in task:  # only use tokens produced by action models
+            feat_action = self.encode_clips(self.action_model, video)  # (bs, num_input, d)
+            feat_lta = self.lta_model(video, None, middle=True).transpose(0, 1)  # (bs, num_input, d)
+            return self.encode_features(task, feat_action.contiguous(), feat_lta.contiguous())
+        feat_action = self.action_model(video).unsqueeze(1)  # (bs, 1, d)
+        return self.encode_features(task, feat_action)
+
+    def forward(self, video, target, task):
+        assert task in ['action_verb', 'action_noun', 'lta_verb', 'lta_noun']
+        return self.decode(target, self.encode(video, task)).permute(1, 2, 0)
+
+    def predict(self, video, task):
+        assert task in ['action', 'lta']
+        encoded_x = self.encode(video, task)
+        batch_size = encoded_x.shape[1]
+        y_verb = (torch.ones((batch_size, 1)) * self.vocab[task + '_verb']).type_as(video[0]).long()
+        preds_verb = self.decode(y_verb, encoded_x)[0, :, self.v_idx]
+        y_noun = (torch.ones((batch_size, 1)) * self.vocab[task + '_noun']).type_as(video[0]).long()
+        preds_noun = self.decode(y_noun, encoded_x)[0, :, self.n_idx]
+        if task == 'lta':
+            preds_verb = preds_verb.unsqueeze(dim=1)
+            preds_noun = preds_noun.unsqueeze(dim=1)
+        return [preds_verb, preds_noun]
+
+    def generate(self, x):
+        from torch.distributions.categorical import Categorical
+        results = []
+        for head_x in self.predict(x, 'lta'):
+            if self.k > 1:
+                preds_dist = Categorical(logits=head_x)
+                preds = [preds_dist.sample() for _ in range(self.k)]
+            elif self.k == 1:
+                preds = [head_x.argmax(2)]
+            results.append(torch.stack(preds, dim=1))
+        return results

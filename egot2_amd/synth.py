@@ -56,7 +56,8 @@ def _randn(gen, shape, device):
 
 
 def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, layers: int | None = None,
-                  dtype: str | None = None, impl: str = "auto", dropout: float | None = None, seed: int = 1234) -> Dict:
+                  dtype: str | None = None, impl: str = "auto", dropout: float | None = None, seed: int = 1234,
+                  encoder_only: bool = False) -> Dict:
     from . import functional as F_egx
     from .train import CrossEntropyLoss
     name = name.lower()
@@ -147,12 +148,14 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
 
         def loss_fn():
             mem = model.encode_features(task, *feats)
+            if encoder_only:
+                return mem.sum()
             logits = model.decode(y[:, :-1], mem)                       # (sy, B, V)
             return F_egx.weighted_cross_entropy(logits.permute(1, 0, 2).reshape(-1, V), y[:, 1:].reshape(-1))
         fl = encoder_flops(B, segs, d, 2048, L)
         desc = (f"configs[4]: EgoT2-g {'HHI (3 tasks, d=256 h=4)' if name == 'c5hhi' else 'HOI (4 backbones / 6 tasks, d=512 h=8)'} "
-                f"encoder S={S} {L} layers + {ntok}-token sequence decoder + vocabulary CE, B={B}/GPU, dropout={p}; "
-                "FLOPs counted for the encoder only")
+                f"encoder S={S} {L} layers" + ("" if encoder_only else f" + {ntok}-token sequence decoder + vocabulary CE")
+                + f", B={B}/GPU, dropout={p}; FLOPs counted for the encoder only")
     else:
         raise ValueError(f"unknown workload {name!r} (c1, c2, c3, c4, c5hhi, c5hoi)")
     params = [q for q in model.parameters() if q.requires_grad] + list(getattr(model, "extra_params", []))

@@ -202,6 +202,14 @@ int egx_pool_head_bwd(const float* d_out, const float* pooled_saved, int B, int 
 /* y[M,N] = x[M,K] W[N,K]^T + b (+ReLU). */
 int egx_linear_fwd(const float* x, const float* W, const float* b, float* y,
                    int M, int N, int K, int relu, int compute, void* stream);
+/* y = x W^T + b + residual[M,N]: a projection with the residual connection in its epilogue (pre-LN blocks of
+ * HOI/models/pnr/simple_vit.py:104-106: `x = attn(x) + x`, `x = ff(x) + x`). b may be NULL. */
+int egx_linear_residual_fwd(const float* x, const float* W, const float* b, const float* residual, float* y, int M, int N, int K,
+                            int compute, void* stream);
+/* Exact (erf) GELU, nn.GELU() of simple_vit.FeedForward (HOI/models/pnr/simple_vit.py:55-65): h = z Phi(z);
+ * backward dz = dh (Phi(z) + z phi(z)). n %% 4 == 0. */
+int egx_gelu_fwd(const float* z, float* h, size_t n, void* stream);
+int egx_gelu_bwd(const float* z, const float* dh, float* dz, size_t n, void* stream);
 /* dx[M,K] = dy W ; dW[N,K] += dy^T x ; db[N] += colsum(dy). Any output may be NULL.
  * scratch must hold egx_linear_bwd_scratch(M,N,K) bytes. */
 size_t egx_linear_bwd_scratch(int M, int N, int K);

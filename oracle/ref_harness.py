@@ -387,3 +387,82 @@ def hoi_g_encode_lta(model, feat_pnr_clips, feat_action, feat_lta):
 def hoi_g_encode_other(model, task, feat_pnr, feat_oscc, slow, fast):
     model.pnr_model, model.oscc_model = _Pick(0), _Pick(1)
     return model.encode([feat_pnr, feat_oscc], [pathway5d(slow), pathway5d(fast)], task)
+
+
+# ---- F3 remainder: LTA 2-task translator, the pre-LN PNR translator, the 2-task and action EgoT2-g models ---------------
+def ref_lta2(cfg) -> nn.Module:
+    """Real TaskFusionMFTransformer2Task of the LTA task (HOI/models/lta/lta_models_lta_transfer.py:429-526); backbone
+    constructors / loaders patched out. REAL forward(x) with x = [action (B, n, d), lta (B, n, 2048)]: the per-clip
+    action model returns its first input, the LTA model the second one (transposed the way the reference expects)."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.lta.lta_models_lta_transfer as m
+    m.SlowFast = lambda cfg, with_head=True: _AcPass()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _LtaPass2()
+    for name in ("load_ckpt", "load_lta_backbone", "freeze_params", "freeze_backbone_params"):
+        setattr(m, name, lambda *a, **k: None)
+    return m.TaskFusionMFTransformer2Task(cfg)
+
+
+def ref_pnrvit(task="keyframe_localization") -> nn.Module:
+    """Real TaskFusionMFTransformer (HOI/models/pnr/video_model_transfer.py:44-67) over the real simple_vit.Transformer; with
+    empty PRETRAIN.*_CFG the base class builds no backbone. REAL forward(x) on x = [pnr_feat, oscc_feat]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.pnr.video_model_transfer as m
+    from types import SimpleNamespace as NS
+    model = m.TaskFusionMFTransformer(NS(DATA=NS(TASK=task), PRETRAIN=NS(PNR_CFG=None, OSCC_CFG=None, PNR_FT=True, OSCC_FT=True)))
+    model.pnr_model, model.oscc_model = _Pick(0), _Pick(1)
+    return model
+
+
+def _patch_decoder_layer(m):
+    orig = m.CustomDecoderLayer._mha_block
+    if orig.__code__.co_argcount == 5:      # torch >= 2 passes is_causal
+
+        def _mha_block(self, x, mem, attn_mask, key_padding_mask, is_causal=False):
+            return orig(self, x, mem, attn_mask, key_padding_mask)
+        m.CustomDecoderLayer._mha_block = _mha_block
+
+
+def ref_hoi_g2(args, vocab=None) -> nn.Module:
+    """Real TaskTranslationPromptTransformer2Task (HOI/models/multitask/video_model_builder_2task.py:124-167). REAL
+    encode(video_pnr) on video_pnr = [pnr_feat, oscc_feat]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.multitask.video_model_builder_2task as m
+    from types import SimpleNamespace as NS
+    m.load_config_file = lambda path: NS(MISC=NS(CHECKPOINT_FILE_PATH=None), MODEL=NS(NO_TEMP_POOL=False))
+    m.KeyframeLocalizationResNet = lambda cfg: _Pick(0)
+    m.StateChangeClsResNet = lambda cfg: _Pick(1)
+    for name in ("load_checkpoint", "freeze_params"):
+        setattr(m, name, lambda *a, **k: None)
+    _patch_decoder_layer(m)
+    return m.TaskTranslationPromptTransformer2Task(args, vocab or HOI_G_VOCAB)
+
+
+class _AcClip(nn.Module):
+    """action model of the ActionTask EgoT2-g: `model(video)` on the non-lta prompts gets the [action, lta] list and returns
+    clip 0 of the action stream (B, d); per clip (`model([a_i, l_i])`, 2-D inputs) it returns a_i."""
+
+    def forward(self, x, *a, **k):
+        return x[0][:, 0] if x[0].dim() == 3 else x[0]
+
+
+def ref_hoi_ga(args, vocab=None) -> nn.Module:
+    """Real TaskTranslationPromptTransformerActionTask (HOI/models/multitask/video_model_builder_action.py:21-187). REAL
+    encode(video, task) on video = [action (B, n, d), lta (B, n, d)]."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    import models.multitask.video_model_builder_action as m
+    from types import SimpleNamespace as NS
+    m.load_lta_config = lambda path: NS(MODEL=NS(NUM_CLASSES=None, HEAD_ACT=None), CHECKPOINT_FILE_PATH_AR=None,
+                                        CHECKPOINT_FILE_PATH_LTA=None, FORECASTING=NS(NUM_SEQUENCES_TO_PREDICT=1, NUM_ACTIONS_TO_PREDICT=20))
+    m.vocab_idx_to_orig = lambda: (None, None)
+    m.SlowFast = lambda cfg, with_head=True: _AcClip()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _LtaPass2()
+    for name in ("load_checkpoint", "load_lta_backbone", "freeze_params", "freeze_backbone_params"):
+        setattr(m, name, lambda *a, **k: None)
+    _patch_decoder_layer(m)
+    args.ff_dim = 2048
+    return m.TaskTranslationPromptTransformerActionTask(args, vocab or HOI_G_VOCAB)

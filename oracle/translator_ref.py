@@ -224,6 +224,75 @@ def hoi_g_encode(sd, n_heads: int, task: str, feat_pnr, feat_oscc, a, b) -> torc
     return x.permute(1, 0, 2)
 
 
+def lta2_forward(sd, n_heads: int, feat_action, feat_lta, num_classes: Sequence[int]):
+    """TaskFusionMFTransformer2Task.forward of the LTA task (HOI/models/lta/lta_models_lta_transfer.py:505-513) on features:
+    action (B, n, d) used as is, lta (B, n, 2048) through proj_lta (identity when the translator is 2048 wide)."""
+    x = hoi_tokens(sd, [feat_action, feat_lta], [None, "proj_lta" if "proj_lta.weight" in sd else None])
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+    pooled = x.mean(dim=1)
+    z, outs = 0, []
+    while f"head.projections.{z}.weight" in sd:
+        outs.append(linear(pooled, sd[f"head.projections.{z}.weight"], sd[f"head.projections.{z}.bias"]))
+        z += 1
+    return list(torch.split(torch.stack(outs, dim=1), list(num_classes), dim=-1))
+
+
+def gelu(x: torch.Tensor) -> torch.Tensor:
+    """nn.GELU() (exact form): x * Phi(x)."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def vit_forward(sd, heads: int, pnr_feat, oscc_feat) -> torch.Tensor:
+    """TaskFusionMFTransformer.forward (HOI/models/pnr/video_model_transfer.py:58-66) over simple_vit.Transformer
+    (HOI/models/pnr/simple_vit.py:55-107) on features: tokens = cat(proj1(pnr), proj2(oscc)) + pe (NO token-prep LayerNorm);
+    per block x = to_out(softmax(q k^T * dim_head^-0.5) v) + x with q, k, v = to_qkv(norm(x)) (no biases, inner width
+    heads * dim_head), then x = W2 gelu(W1 norm(x) + b1) + b2 + x; head = Linear(LayerNorm(mean_s x))."""
+    x = torch.cat((linear(pnr_feat, sd["proj1.weight"], sd["proj1.bias"]), linear(oscc_feat, sd["proj2.weight"], sd["proj2.bias"])), dim=1) + sd["pe"]
+    B, S, d = x.shape
+    i = 0
+    while f"transformer.layers.{i}.0.to_qkv.weight" in sd:
+        pa, pf = f"transformer.layers.{i}.0.", f"transformer.layers.{i}.1.net."
+        h = layer_norm(x, sd[pa + "norm.weight"], sd[pa + "norm.bias"])
+        qkv = linear(h, sd[pa + "to_qkv.weight"], None)
+        inner = qkv.shape[-1] // 3
+        dh = inner // heads
+        q, k, v = [t.reshape(B, S, heads, dh).permute(0, 2, 1, 3) for t in qkv.split(inner, dim=-1)]
+        dots = (q @ k.transpose(-1, -2)) * dh ** -0.5
+        dots = dots - dots.max(dim=-1, keepdim=True).values
+        p = torch.exp(dots)
+        p = p / p.sum(dim=-1, keepdim=True)
+        o = (p @ v).permute(0, 2, 1, 3).reshape(B, S, inner)
+        x = linear(o, sd[pa + "to_out.weight"], None) + x
+        h = layer_norm(x, sd[pf + "0.weight"], sd[pf + "0.bias"])
+        x = linear(gelu(linear(h, sd[pf + "1.weight"], sd[pf + "1.bias"])), sd[pf + "3.weight"], sd[pf + "3.bias"]) + x
+        i += 1
+    y = layer_norm(x.mean(dim=1), sd["linear_head.0.weight"], sd["linear_head.0.bias"])
+    return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])
+
+
+def hoi_g2_encode(sd, n_heads: int, feat_pnr, feat_oscc) -> torch.Tensor:
+    """TaskTranslationPromptTransformer2Task.encode (HOI/models/multitask/video_model_builder_2task.py:128-140) on features."""
+    pe = sd["pos_embed.pe"][:, 0, :]
+    lw, lb, te = sd["ln.weight"], sd["ln.bias"], sd["task_embed"]
+    x1 = encode_prepare(feat_pnr, sd["proj_pnr.weight"], sd["proj_pnr.bias"], lw, lb, te[0, 0], pe[:feat_pnr.shape[1]])
+    x2 = encode_prepare(feat_oscc, sd["proj_oscc.weight"], sd["proj_oscc.bias"], lw, lb, te[0, 1], pe[:feat_oscc.shape[1]])
+    x = encoder(torch.cat((x1, x2), dim=1), sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    return x.permute(1, 0, 2)
+
+
+def hoi_ga_encode(sd, n_heads: int, task: str, feat_action, feat_lta=None) -> torch.Tensor:
+    """TaskTranslationPromptTransformerActionTask.encode (HOI/models/multitask/video_model_builder_action.py:117-133) on
+    features: 'lta' prompts -> ln(cat(action, lta)) + learned pe (1, 4, d); otherwise ONE action token with task embedding 0
+    and sinusoid position 0."""
+    lw, lb = sd["ln.weight"], sd["ln.bias"]
+    if "lta" in task:
+        x = layer_norm(torch.cat((feat_action, feat_lta), dim=1), lw, lb) + sd["pe"]
+    else:
+        x = encode_prepare(feat_action, None, None, lw, lb, sd["task_embed"][0, 0], sd["pos_embed.pe"][:feat_action.shape[1], 0, :])
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    return x.permute(1, 0, 2)
+
+
 # ---- EgoT2-g sequence decoder + vocabulary head (SURVEY.md §8f row F1) ---------------------------------------------
 def attention(q_in: torch.Tensor, kv_in: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int, causal: bool) -> torch.Tensor:
     """nn.MultiheadAttention math, batch-first: q_in (B, Sq, d), kv_in (B, Sk, d); packed in-projection rows

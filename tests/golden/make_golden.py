@@ -37,6 +37,11 @@ HOI_CASES = [
     dict(name="ar2_B3_L1_d128", kind="ar2", B=3, L=1, d=128, h=4, n=2, classes=[11, 70], wseed=91, fseed=92),
     # HOI EgoT2-g encoder (config C5): REAL encode() of the 6-task model on the 48-token and on the per-clip 'lta' layout
     dict(name="hoig_B2_n3_L2_d256", kind="hoig", B=2, n=3, L=2, d=256, h=8, wseed=95, fseed=96),
+    # row F3 remainder: LTA 2-task translator, pre-LN / GELU PNR translator (simple_vit), 2-task and action EgoT2-g encoders
+    dict(name="lta2_B3_n3_L2_d256", kind="lta2", B=3, n=3, L=2, d=256, h=8, classes=[5, 7], z=3, wseed=101, fseed=102),
+    dict(name="pnrvit_B2_kf", kind="pnrvit", B=2, task="keyframe_localization", wseed=103, fseed=104),
+    dict(name="hoig2_B2_L2_d256", kind="hoig2", B=2, L=2, d=256, h=8, wseed=105, fseed=106),
+    dict(name="hoiga_B3_L2_d128", kind="hoiga", B=3, L=2, d=128, h=4, wseed=107, fseed=108),
 ]
 
 
@@ -124,6 +129,12 @@ def hoi_feat_shapes(c):
     if c["kind"] == "hoig":     # pnr, oscc, slow, fast (48-token layout); per-clip pnr frames, action, lta ('lta' layout)
         n, d = c["n"], c["d"]
         return [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256), (B, n, 1, 8192), (B, n, d), (B, n, 2048)]
+    if c["kind"] == "lta2":
+        return [(B, c["n"], c["d"]), (B, c["n"], 2048)]                            # action, lta
+    if c["kind"] in ("pnrvit", "hoig2"):
+        return [(B, 16, 8192), (B, 16, 8192)]                                      # pnr, oscc
+    if c["kind"] == "hoiga":
+        return [(B, 2, c["d"]), (B, 2, c["d"])]                                    # action, lta (both already d wide)
     raise KeyError(c["kind"])
 
 
@@ -144,11 +155,34 @@ def run_hoi():
             m = rh.ref_hoi_g(rh.hoi_g_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
         elif c["kind"] == "ar3":
             m = rh.ref_ar3(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"]))
+        elif c["kind"] == "lta2":
+            m = rh.ref_lta2(rh.hoi_cfg(d=c["d"], heads=c["h"], layers=c["L"], n_clips=c["n"], num_classes=c["classes"], z=c["z"]))
+        elif c["kind"] == "pnrvit":
+            m = rh.ref_pnrvit(c["task"])
+        elif c["kind"] == "hoig2":
+            m = rh.ref_hoi_g2(rh.hoi_g_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
+        elif c["kind"] == "hoiga":
+            m = rh.ref_hoi_ga(rh.hoi_g_args(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"]))
         else:
             m = rh.ref_ar2(rh.hoi_s_cfg(d=c["d"], layers=c["L"], heads=c["h"], num_classes=c["classes"], n_clips=c["n"]))
         m.load_state_dict(seeded_state_dict(m, c["wseed"]))
         m.train()
-        if c["kind"] == "hoig":
+        if c["kind"] == "lta2":         # REAL forward(x)
+            outs = m([feats[0], feats[1]])
+            named = {"out_verb": outs[0], "out_noun": outs[1]}
+        elif c["kind"] == "pnrvit":     # REAL forward(x) over pass-through PNR / OSCC backbones
+            named = {"out": m([feats[0], feats[1]])}
+        elif c["kind"] == "hoig2":      # REAL encode(video_pnr) + decode
+            m.pos_embed.dropout.p = 0.0
+            enc = m.encode([feats[0], feats[1]])
+            named = {"out": enc, "dec": m.decode(g_targets(c, "pnr", enc.shape[1], len(m.vocab), 2), enc)}
+        elif c["kind"] == "hoiga":      # REAL encode(video, task) on both branches + decode
+            m.pos_embed.dropout.p = 0.0
+            named = {"out_lta": m.encode([feats[0], feats[1]], "lta_verb"), "out_action": m.encode([feats[0], feats[1]], "action_verb")}
+            for task, sy in (("lta", 3), ("action", 2)):
+                enc = named[f"out_{task}"]
+                named[f"dec_{task}"] = m.decode(g_targets(c, task, enc.shape[1], len(m.vocab), sy), enc)
+        elif c["kind"] == "hoig":
             m.pos_embed.dropout.p = 0.0
             named = {"out_pnr": rh.hoi_g_encode_other(m, "pnr", *feats[:4]),
                      "out_lta": rh.hoi_g_encode_lta(m, *feats[4:])}

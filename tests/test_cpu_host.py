@@ -329,3 +329,105 @@ def _overlap_params_worker(rank, world, port, q):
         q.put((n, pa.grad.numpy().copy(), pb.grad.numpy().copy(), raised))
     dist.barrier()
     dist.destroy_process_group()
+
+
+class _StubBackbone(torch.nn.Module):
+    """Factory-built stand-in for a frozen HOI backbone: one parameter (to check freezing), records how it was built."""
+
+    def __init__(self, kind, **kw):
+        super().__init__()
+        self.kind, self.kw = kind, kw
+        self.w = torch.nn.Parameter(torch.ones(1))
+        self.head = torch.nn.Linear(2, 2)                 # "head" parameters stay trainable under freeze_backbone_params
+
+    def forward(self, x, *a, middle=False, **k):
+        B = x[0].shape[0]
+        if self.kind in ("pnr", "oscc"):
+            return torch.zeros(B, 16, 8192)
+        if self.kind == "lta":
+            return torch.zeros(x[0].shape[1], B, 2048)    # (n, B, 2048), transposed by the caller
+        return torch.zeros(B, self.kw["num_classes"][0])  # SlowFast with head: (B, d)
+
+
+def _with_hoi_factories(fn):
+    from egot2_amd import backbones
+    built = []
+    keys = ("hoi_pnr", "hoi_oscc", "hoi_slowfast", "hoi_lta")
+    for key in keys:
+        backbones.register_backbone_factory(key, lambda _k=key[4:], **kw: built.append(_k) or _StubBackbone(_k, **kw))
+    try:
+        return fn(built)
+    finally:
+        for key in keys:
+            backbones._FACTORIES.pop(key, None)
+
+
+def test_hoi_constructors_build_their_backbones():
+    """`Class(cfg)` of the HOI translators must build and freeze its backbones where the reference does
+    (lta_models_lta_transfer.py:279-302, video_model_transfer_3task.py:23-58, video_model_builder.py:98-130), so that the
+    real forward signature works on a stock instance. Backbones come from injected factories; forward() must get as far
+    as the HIP call (which refuses CPU tensors) instead of dying on a missing attribute."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import _lib, hoi_ar, hoi_lta, hoi_multitask, hoi_pnr
+
+    def run(built):
+        cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=2, NUM_ACTIONS_TO_PREDICT=3, INPUT_OFFSET=0),
+                 MODEL=NS(TRANSLATION_HEADS=8, TRANSLATION_LAYERS=1, TRANSLATION_INPUT_FEATURES=256, TRANSLATION_DROPOUT=0.0,
+                          NUM_CLASSES=[5, 7], DROPOUT_RATE=0.0, HEAD_ACT="softmax", FEAT_DROPOUT_RATE=0.0, TRANSFORMER_DROPOUT_RATE=0.0),
+                 TEST=NS(NO_ACT=False), DATA=NS(TASK="state_change_detection"),
+                 PRETRAIN=NS(PNR_CFG="pnr.yaml", OSCC_CFG="oscc.yaml", ACTION_CFG="ar.yaml", LTA_CFG="lta.yaml", PNR_FT=True, OSCC_FT=True, ACTION_FT=True),
+                 CHECKPOINT_FILE_PATH_AR="ar.ckpt", CHECKPOINT_FILE_PATH_LTA="lta.ckpt")
+        m = hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+        assert built == ["pnr", "oscc", "slowfast", "lta"]
+        assert m.oscc_model.kw["no_temp_pool"] is False and m.action_model.kw["num_classes"] == [256] and m.lta_model.kw["build_decoder"] is True
+        assert not m.pnr_model.w.requires_grad and not m.lta_model.w.requires_grad
+        assert not m.action_model.w.requires_grad and m.action_model.head.weight.requires_grad      # head stays trainable
+        # xavier init ran BEFORE the backbones were attached: their parameters are untouched
+        assert m.pnr_model.w.item() == 1.0
+        x_lta = [torch.zeros(2, 2, 3, 8, 4, 4), torch.zeros(2, 2, 3, 32, 4, 4)]
+        with pytest.raises(_lib.EgxError, match="no CPU fallback"):
+            m(x_lta, torch.zeros(2, 2, 3, 16, 4, 4))                                           # real forward(x_lta, x_pnr)
+        del built[:]
+        m2 = hoi_lta.TaskFusionMFTransformer2Task(cfg)
+        assert built == ["slowfast", "lta"] and m2.lta_model.kw["build_decoder"] is False
+        with pytest.raises(_lib.EgxError, match="no CPU fallback"):
+            m2(x_lta)
+        del built[:]
+        p = hoi_pnr.TaskFusionMFTransformer3TaskDropout(cfg)
+        assert built == ["pnr", "oscc", "slowfast"] and p.oscc_model.kw["no_temp_pool"] is True
+        assert p.recognition_model.kw["with_head"] is False and p.recognition_model.kw["loader"] == "recognition"
+        assert not p.pnr_model.training                                                        # .eval() as the reference does under *_FT
+        del built[:]
+        v = hoi_pnr.TaskFusionMFTransformer(cfg)
+        assert built == ["pnr", "oscc"]
+        with pytest.raises(_lib.EgxError, match="no CPU fallback"):
+            v([torch.zeros(2, 3, 16, 4, 4)])                                                   # real forward(x)
+        del built[:]
+        a3 = hoi_ar.TaskFusionMFTransformer3Task(cfg)
+        a2 = hoi_ar.TaskFusionMFTransformer2TaskAR(cfg)
+        assert built == ["pnr", "oscc", "slowfast", "slowfast", "lta"] and hasattr(a3, "recognition_model") and hasattr(a2, "lta_model")
+        del built[:]
+        args = NS(hidden_dim=256, num_heads=8, num_layers=1, dropout=0.0, pnr_cfg_file="p", oscc_cfg_file="o", action_cfg_file="a", lta_cfg_file="l")
+        from egot2_amd.synth import HOI_G_VOCAB
+        g = hoi_multitask.TaskTranslationPromptTransformer6Task(args, HOI_G_VOCAB)
+        assert built == ["pnr", "oscc", "slowfast", "lta"] and g.recognition_model.kw["num_classes"] == [256]
+        del built[:]
+        g2 = hoi_multitask.TaskTranslationPromptTransformer2Task(args, HOI_G_VOCAB)
+        assert built == ["pnr", "oscc"] and g2.oscc_model.kw["no_temp_pool"] is True
+        with pytest.raises(_lib.EgxError, match="no CPU fallback"):
+            g2([torch.zeros(2, 3, 16, 4, 4)], torch.zeros(2, 2, dtype=torch.long))             # real forward(video_pnr, target)
+        return True
+
+    assert _with_hoi_factories(run)
+
+
+def test_hoi_backbone_without_reference_tree_or_factory_raises():
+    """A config that names a backbone, outside the reference tree and with no factory registered: loud ImportError."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import hoi_lta
+    cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=2, NUM_ACTIONS_TO_PREDICT=3),
+             MODEL=NS(TRANSLATION_HEADS=8, TRANSLATION_LAYERS=1, TRANSLATION_INPUT_FEATURES=256, TRANSLATION_DROPOUT=0.0,
+                      NUM_CLASSES=[5, 7], DROPOUT_RATE=0.0, HEAD_ACT="softmax"), TEST=NS(NO_ACT=False),
+             PRETRAIN=NS(PNR_CFG="pnr.yaml", OSCC_CFG=None))
+    with pytest.raises(ImportError, match="register_backbone_factory"):
+        hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)

@@ -43,9 +43,23 @@ def hip_run(c, model, feats):
     if c["kind"] == "pnr3":
         out = model.forward_features(*feats)
         return {"out": out}, lin(out)
-    if c["kind"] in ("ar3", "ar2"):
+    if c["kind"] in ("ar3", "ar2", "lta2"):
         o = model.forward_features(*feats)
         return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1])
+    if c["kind"] == "pnrvit":
+        out = model.forward_features(*feats)
+        return {"out": out}, lin(out)
+    if c["kind"] == "hoig2":
+        enc = model.encode_features(*feats)
+        outs = {"out": enc, "dec": model.decode(g_targets(c, "pnr", enc.shape[1], 12, 2).to(enc.device), enc)}
+        return outs, sum(lin(v) for v in outs.values())
+    if c["kind"] == "hoiga":
+        outs = {"out_lta": model.encode_features("lta_verb", feats[0], feats[1]),
+                "out_action": model.encode_features("action_verb", feats[0][:, 0:1].contiguous())}
+        for task, sy in (("lta", 3), ("action", 2)):
+            enc = outs[f"out_{task}"]
+            outs[f"dec_{task}"] = model.decode(g_targets(c, task, enc.shape[1], 12, sy).to(enc.device), enc)
+        return outs, sum(lin(v) for v in outs.values())
     raise KeyError(c["kind"])
 
 

@@ -53,6 +53,21 @@ def build_ours(c):
         from oracle.ref_harness import HOI_G_VOCAB
         return hoi_multitask.TaskTranslationPromptTransformer6Task(
             NS(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"], dropout=0.0), HOI_G_VOCAB)
+    if c["kind"] == "lta2":
+        from egot2_amd import hoi_lta
+        cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=c["n"], NUM_ACTIONS_TO_PREDICT=c["z"]),
+                 MODEL=NS(TRANSLATION_HEADS=c["h"], TRANSLATION_LAYERS=c["L"], TRANSLATION_INPUT_FEATURES=c["d"],
+                          TRANSLATION_DROPOUT=0.0, NUM_CLASSES=c["classes"], DROPOUT_RATE=0.0, HEAD_ACT="softmax"),
+                 TEST=NS(NO_ACT=False))
+        return hoi_lta.TaskFusionMFTransformer2Task(cfg)
+    if c["kind"] == "pnrvit":
+        from egot2_amd import hoi_pnr
+        return hoi_pnr.TaskFusionMFTransformer(NS(DATA=NS(TASK=c["task"])))
+    if c["kind"] in ("hoig2", "hoiga"):
+        from egot2_amd import hoi_multitask
+        from oracle.ref_harness import HOI_G_VOCAB
+        cls = hoi_multitask.TaskTranslationPromptTransformer2Task if c["kind"] == "hoig2" else hoi_multitask.TaskTranslationPromptTransformerActionTask
+        return cls(NS(hidden_dim=c["d"], num_heads=c["h"], num_layers=c["L"], dropout=0.0, ff_dim=2048), HOI_G_VOCAB)
     if c["kind"] in ("ar3", "ar2"):
         from egot2_amd import hoi_ar
         cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=c.get("n", 2), INPUT_OFFSET=0),
@@ -87,6 +102,12 @@ def fixture_feats(c):
         # is the channel-reversed PNR stream (oracle/ref_harness.py _Flip)
         pnr_clips = f[4][:, :, 0, :].contiguous()
         return f[:4] + [pnr_clips, pnr_clips.flip(-1).contiguous(), f[5], f[6]]
+    if c["kind"] == "lta2":
+        return seeded_feats(c["fseed"], [(B, c["n"], c["d"]), (B, c["n"], 2048)])
+    if c["kind"] in ("pnrvit", "hoig2"):
+        return seeded_feats(c["fseed"], [(B, 16, 8192), (B, 16, 8192)])
+    if c["kind"] == "hoiga":
+        return seeded_feats(c["fseed"], [(B, 2, c["d"]), (B, 2, c["d"])])
     return seeded_feats(c["fseed"], [(c["B"], c["T"], 256)] * c["n_tasks"])
 
 
@@ -122,6 +143,23 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
     if c["kind"] == "hoig":
         outs = {"out_pnr": tr.hoi_g_encode(sdd, c["h"], "pnr", *f[:4]), "out_lta": tr.hoi_g_encode(sdd, c["h"], "lta_verb", *f[4:])}
         for task, sy in (("pnr", 2), ("lta", 4)):
+            enc = outs[f"out_{task}"]
+            outs[f"dec_{task}"] = tr.g_decode(sdd, c["h"], g_targets(c, task, enc.shape[1], 12, sy), enc)
+        return outs, sum(lin(v) for v in outs.values()), sdd
+    if c["kind"] == "lta2":
+        o = tr.lta2_forward(sdd, c["h"], f[0], f[1], c["classes"])
+        return {"out_verb": o[0], "out_noun": o[1]}, lin(o[0]) + lin(o[1]), sdd
+    if c["kind"] == "pnrvit":
+        out = tr.vit_forward(sdd, 8, f[0], f[1]).unsqueeze(1 if c["task"] == "keyframe_localization" else 2)
+        return {"out": out}, lin(out), sdd
+    if c["kind"] == "hoig2":
+        enc = tr.hoi_g2_encode(sdd, c["h"], f[0], f[1])
+        outs = {"out": enc, "dec": tr.g_decode(sdd, c["h"], g_targets(c, "pnr", enc.shape[1], 12, 2), enc)}
+        return outs, sum(lin(v) for v in outs.values()), sdd
+    if c["kind"] == "hoiga":
+        outs = {"out_lta": tr.hoi_ga_encode(sdd, c["h"], "lta_verb", f[0], f[1]),
+                "out_action": tr.hoi_ga_encode(sdd, c["h"], "action_verb", f[0][:, 0:1])}
+        for task, sy in (("lta", 3), ("action", 2)):
             enc = outs[f"out_{task}"]
             outs[f"dec_{task}"] = tr.g_decode(sdd, c["h"], g_targets(c, task, enc.shape[1], 12, sy), enc)
         return outs, sum(lin(v) for v in outs.values()), sdd
