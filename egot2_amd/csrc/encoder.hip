@@ -214,7 +214,7 @@ static bool use_wide(const egx_config* cfg, const egx_segment* segs, const Plan&
     *err = false;
     const bool ok = wide_ok(cfg, segs, pl.B);
     if (cfg->impl == EGX_IMPL_WIDE) {
-        if (!ok) { set_error("wide implementation does not support this configuration (needs compute = bf16, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128)"); *err = true; }
+        if (!ok) { set_error("wide implementation does not support this configuration (needs compute = bf16, d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128)"); *err = true; }
         return ok;
     }
     return cfg->impl == EGX_IMPL_AUTO && ok && !fused_ok(cfg, segs, pl);

@@ -5,7 +5,7 @@
 
 namespace egx {
 
-// bf16 compute, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128
+// bf16 compute, d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128
 bool wide_ok(const egx_config* cfg, const egx_segment* segs, int B);
 void wide_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved, size_t* scratch);
 int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float* ln_w, const float* ln_b, const egx_layer* layers,

@@ -144,7 +144,7 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
  * 0 for the shape-generic kernels (which consume d_tokens). */
 int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B);
 /* Which kernels this configuration runs on: EGX_IMPL_FUSED (per-clip kernels: d = 128, h = 4, S <= 48), EGX_IMPL_WIDE
- * (compute = bf16 with d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128: all B*S tokens
+ * (compute = bf16 with d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128: all B*S tokens
  * through bf16-storage MFMA GEMMs and MFMA attention - BASELINE.json configs[3], configs[4]) or EGX_IMPL_GENERIC; -1 on an
  * invalid configuration. */
 int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B);
