@@ -1,6 +1,7 @@
 """-m gpu: the HIP translator classes against the golden fixtures generated from the REAL reference (outputs and
 gradient digests), through the C ABI of libegot2x.so. fp32: outputs within 1e-3, gradients within 1e-2 relative
-(BASELINE.json:north_star); bf16: 1e-2 / 1e-1."""
+(BASELINE.json:north_star); bf16: 1e-2 / 6e-2 (measured worst gradient-norm error 5.6e-2 on the 4-token
+EgoT2-g action fixture, <= 1.1e-2 on most; tools/bf16_err_report.py)."""
 import numpy as np
 import pytest
 import torch
@@ -63,7 +64,7 @@ def hip_run(c, model, feats):
     raise KeyError(c["kind"])
 
 
-@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 1e-1)])
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 6e-2)])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_hip_matches_reference_fixture(egx_lib, cuda, name, compute, tol_out, tol_grad):
     c, z = load_fixture(name)

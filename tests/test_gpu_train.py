@@ -263,3 +263,60 @@ def test_run_ttm_synth_plumbing_entry(egx_lib, cuda):
         losses = mod.main(["--model", name, "--num_layers", "1", "--hidden_dim", "128", "--dropout", "0.1", "--steps", "24",
                            "--lr", "2e-3"])
         assert all(l == l for l in losses) and sum(losses[-4:]) < sum(losses[:4])
+
+
+def _hip_ddp_worker(rank, world, port, q, overlapped):
+    """One rank of the 2-rank data-parallel step on the REAL HIP backward (both ranks share cuda:0; gloo moves the CUDA
+    buffers through the host, which is enough to pin the flat-buffer layout and the exchange logic)."""
+    import os
+    import torch.distributed as dist
+    from egot2_amd import ddp, functional as F_egx
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    m = _ttm(dev, 12)
+    ddp.broadcast_parameters(m)
+    feats = seeded_feats(41, [(8, 15, 256)] * 3)
+    y = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    sf = [f.to(dev) for f in ddp.shard_batch(feats, rank, world)]
+    sy = ddp.shard_batch([y], rank, world)[0].to(dev)
+    m.egx_defer_small = overlapped
+    loss = torch.nn.functional.cross_entropy(m.forward_features(*sf), sy)       # unweighted: rank means average exactly
+    loss.backward()
+    params = [p for p in m.parameters() if p.grad is not None]
+    if overlapped:
+        n = ddp.allreduce_gradients_overlapped(F_egx.run_deferred, params)
+    else:
+        n = ddp.allreduce_gradients(params)
+    torch.cuda.synchronize()
+    one_storage = len({p.grad.untyped_storage().data_ptr() for p in params}) == 1
+    if rank == 0:
+        q.put((n, one_storage, {k: p.grad.cpu().numpy().copy() for k, p in m.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, overlapped):
+    """the N-rank leg on the HIP backward itself (not the stock module): rank-sharded clips, ONE flat
+    gradient buffer per rank straight out of the fused backward, one all-reduce (or the overlapped early / late pair),
+    result == the single-process gradient on the concatenated batch."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + os.getpid() % 2000 + (7 if overlapped else 0)
+    procs = [ctx.Process(target=_hip_ddp_worker, args=(r, 2, port, q, overlapped)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, one_storage, grads = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert one_storage and n == (2 if overlapped else 1)      # every gradient of the translator lives in one flat buffer
+    m = _ttm(cuda, 12)
+    feats = [f.to(cuda) for f in seeded_feats(41, [(8, 15, 256)] * 3)]
+    y = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1], device=cuda)
+    torch.nn.functional.cross_entropy(m.forward_features(*feats), y).backward()
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad.cpu(), torch.from_numpy(grads[k]), rtol=2e-3, atol=2e-6), k

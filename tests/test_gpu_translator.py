@@ -20,11 +20,14 @@ def _oracle_ttm(sd, n_heads, feats, target):
     return logits.detach(), loss.detach(), {k: v.grad for k, v in sd64.items() if v.grad is not None}
 
 
-# bf16 gradients: ReLU-mask sign flips of near-zero pre-activations dominate (relative error ~ sqrt(flipped fraction))
+# bf16 gradients against the fp64 oracle on UNROUNDED operands: measured worst per-parameter relative errors are 1.5e-2 ..
+# 7.4e-2 over these shapes (tools/bf16_grad_report.py; the largest on the 3-clip / 7-frame case, where a handful of ReLU
+# sign flips of near-zero pre-activations moves a bias gradient), median 3e-3 .. 4.6e-2. Bound: 8e-2 (round 1: 1e-1).
+# Dropout scaling in bf16 is pinned separately by test_bf16_matches_fp32_under_the_same_dropout_masks.
 @pytest.mark.parametrize("impl", ["generic", "fused"])
 # fp32 gradients: 1e-2 relative — a single ReLU pre-activation within 1e-6 of zero flips between the
 # fp32 kernels and the fp64 oracle and moves a weight gradient by ~1e-3; everything else agrees to ~1e-6.
-@pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 1e-1)])
+@pytest.mark.parametrize("compute,tol_logit,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 8e-2)])
 @pytest.mark.parametrize("n_tasks,B,T,L", [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1), (3, 6, 16, 2),
                                            # edges: one clip of one frame per task, S = 48 with 4 layers, short ragged
                                            # tiles with an odd clip count, one clip more than the CU count
@@ -100,3 +103,29 @@ def test_fused_forward_vs_oracle(egx_lib, cuda, compute, tol, n_tasks, B, T, L):
     rel = lambda a, b: ((a.double().cpu() - b.double().cpu()).abs() / b.double().cpu().abs().clamp(min=1.0)).max().item()  # noqa: E731
     assert rel(fused, ref) < tol, f"fused vs oracle {rel(fused, ref)}"
     assert rel(fused, generic) < 2 * tol
+
+
+@pytest.mark.parametrize("impl", ["generic", "fused"])
+def test_bf16_matches_fp32_under_the_same_dropout_masks(egx_lib, cuda, impl):
+    """Train mode, p = 0.5 (+0.1 on the positional encoding): the masks are counter-based (seed, site, row, column), so the
+    fp32 and the bf16 kernels draw IDENTICAL masks for the same seed and their outputs / gradients may differ by bf16
+    rounding only. A mis-scaled or mis-keyed dropout in one precision (which the p = 0 oracle tests cannot see) shows up
+    here as an O(1) difference."""
+    from egot2_amd import hhi_ttm
+    res = {}
+    for compute in ("f32", "bf16"):
+        torch.manual_seed(1234)
+        model = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=2, dropout=0.5))
+        model.load_state_dict(seeded_state_dict(model, seed=77))
+        model = model.to(cuda).set_compute(compute, impl).train()
+        model._egx_step = 0
+        feats = [f.to(cuda) for f in seeded_feats(78, [(16, 15, 256)] * 3)]
+        target = torch.arange(16, device=cuda) % 2
+        logits = model.forward_features(*feats)
+        torch.nn.functional.cross_entropy(logits, target, weight=torch.tensor(CE_W, device=cuda)).backward()
+        res[compute] = (logits.detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b = res["f32"], res["bf16"]
+    assert (a[0] - b[0]).abs().max().item() < 2e-2 * max(1.0, a[0].abs().max().item())
+    errs = {k: rel_err(b[1][k], a[1][k]) for k in a[1]}
+    bad = {k: v for k, v in errs.items() if not v < 8e-2}
+    assert not bad, bad

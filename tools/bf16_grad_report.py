@@ -1,0 +1,23 @@
+import sys, torch, numpy as np
+sys.path.insert(0, "/root/repo")
+from oracle import translator_ref as tr
+from tests.util import hhi_args, rel_err, seeded_feats, seeded_state_dict
+from egot2_amd import hhi_ttm
+dev = torch.device("cuda:0"); CE_W = [0.266, 0.734]
+def bf(t): return t.to(torch.bfloat16).to(t.dtype)
+for impl in ("generic", "fused"):
+  for (n_tasks, B, T, L) in [(3, 8, 15, 1), (2, 32, 15, 1), (3, 5, 23, 2), (3, 256, 15, 1), (3, 6, 16, 2), (3, 1, 1, 1), (3, 1, 16, 4), (2, 3, 7, 3), (3, 257, 3, 1)]:
+    if impl == "fused" and n_tasks * T > 48: continue
+    cls = hhi_ttm.TaskFusionMFTransformer3Task if n_tasks == 3 else hhi_ttm.TaskFusionMFTransformer2Task
+    model = cls(hhi_args(num_layers=L)); sd = seeded_state_dict(model, seed=100 + n_tasks + B); model.load_state_dict(sd)
+    model = model.to(dev).set_compute("bf16", impl).train(); model.pos_embed.dropout.p = 0.0
+    feats = seeded_feats(7 + B, [(B, T, 256)] * n_tasks)
+    target = torch.from_numpy(np.random.default_rng(B).integers(0, 2, B)).long()
+    logits = model.forward_features(*[f.to(dev) for f in feats])
+    torch.nn.functional.cross_entropy(logits, target.to(dev), weight=torch.tensor(CE_W, device=dev)).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats]); tr.weighted_ce(ref, target, CE_W).backward()
+    named = dict(model.named_parameters())
+    errs = {k: rel_err(named[k].grad, v.grad) for k, v in sd64.items() if v.grad is not None}
+    w = max(errs, key=errs.get)
+    print(impl, (n_tasks, B, T, L), "worst", w, round(errs[w], 4), "median", round(float(np.median(list(errs.values()))), 4))
