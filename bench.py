@@ -69,6 +69,8 @@ def parse_args(argv=None):
                     help="exercise only the launcher plumbing (rank spawn, process group on --backend, barrier, max-over-ranks timing, JSON relay) without the model; CPU-runnable")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo only for --launch-selftest)")
     ap.add_argument("--encoder-only", action="store_true", help="c5*: time the task-translation encoder alone (loss = sum of the memory), without the sequence decoder + vocabulary CE")
+    ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"], help="c4: dtype of the backbone features handed to the translator (row F4)")
+    ap.add_argument("--feat-frames", type=int, default=1, help="c4: per-frame PNR / OSCC features, this many frames per clip, temporal mean fused into the hand-off")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -184,7 +186,8 @@ def run(args) -> int:
     lib = _lib.load()
 
     wl = synth.make_workload(args.config, dev, batch=args.batch, frames=args.frames, layers=args.layers or None,
-                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only)
+                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
+                             feat_dtype=args.feat_dtype, feat_frames=args.feat_frames)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
     ddp.broadcast_parameters(model)

@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 5
+EGX_ABI_VERSION = 6
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16 = 0, 1
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
@@ -20,7 +20,7 @@ _fp = C.c_void_p  # all device pointers travel as raw addresses
 
 class Segment(C.Structure):
     _fields_ = [("feat", _fp), ("T", C.c_int), ("d_in", C.c_int), ("proj_w", _fp), ("proj_b", _fp),
-                ("add_vec", _fp), ("pos", _fp), ("pos_stride", C.c_int)]
+                ("add_vec", _fp), ("pos", _fp), ("pos_stride", C.c_int), ("feat_bf16", C.c_int), ("pool", C.c_int)]
 
 
 class SegmentGrads(C.Structure):

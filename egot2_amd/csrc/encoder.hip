@@ -63,6 +63,8 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
         EGX_CHECK(segs[i].T > 0, "segment %d has T=%d", i, segs[i].T);
         EGX_CHECK(segs[i].d_in > 0, "segment %d has d_in=%d", i, segs[i].d_in);
         EGX_CHECK(segs[i].proj_w || segs[i].d_in == pl.d, "segment %d: identity projection needs d_in == d_model", i);
+        EGX_CHECK(segs[i].pool >= 0 && (segs[i].proj_w || (!segs[i].feat_bf16 && segs[i].pool <= 1)),
+                  "segment %d: bf16 / frame-pooled features need a projection", i);
         pl.seg_off[i] = S;
         S += segs[i].T;
     }
@@ -110,8 +112,14 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
 }
 
 // ---- fused per-clip path (fused.hip) ---------------------------------------------------------------
+static bool packed_feats(const egx_segment* segs, int nseg) {
+    for (int i = 0; i < nseg; ++i)
+        if (segs[i].feat_bf16 || segs[i].pool > 1) return true;
+    return false;
+}
 static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     if (pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1) return false;
+    if (packed_feats(segs, pl.nseg)) return false;
     if (cfg->p_feat > 0.f) return false;
     int d_in[EGX_MAX_SEGMENTS], T[EGX_MAX_SEGMENTS];
     bool hp[EGX_MAX_SEGMENTS];
@@ -473,6 +481,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     }
     EGX_CHECK(!(cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)),
               "device-resident dropout seed (seed_ptr) is only supported by the fused kernels");
+    EGX_CHECK(!packed_feats(segs, pl.nseg), "bf16 / frame-pooled features (egx_segment.feat_bf16 / pool) are only supported by the wide bf16 path");
 
     // generic path with a head: tokens and the pooled vector live behind the layer intermediates in `saved`
     float* head_pooled = nullptr;

@@ -36,6 +36,9 @@ int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st);
 // dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32
 int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st);
 
+// dst[r][c] = bf16(mean_{j < pool} src[r * pool + j][c]); src fp32 or bf16 (R * pool, C), dst (R, C) bf16. C % 8 == 0.
+int wide_pool_cast(const void* src, int src_bf16, int R, int pool, int C, bf16_t* dst, hipStream_t st);
+
 // Row kernels with bf16 side outputs --------------------------------------------------------------------------------
 // y[orow] = dropout(LN(x[row]) * w + b + add_vec + pos[t]); y32 and / or y16 written; stats (mean, rstd) saved.
 struct WideLnFwdParams {

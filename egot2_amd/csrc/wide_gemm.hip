@@ -469,4 +469,42 @@ int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t
     return 0;
 }
 
+// ---- feature hand-off: temporal mean over `pool` frames fused with the cast to the projection operand -----------------
+template <bool SRC_BF16>
+__global__ __launch_bounds__(256) void wide_pool_cast_kernel(const void* __restrict__ src, int R, int pool, int C, bf16_t* __restrict__ dst) {
+    const int c8 = C / 8;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * c8) return;
+    const int r = (int)(i / c8), c = (int)(i % c8) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < pool; ++j) {
+        const size_t row = (size_t)r * pool + j;
+        if constexpr (SRC_BF16) {
+            uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + row * C + c);
+            acc[0] += bf2f((bf16_t)(v.x & 0xffffu)); acc[1] += bf2f((bf16_t)(v.x >> 16));
+            acc[2] += bf2f((bf16_t)(v.y & 0xffffu)); acc[3] += bf2f((bf16_t)(v.y >> 16));
+            acc[4] += bf2f((bf16_t)(v.z & 0xffffu)); acc[5] += bf2f((bf16_t)(v.z >> 16));
+            acc[6] += bf2f((bf16_t)(v.w & 0xffffu)); acc[7] += bf2f((bf16_t)(v.w >> 16));
+        } else {
+            const float* p = reinterpret_cast<const float*>(src) + row * C + c;
+            float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
+    }
+    const float s = 1.f / (float)pool;
+    *reinterpret_cast<uint4*>(dst + (size_t)r * C + c) =
+        make_uint4(pack2(acc[0] * s, acc[1] * s), pack2(acc[2] * s, acc[3] * s), pack2(acc[4] * s, acc[5] * s), pack2(acc[6] * s, acc[7] * s));
+}
+
+int wide_pool_cast(const void* src, int src_bf16, int R, int pool, int C, bf16_t* dst, hipStream_t st) {
+    EGX_CHECK(src && dst && C % 8 == 0 && pool >= 1, "wide_pool_cast: bad arguments");
+    if (R <= 0) return 0;
+    const size_t n = (size_t)R * (C / 8);
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (src_bf16) hipLaunchKernelGGL(wide_pool_cast_kernel<true>, dim3(blocks), dim3(256), 0, st, src, R, pool, C, dst);
+    else hipLaunchKernelGGL(wide_pool_cast_kernel<false>, dim3(blocks), dim3(256), 0, st, src, R, pool, C, dst);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace egx

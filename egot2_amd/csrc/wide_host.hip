@@ -46,7 +46,8 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
         size_t rows = (size_t)B * segs[i].T;
         if (segs[i].proj_w) {
             pl.seg_w[i] = take(cur, d * segs[i].d_in * 2);
-            pl.seg_feat16[i] = take(cur, rows * segs[i].d_in * 2);
+            // bf16 copy of the features (the projection GEMM's operand); features that arrive in bf16 and un-pooled are used in place
+            if (!(segs[i].feat_bf16 && segs[i].pool <= 1)) pl.seg_feat16[i] = take(cur, rows * segs[i].d_in * 2);
             pl.seg_pre[i] = take(cur, rows * d * 4);
         }
         pl.seg_stats[i] = take(cur, rows * 2 * 4);
@@ -151,10 +152,11 @@ int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float
         const float* pre = sg.feat;
         if (sg.proj_w) {
             bf16_t* w16 = at<bf16_t>(saved, pl.seg_w[i]);
-            bf16_t* f16 = at<bf16_t>(saved, pl.seg_feat16[i]);
+            const bool in_place = sg.feat_bf16 && sg.pool <= 1;
+            const bf16_t* f16 = in_place ? reinterpret_cast<const bf16_t*>(sg.feat) : at<bf16_t>(saved, pl.seg_feat16[i]);
             float* po = at<float>(saved, pl.seg_pre[i]);
             if (wide_cast(sg.proj_w, d, sg.d_in, sg.d_in, w16, nullptr, st)) return 1;
-            if (wide_cast(sg.feat, rows, sg.d_in, sg.d_in, f16, nullptr, st)) return 1;
+            if (!in_place && wide_pool_cast(sg.feat, sg.feat_bf16, rows, sg.pool > 1 ? sg.pool : 1, sg.d_in, at<bf16_t>(saved, pl.seg_feat16[i]), st)) return 1;
             WideGemmParams g;
             g.A = f16; g.B = w16; g.M = rows; g.N = d; g.K = sg.d_in; g.lda = sg.d_in; g.ldb = sg.d_in;
             g.Cf = po; g.ldc = d; g.bias = sg.proj_b; g.zero_page = zero;
@@ -361,7 +363,8 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
         }
         b.dw = d_ln_w; b.db = d_ln_b; b.dadd = sgr.add_vec; b.dbias = sg.proj_w ? sgr.proj_b : nullptr;
         if (wide_ln_bwd(b, lnpart, st)) return 1;
-        if (sg.proj_w && dw_tn(dseg16, d, cat<bf16_t>(saved, pl.seg_feat16[i]), sg.d_in, sgr.proj_w, d, sg.d_in, rows)) return 1;
+        const bf16_t* f16 = (sg.feat_bf16 && sg.pool <= 1) ? reinterpret_cast<const bf16_t*>(sg.feat) : cat<bf16_t>(saved, pl.seg_feat16[i]);
+        if (sg.proj_w && dw_tn(dseg16, d, f16, sg.d_in, sgr.proj_w, d, sg.d_in, rows)) return 1;
     }
     return 0;
 }

@@ -26,6 +26,7 @@ class SegmentSpec:
     has_proj: bool
     add_row: Optional[int] = None      # row of the (1, K, d) task-embedding table, or None
     pos_row0: Optional[int] = None     # first row of the positional table used by this segment, or None
+    pool: int = 1                      # > 1: the feature tensor holds T * pool frames, token t = mean of frames [t pool, (t+1) pool)
 
 
 @dataclass
@@ -55,6 +56,9 @@ class EncoderSpec:
 
 
 _scratch_cache = {}
+# EGX_POISON=1 (testing aid): every workspace handed to the library is filled with 0xFF bytes (NaN in fp32 and bf16) first,
+# so that a kernel reading memory nobody wrote shows up as NaNs instead of passing on whatever the allocator left there
+_POISON = bool(int(__import__("os").environ.get("EGX_POISON", "0") or 0))
 
 
 def _workspace(tag: str, device: torch.device, nbytes: int) -> torch.Tensor:
@@ -64,6 +68,8 @@ def _workspace(tag: str, device: torch.device, nbytes: int) -> torch.Tensor:
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         _scratch_cache[key] = buf
+    if _POISON:
+        buf.fill_(255)
     return buf
 
 
@@ -77,6 +83,16 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
                             "(no CPU fallback)")
     if t.dtype != torch.float32:
         raise _lib.EgxError(f"{name} has dtype {t.dtype}; libegot2x stores activations and weights in fp32")
+    return t.contiguous()
+
+
+def _dev_feat(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Backbone features: fp32, or bf16 in the packed layout the wide path's projection GEMM reads."""
+    if not t.is_cuda:
+        raise _lib.EgxError(f"{name} is on {t.device}: the translator runs only on the GPU through libegot2x.so "
+                            "(no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.EgxError(f"{name} has dtype {t.dtype}; features are fp32 or bf16")
     return t.contiguous()
 
 
@@ -114,6 +130,8 @@ class _GradPacker:
         self.total = cur
         n = max(cur, 4)
         flat = torch.zeros(n, dtype=torch.float32, device=device) if zero else torch.empty(n, dtype=torch.float32, device=device)
+        if _POISON and not zero:
+            flat.fill_(float("nan"))
         self.flat = flat
         out = []
         for i, e in enumerate(self.entries):
@@ -155,7 +173,7 @@ class EncoderFn(torch.autograd.Function):
     def forward(ctx, spec: EncoderSpec, task_embed, pos_table, ln_w, ln_b, *rest):
         lib = _lib.load()
         nseg = len(spec.segments)
-        feats = [_dev_f32(t, f"feats[{i}]") for i, t in enumerate(rest[:nseg])]
+        feats = [_dev_feat(t, f"feats[{i}]") for i, t in enumerate(rest[:nseg])]
         nproj = sum(1 for s in spec.segments if s.has_proj)
         proj = [_dev_f32(t, "projection weight") for t in rest[nseg:nseg + 2 * nproj]]
         nhead = 4 if spec.head_n_out else 0
@@ -175,11 +193,13 @@ class EncoderFn(torch.autograd.Function):
         segs = (Segment * nseg)()
         pi = 0
         for i, (ss, f) in enumerate(zip(spec.segments, feats)):
-            if f.dim() != 3 or f.shape[0] != B or f.shape[1] != ss.T or f.shape[2] != ss.d_in:
-                raise _lib.EgxError(f"feats[{i}] has shape {tuple(f.shape)}, expected ({B}, {ss.T}, {ss.d_in})")
+            if f.dim() != 3 or f.shape[0] != B or f.shape[1] != ss.T * max(ss.pool, 1) or f.shape[2] != ss.d_in:
+                raise _lib.EgxError(f"feats[{i}] has shape {tuple(f.shape)}, expected ({B}, {ss.T * max(ss.pool, 1)}, {ss.d_in})")
             segs[i].feat = ptr(f)
             segs[i].T = ss.T
             segs[i].d_in = ss.d_in
+            segs[i].feat_bf16 = int(f.dtype == torch.bfloat16)
+            segs[i].pool = int(ss.pool)
             if ss.has_proj:
                 w, b = proj[2 * pi], proj[2 * pi + 1]
                 if tuple(w.shape) != (d, ss.d_in):
@@ -218,6 +238,8 @@ class EncoderFn(torch.autograd.Function):
         S = sum(s.T for s in spec.segments)
         if needs_grad:
             saved = torch.empty(max(sv.value, 256), dtype=torch.uint8, device=device)
+            if _POISON:
+                saved.fill_(255)
         else:
             saved = _workspace("saved", device, sv.value)
         scratch = _workspace("scratch", device, sc.value)
@@ -284,6 +306,8 @@ class EncoderFn(torch.autograd.Function):
             segs[i].feat = ptr(f)
             segs[i].T = ss.T
             segs[i].d_in = ss.d_in
+            segs[i].feat_bf16 = int(f.dtype == torch.bfloat16)
+            segs[i].pool = int(ss.pool)
             sgr[i].feat = ptr(g(i_feat[i]))
             if ss.has_proj:
                 segs[i].proj_w, segs[i].proj_b = ptr(proj[2 * pi]), ptr(proj[2 * pi + 1])

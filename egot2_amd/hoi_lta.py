@@ -111,11 +111,13 @@ class _LTATranslator(nn.Module, TranslatorMixin):
         x = torch.stack(self.head(x), dim=1)  # (B, Z, #verbs + #nouns)
         return torch.split(x, self.cfg.MODEL.NUM_CLASSES, dim=-1)
 
-    def _translate(self, feats, projs):
+    def _translate(self, feats, projs, pools=None):
         segs, off = [], 0
-        for f, pj in zip(feats, projs):
-            segs.append(SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=pj is not None, add_row=None, pos_row0=off))
-            off += f.shape[1]
+        for i, (f, pj) in enumerate(zip(feats, projs)):
+            pool = pools[i] if pools else 1
+            T = f.shape[1] // pool
+            segs.append(SegmentSpec(T=T, d_in=f.shape[2], has_proj=pj is not None, add_row=None, pos_row0=off, pool=pool))
+            off += T
         assert off == self.sequence_len, f"token count {off} != sequence_len {self.sequence_len}"
         tokens = self._egx_encode(feats, segs, encoder=self.transformer, ln=self.ln, projs=projs, task_embed=None,
                                   pos_table=self.pe[0], p_drop=self.dp_rate)
@@ -162,6 +164,14 @@ class TaskFusionMFTransformerLTA4Task(_LTATranslator):
         """pnr/oscc (B, n, 8192), action (B, n, d), lta (B, n, 2048) -> [(B, Z, #verbs), (B, Z, #nouns)]."""
         return self._translate([feat_pnr, feat_oscc, feat_action, feat_lta],
                                [self.proj_pnr, self.proj_oscc, None, self.proj_lta])
+
+    def forward_frame_features(self, frames_pnr, frames_oscc, feat_action, feat_lta, frames_per_clip=16):
+        """Feature hand-off without the pooled intermediate: frames_pnr / frames_oscc are the PNR /
+        OSCC backbones' per-FRAME `middle=True` features of all clips, (B, n * frames_per_clip, 8192) in fp32 or bf16; the
+        temporal mean of encode_clips_pnr (`.mean(dim=1)`) is taken on the way into the projection GEMM's bf16 operand
+        (wide bf16 path). action (B, n, d) and lta (B, n, 2048) as in forward_features (fp32 or bf16)."""
+        return self._translate([frames_pnr, frames_oscc, feat_action, feat_lta],
+                               [self.proj_pnr, self.proj_oscc, None, self.proj_lta], pools=[frames_per_clip, frames_per_clip, 1, 1])
 
     def encode_clips_pnr(self, model, x):
         return torch.stack([model([x[:, i, ...]], middle=True).mean(dim=1) for i in range(x.shape[1])], dim=1)

@@ -57,7 +57,7 @@ def _randn(gen, shape, device):
 
 def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, layers: int | None = None,
                   dtype: str | None = None, impl: str = "auto", dropout: float | None = None, seed: int = 1234,
-                  encoder_only: bool = False) -> Dict:
+                  encoder_only: bool = False, feat_dtype: str = "f32", feat_frames: int = 1) -> Dict:
     from . import functional as F_egx
     from .train import CrossEntropyLoss
     name = name.lower()
@@ -109,20 +109,27 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
         p = 0.1 if dropout is None else dropout
         model = hoi_lta.TaskFusionMFTransformerLTA4Task(lta4_cfg(n, 768, 8, L, p))
         model = model.to(device).set_compute(dtype or "bf16", impl).train()
-        feats = [_randn(gen, (B, n, 8192), device), _randn(gen, (B, n, 8192), device), _randn(gen, (B, n, 768), device),
-                 _randn(gen, (B, n, 2048), device)]
+        # feature hand-off (row F4): --feat-dtype bf16 = the backbones write packed bf16 features (the action stream feeds
+        # the LayerNorm directly and stays fp32); --feat-frames F = per-frame PNR / OSCC features, temporal mean fused
+        fr = max(int(feat_frames), 1)
+        feats = [torch.randn(B, n * fr, 8192, device=device), torch.randn(B, n * fr, 8192, device=device),
+                 _randn(gen, (B, n, 768), device), _randn(gen, (B, n, 2048), device)]
+        if feat_dtype == "bf16":
+            feats = [feats[0].bfloat16(), feats[1].bfloat16(), feats[2], feats[3].bfloat16()]
         tv = torch.randint(0, 115, (B * 20,), generator=gen).to(device)
         tn = torch.randint(0, 478, (B * 20,), generator=gen).to(device)
 
         def loss_fn():
-            verbs, nouns = model.forward_features(*feats)      # (B, 20, 115), (B, 20, 478)
+            verbs, nouns = (model.forward_frame_features(*feats, frames_per_clip=fr) if fr > 1
+                            else model.forward_features(*feats))      # (B, 20, 115), (B, 20, 478)
             # hundreds of classes x thousands of rows: outside the (B, few-class) shape the fused CE kernel is built for
             ce = torch.nn.functional.cross_entropy
             return ce(verbs.reshape(-1, 115), tv) + ce(nouns.reshape(-1, 478), tn)
         segs = [(n, 8192, True), (n, 8192, True), (n, 768, False), (n, 2048, True)]
         fl = encoder_flops(B, segs, 768, 2048, L, extra_fwd=2.0 * B * 768 * 593 * 20)
         desc = (f"configs[3]: HOI LTA 4-task translator (PNR+OSCC+AR+LTA), n={n} clips/task S={4 * n} d=768 h=8 d_ff=2048, "
-                f"{L} layers, B={B}/GPU, MultiTaskHead 20x593 + CE, dropout={p}")
+                f"{L} layers, B={B}/GPU, MultiTaskHead 20x593 + CE, dropout={p}, features {feat_dtype}"
+                + (f", {fr} frames per clip pooled in the hand-off" if fr > 1 else ""))
         d, S = 768, 4 * n
     elif name in ("c5", "c5hhi", "c5hoi"):
         L = layers or 3

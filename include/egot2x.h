@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 5
+#define EGX_ABI_VERSION 6
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
@@ -63,6 +63,15 @@ typedef struct egx_segment {
     const float* add_vec; /* [d_model] task-embedding row, or NULL */
     const float* pos;     /* first positional row for this segment, or NULL */
     int pos_stride;       /* floats between consecutive positional rows */
+    /* Feature hand-off from the frozen backbones (wide bf16 path only, projected segments only):
+     * feat_bf16 != 0: `feat` points at bf16 data (the backbone wrote its `middle=True` features in the packed bf16 layout
+     *                 the projection GEMM reads; no fp32 copy, no cast pass).
+     * pool > 1      : `feat` holds (B, T * pool, d_in) per-FRAME features and token t is the mean of frames
+     *                 [t * pool, (t + 1) * pool): the temporal mean of HOI encode_clips_pnr
+     *                 (HOI/models/lta/lta_models_lta_transfer.py:335-343, `tmp.mean(dim=1)`) fused with the cast into the
+     *                 projection operand, so the pooled fp32 tensor is never written. */
+    int feat_bf16;
+    int pool;
 } egx_segment;
 
 /* Gradient sinks matching egx_segment; any pointer may be NULL (gradient not wanted).

@@ -225,3 +225,46 @@ def test_wide_path_dropout_training_is_reproducible(egx_lib, cuda):
     with torch.no_grad():
         e = m.forward_features(*feats)[0]
     assert not torch.equal(e, runs[0][0]) and torch.isfinite(e).all()
+
+
+def test_feature_handoff_bf16_and_frame_pooling(egx_lib, cuda):
+    """SURVEY.md 8f row F4. (1) Features handed over in bf16 are used in place by the projection GEMMs: results are
+    BIT-IDENTICAL to fp32 features holding the same (bf16-representable) values, which go through the cast pass.
+    (2) Per-frame PNR / OSCC features with the temporal mean fused into the hand-off equal the pooled-then-handed-over
+    path (HOI encode_clips_pnr `.mean(dim=1)`) to bf16 rounding. (3) The fp32-storage kernels refuse packed features."""
+    from egot2_amd import hoi_lta, _lib
+    B, n, F = 3, 4, 16
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(n, 256, 8, 2))
+    m.load_state_dict(seeded_state_dict(m, 15))
+    m = m.to(cuda).set_compute("bf16").train()
+    frames = [f.to(cuda) for f in seeded_feats(16, [(B, n * F, 8192), (B, n * F, 8192)])]
+    act, lta = [f.to(cuda) for f in seeded_feats(17, [(B, n, 256), (B, n, 2048)])]
+    pooled = [f.view(B, n, F, 8192).mean(2) for f in frames]
+
+    def run(fn):
+        m.zero_grad(set_to_none=True)
+        o = fn()
+        (o[0].sum() + (o[1] * o[1]).sum()).backward()
+        return torch.cat([t.detach().flatten() for t in o]), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    # (1) bf16 in place == fp32 holding the same values
+    p16 = [f.bfloat16() for f in pooled]
+    l16 = lta.bfloat16()
+    o_a, g_a = run(lambda: m.forward_features(p16[0], p16[1], act, l16))
+    o_b, g_b = run(lambda: m.forward_features(p16[0].float(), p16[1].float(), act, l16.float()))
+    assert torch.equal(o_a, o_b)
+    for k in g_a:
+        if not k.startswith("head."):
+            assert torch.equal(g_a[k], g_b[k]), k
+    # (2) fused temporal mean (fp32 and bf16 frames) vs pooled features
+    o_ref, g_ref = run(lambda: m.forward_features(pooled[0], pooled[1], act, lta))
+    for fr in (frames, [f.bfloat16() for f in frames]):
+        o_f, g_f = run(lambda: m.forward_frame_features(fr[0], fr[1], act, lta, frames_per_clip=F))
+        assert (o_f - o_ref).abs().max().item() < 1e-2 * max(1.0, o_ref.abs().max().item())
+        errs = {k: (g_f[k] - g_ref[k]).norm().item() / (g_ref[k].norm().item() + 1e-12) for k in g_ref}
+        bad = {k: v for k, v in errs.items() if not v < 5e-2}     # two different bf16 roundings of the projection operands: ~3e-2
+        assert not bad, bad
+    # (3) fp32 compute (generic kernels): no packed features
+    m.set_compute("f32")
+    with pytest.raises(_lib.EgxError, match="wide bf16 path"):
+        m.forward_features(p16[0], p16[1], act, l16)
