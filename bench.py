@@ -69,6 +69,7 @@ def parse_args(argv=None):
                     help="exercise only the launcher plumbing (rank spawn, process group on --backend, barrier, max-over-ranks timing, JSON relay) without the model; CPU-runnable")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (gloo only for --launch-selftest)")
     ap.add_argument("--encoder-only", action="store_true", help="c5*: time the task-translation encoder alone (loss = sum of the memory), without the sequence decoder + vocabulary CE")
+    ap.add_argument("--deterministic", action="store_true", help="fixed-order reductions in the backward (bit-identical gradients run to run)")
     ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"], help="c4: dtype of the backbone features handed to the translator (row F4)")
     ap.add_argument("--feat-frames", type=int, default=1, help="c4: per-frame PNR / OSCC features, this many frames per clip, temporal mean fused into the hand-off")
     ap.add_argument("--master-port", type=int, default=0)
@@ -190,6 +191,8 @@ def run(args) -> int:
                              feat_dtype=args.feat_dtype, feat_frames=args.feat_frames)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
+    if args.deterministic:
+        model.set_deterministic(True)
     ddp.broadcast_parameters(model)
     one = F_egx.unit_grad(dev)
     loss_fn = wl["loss_fn"]
@@ -354,7 +357,16 @@ def run(args) -> int:
                 with_opt.step()
         return step
 
-    step = make_step(opt)
+    try:
+        step = make_step(opt)
+    except Exception as e:      # noqa: BLE001  (overlapped capture failed: the plain exchange still measures the step)
+        if not overlap:
+            raise
+        print(f"[bench] overlapped exchange unavailable ({e}); using one all-reduce after the backward", file=sys.stderr)
+        overlap = False
+        model.egx_defer_small = False
+        F_egx.run_deferred()
+        step = make_step(opt)
     trials = auto_trials(step, args.steps)
     dts = time_trials(step, args.warmup, args.steps, trials)
     dt_med = percentile(dts, 0.5)
@@ -390,7 +402,8 @@ def run(args) -> int:
         "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
                                + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
-                   "launch": "one hipGraph replay per step" if use_graph else "eager"},
+                   "launch": "one hipGraph replay per step" if use_graph else "eager",
+                   "deterministic": bool(args.deterministic)},
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
         "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
     }

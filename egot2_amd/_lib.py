@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 6
+EGX_ABI_VERSION = 7
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16 = 0, 1
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
@@ -51,7 +51,8 @@ class Config(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int),
                 ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
                 ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float), ("seed_ptr", _fp),
-                ("advance_seed", C.c_int), ("zero_buf", _fp), ("zero_bytes", C.c_size_t), ("bwd_stage", C.c_int)]
+                ("advance_seed", C.c_int), ("zero_buf", _fp), ("zero_bytes", C.c_size_t), ("bwd_stage", C.c_int),
+                ("deterministic", C.c_int)]
 
 
 # symbol -> (restype, argtypes); every symbol include/egot2x.h declares

@@ -200,6 +200,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     slab = size_max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
     slab = size_max(slab, gemm_scratch_bytes(2, pl.d, pl.d, (int)pl.N));
     for (int i = 0; i < pl.nseg; ++i) slab = size_max(slab, gemm_scratch_bytes(2, pl.d, segs[i].d_in, pl.B * segs[i].T));
+    slab = size_max(slab, (size_t)(512 + SMALL_DW_MAX * 16) * 64 * 128 * sizeof(float));   // deterministic small_dw: one tile per workgroup
     s.slab_bytes = slab;
     s.slabs = take(cur, slab);
     s.dhid = take(cur, fused_hid_total(cfg, pl));
@@ -654,16 +655,20 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
                         fp.B = B;
                     }
-                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr)) return 1;
+                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr, cfg->deterministic != 0)) return 1;
                     rp_pending = false;
                 }
             }
-            if (rp_pending && reduce_partials(rp, st)) return 1;
+            if (rp_pending && reduce_partials(rp, st, cfg->deterministic != 0)) return 1;
             // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches
             if (stage != 1) {
                 SmallDwParams sp;
                 memset(&sp, 0, sizeof(sp));
-                auto flush = [&]() -> int { int rc = sp.n ? small_dw(sp, comp, st) : 0; memset(&sp, 0, sizeof(sp)); return rc; };
+                auto flush = [&]() -> int {
+                    int rc = sp.n ? small_dw(sp, comp, st, cfg->deterministic ? slab : nullptr, SC.slab_bytes) : 0;
+                    memset(&sp, 0, sizeof(sp));
+                    return rc;
+                };
                 auto add = [&](const float* G, int ldg, const float* X, int ldx, float* out, int R, int Cc, int K) -> int {
                     if (!out) return 0;
                     if (sp.n == SMALL_DW_MAX && flush()) return 1;

@@ -91,7 +91,7 @@ size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
 struct ReducePartialsParams;
 // `rp` (optional): per-clip partial sums to reduce in the same launch as the slab reduction
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
-           const ReducePartialsParams* rp = nullptr);
+           const ReducePartialsParams* rp = nullptr, bool deterministic = false);
 
 struct FusedBwdLayer {
     const void* in_proj_wp;    // packed W_in   (R = 384, K = 128): QKV recompute
@@ -144,8 +144,10 @@ constexpr int SMALL_DW_MAX = 8;
 struct SmallDwParams {
     SmallDwProblem pr[SMALL_DW_MAX];
     int n, per;           // per = K-blocks (32 tokens) per workgroup, the same for every problem (balanced grid)
+    float* slabs;         // deterministic mode: one dense [64][128] fp32 tile per workgroup, summed in split order afterwards
 };
-int small_dw(SmallDwParams& p, int compute, hipStream_t st);
+// slabs / slab_bytes: optional scratch for the deterministic (atomic-free) variant; null = atomic accumulation
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullptr, size_t slab_bytes = 0);
 int seed_advance(uint64_t* seed, hipStream_t st);
 
 struct PartialDst { float* dst; int off, len; };
@@ -155,7 +157,7 @@ struct ReducePartialsParams {
     int n, B, P;
     const float* partials;
 };
-int reduce_partials(const ReducePartialsParams& rp, hipStream_t st);
+int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool deterministic = false);
 
 // Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.
 enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_FFN_FWD = 3, TIMER_FFN_BWD = 4, TIMER_WIDE_GEMM = 5,

@@ -463,7 +463,7 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
 
 // dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H with H, dH recomputed. `slabs` holds ffn_dw_scratch_bytes().
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
-           const ReducePartialsParams* rp) {
+           const ReducePartialsParams* rp, bool deterministic) {
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
     EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
     int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
@@ -489,7 +489,8 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     size_t total = a.n[0] + a.n[1] + a.n[2];
     unsigned slab_blocks = (unsigned)((total / 4 + 255) / 256);
     if (rp) {
-        int chunks = partial_chunks(rp->B);
+        // deterministic: ONE workgroup per 64 partial columns walks all clips (a single adder per gradient element)
+        int chunks = deterministic ? 1 : partial_chunks(rp->B);
         hipLaunchKernelGGL(reduce_tail_kernel, dim3(slab_blocks + (unsigned)(cdiv(rp->P, 64) * chunks)), dim3(256), 0, st, a, *rp, slab_blocks, chunks);
     } else {
         hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3(slab_blocks), dim3(256), 0, st, a);
@@ -569,6 +570,14 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
         }
         cur ^= 1;
     }
+    if (p.slabs) {      // deterministic: dense tile per workgroup, summed in split order by small_dw_reduce_kernel
+        float* tile = p.slabs + (size_t)blockIdx.x * (64 * 128);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(wave * 16 + 4 * q + e) * 128 + j * 16 + r] = acc[j][e];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -578,7 +587,37 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
         }
 }
 
-int small_dw(SmallDwParams& p, int compute, hipStream_t st) {
+// out[row][col] += sum over the splits of one (problem, item) of its slab tiles, in split order. grid.x = work items, 8 blocks each.
+__global__ __launch_bounds__(256) void small_dw_reduce_kernel(SmallDwParams p) {
+    const int unit = blockIdx.x >> 3, part = blockIdx.x & 7;      // part: 8 rows of the 64 x 128 tile
+    int pi = 0, base = 0;
+    for (;; ++pi) {
+        const int items = ((p.pr[pi].R + 63) / 64) * ((p.pr[pi].C + 127) / 128);
+        if (unit < base + items || pi + 1 >= p.n) break;
+        base += items;
+    }
+    const SmallDwProblem& pr = p.pr[pi];
+    const int item = unit - base;
+    const int ncol = (pr.C + 127) / 128;
+    const int row0 = (item / ncol) * 64, col0 = (item % ncol) * 128;
+    const int nkb = (pr.K + 31) / 32;
+    const int r = part * 8 + (threadIdx.x >> 5), c = (threadIdx.x & 31) * 4;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int sp = 0; sp < pr.splits; ++sp) {
+        if (sp * p.per >= nkb) break;                               // workgroups without K-blocks wrote nothing
+        const float* tile = p.slabs + (size_t)(pr.first_block + item * pr.splits + sp) * (64 * 128);
+        float4 v = *reinterpret_cast<const float4*>(tile + r * 128 + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int row = row0 + r, col = col0 + c;
+    if (row < pr.R && col < pr.C) {                                 // C % 4 == 0
+        float4* dst = reinterpret_cast<float4*>(pr.out + (size_t)row * pr.C + col);
+        float4 o = *dst;
+        *dst = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+    }
+}
+
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t slab_bytes) {
     int items[SMALL_DW_MAX], nkb[SMALL_DW_MAX], total_items = 0;
     for (int i = 0; i < p.n; ++i) {
         EGX_CHECK(p.pr[i].R % 4 == 0 && p.pr[i].C % 4 == 0 && p.pr[i].ldg % 4 == 0 && p.pr[i].ldx % 4 == 0,
@@ -604,8 +643,15 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st) {
         p.pr[i].splits = cdiv(nkb[i], per);
         blocks += items[i] * p.pr[i].splits;
     }
+    p.slabs = nullptr;
+    if (slabs) {
+        EGX_CHECK((size_t)blocks * 64 * 128 * sizeof(float) <= slab_bytes, "small_dw: deterministic mode needs %zu bytes of slab scratch, got %zu",
+                  (size_t)blocks * 64 * 128 * sizeof(float), slab_bytes);
+        p.slabs = (float*)slabs;
+    }
     if (compute == 1) hipLaunchKernelGGL(small_dw_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(small_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
+    if (p.slabs) hipLaunchKernelGGL(small_dw_reduce_kernel, dim3(total_items * 8), dim3(256), 0, st, p);
     EGX_LAUNCH_CHECK();
     return 0;
 }
@@ -1256,8 +1302,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(ReducePartialsPara
     reduce_partials_block(rp, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
-int reduce_partials(const ReducePartialsParams& rp, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(rp.P, 64), partial_chunks(rp.B)), dim3(256), 0, st, rp);
+int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool deterministic) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(rp.P, 64), deterministic ? 1 : partial_chunks(rp.B)), dim3(256), 0, st, rp);
     EGX_LAUNCH_CHECK();
     return 0;
 }

@@ -48,11 +48,13 @@ class EncoderSpec:
     head_n_out: int = 0    # > 0: pooled head (mean -> LN -> Linear) evaluated with the encoder; output = logits
     advance_seed: bool = False   # with seed_ptr: the training forward advances the device seed in its first kernel
     defer_small: bool = False    # backward: leave the grouped small weight gradients to run_deferred() (all-reduce overlap)
+    deterministic: bool = False  # backward: fixed-order reductions instead of fp32 atomics (bit-identical gradients run to run)
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
                       COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
-                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0, 0)
+                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0, 0,
+                      int(bool(self.deterministic)))
 
 
 _scratch_cache = {}

@@ -58,11 +58,18 @@ class TranslatorMixin:
     egx_compute: str = "f32"
     egx_impl: str = "auto"
     egx_defer_small: bool = False      # staged backward for the all-reduce overlap (ddp.allreduce_gradients_overlapped)
+    egx_deterministic: bool = False    # fixed-order reductions in the backward (egx_config.deterministic)
     _egx_step: int = 0
 
     def set_compute(self, compute: str = "f32", impl: str = "auto"):
         assert compute in F_egx.COMPUTE and impl in F_egx.IMPL
         self.egx_compute, self.egx_impl = compute, impl
+        return self
+
+    def set_deterministic(self, on: bool = True):
+        """Bit-identical gradients run to run (same inputs, same seed): the fused per-clip backward replaces its fp32-atomic
+        cross-workgroup sums by fixed-order slab reductions; the wide bf16 path is deterministic by construction."""
+        self.egx_deterministic = bool(on)
         return self
 
     def enable_device_seed(self, device=None):
@@ -94,7 +101,7 @@ class TranslatorMixin:
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
                            head_n_out=head[1].out_features if head is not None else 0,
                            advance_seed=seed_dev is not None and bool(self.training),   # fresh masks per (replayed) step
-                           defer_small=bool(self.egx_defer_small))
+                           defer_small=bool(self.egx_defer_small), deterministic=bool(self.egx_deterministic))
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 6
+#define EGX_ABI_VERSION 7
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1 };
@@ -140,6 +140,11 @@ typedef struct egx_config {
                                  dW_in, dW_o); 2 = only those (same arguments, zero_buf ignored). Lets the caller start the
                                  all-reduce of every other gradient while stage 2 still runs (fused path; the generic
                                  path does all its work in stage 1). */
+    int deterministic;        /* != 0: every cross-workgroup sum of the BACKWARD runs in a fixed order (split-K slabs and
+                                 per-clip partial rows reduced by one workgroup per output instead of fp32 atomics), so the
+                                 same inputs and seed give bit-identical gradients run to run. Honoured by the fused per-clip
+                                 kernels; the wide bf16 path is always deterministic; the shape-generic kernels keep their
+                                 atomic reductions. */
 } egx_config;
 
 int egx_abi_version(void);

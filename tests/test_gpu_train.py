@@ -320,3 +320,33 @@ def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, ov
     torch.nn.functional.cross_entropy(m.forward_features(*feats), y).backward()
     for k, p in m.named_parameters():
         assert torch.allclose(p.grad.cpu(), torch.from_numpy(grads[k]), rtol=2e-3, atol=2e-6), k
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute):
+    """same inputs + same dropout seed => bit-identical logits and gradients across runs with
+    `set_deterministic()`: the fused backward sums its split-K slabs and per-clip partial rows in a fixed order instead of
+    fp32 atomics. The result must still match the default (atomic) mode to accumulation-order noise. B = 300 clips: more
+    than one round of workgroups, several token splits per weight-gradient problem."""
+    B = 300
+    feats = [f.to(cuda) for f in seeded_feats(55, [(B, 15, 256)] * 3)]
+    target = (torch.arange(B, device=cuda) * 7) % 2
+    w = torch.tensor(CE_W, device=cuda)
+
+    def run(det):
+        torch.manual_seed(4321)
+        from egot2_amd import hhi_ttm
+        m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=2, dropout=0.5))
+        m.load_state_dict(seeded_state_dict(m, 9))
+        m = m.to(cuda).set_compute(compute, "fused").set_deterministic(det).train()
+        m._egx_step = 0
+        logits = m.forward_features(*feats)
+        torch.nn.functional.cross_entropy(logits, target, weight=w).backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+        assert torch.allclose(a[1][k], c[1][k], rtol=2e-3, atol=1e-6), k
