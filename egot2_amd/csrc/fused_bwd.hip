@@ -722,13 +722,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         // forward/backward for this clip (wave 0) and broadcast d(tokens) = d(pooled) / S into Gs.
         const FusedBwdLayer& wl = p.layer[p.n_layers - 1];
         float* hp = part + p.head_off;
-        load_block(Gs, p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD);
+        {   // res2 of the last layer -> Gs (normalised in place below) AND B1 (LayerNorm2 backward needs it again: P1 is skipped)
+            const float* src = p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD;
+            for (int i = tid; i < S * (FD / 4); i += 256) {
+                int row = i >> 5, c = (i & 31) << 2;
+                float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * FD + c);
+                *reinterpret_cast<float4*>(Gs + row * LDX + c) = v;
+                *reinterpret_cast<float4*>(B1 + row * LDX + c) = v;
+            }
+        }
         __syncthreads();
         ln_rows(Gs, S, wl.norm2_w, wl.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(Gs + row * LDX + c0, y);
         });
         __syncthreads();
-        float* pooled = B1;        // [0,128): pooled; [128,256): d(pooled)
+        float* pooled = B2;        // [0,128): pooled; [128,256): d(pooled)   (B1 holds res2 for LayerNorm2 backward)
         if (tid < FD) pooled[tid] = colsum_lds(Gs, 0, S, tid) * (1.f / (float)S);
         __syncthreads();
         if (wave == 0) {
@@ -777,8 +785,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         float* pl = part + l * FUSED_P_LAYER;
 
         BSTAMP(0);
-        // P1: res2 -> B1
-        load_block(B1, sv_res2);
+        // P1: res2 -> B1 (already there when the fused head backward loaded it for the last layer)
+        if (!(p.head.n_out > 0 && l == p.n_layers - 1)) load_block(B1, sv_res2);
         __syncthreads();
         // P2: LayerNorm2 backward. B1 <- d_res2 (in place), B3 <- dY * xhat, B2 <- g2 = d_res2 .* dropout2 mask
         ln_bwd_rows(S, w.norm2_w, p.eps,
@@ -803,11 +811,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         } else {
             pl[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
         }
-        load_block(B4, sv_res1);
+        load_block(B5, sv_res1);        // stays in B5 until LayerNorm1 backward (P5): one global read of res1 per layer
         __syncthreads();
-        ln_rows(B4, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-            store32(B4 + row * LDX + c0, y);
-            store32(w.x1_out + (tok0 + row) * FD + c0, y);
+        ln_rows(B5, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            store32(w.x1_out + (tok0 + row) * FD + c0, y);      // x1 is only an operand of the weight-gradient kernel
         });
         __syncthreads();
 
@@ -908,34 +915,39 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
             }
         BSTAMP(3);
-            // deterministic cross-wave sum into Gs (dY is dead): wave 0 stores, waves 1..3 add in turn
-            for (int round = 0; round < 4; ++round) {
-                if (wave == round) {
+            // cross-wave sum: every wave parks its partial dX1 in a block of its own (dY in Gs, dY.xhat in B3 and B4 are dead;
+            // g2 in B2 is dead once every wave has left the loop); LayerNorm1 backward adds the four in a fixed order
+            __syncthreads();
+            {
+                float* mine = wave == 0 ? Gs : (wave == 1 ? B2 : (wave == 2 ? B3 : B4));
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                for (int i = 0; i < 8; ++i)
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            float* d = Gs + (t * 16 + r) * LDX + i * 16 + 4 * q;
-                            float4 v = make_float4(dxa[i][t][0], dxa[i][t][1], dxa[i][t][2], dxa[i][t][3]);
-                            if (round) { float4 o = *reinterpret_cast<float4*>(d); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                            *reinterpret_cast<float4*>(d) = v;
-                        }
-                }
-                __syncthreads();
+                    for (int t = 0; t < NT; ++t)
+                        *reinterpret_cast<float4*>(mine + (t * 16 + r) * LDX + i * 16 + 4 * q) =
+                            make_float4(dxa[i][t][0], dxa[i][t][1], dxa[i][t][2], dxa[i][t][3]);
             }
         }
         BSTAMP(4);
-        // P5: res1 -> B3; LayerNorm1 backward with dy = dX1 (Gs) + d_res2 (B1).
-        load_block(B3, sv_res1);
+        // P5: LayerNorm1 backward with dy = dX1 (four wave partials in Gs, B2, B3, B4) + d_res2 (B1); x = res1 (B5, from P3).
         __syncthreads();
         ln_bwd_rows(S, w.norm1_w, p.eps,
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
                 float t[32];
                 load32(Gs + row * LDX + c0, dy);
+                load32(B2 + row * LDX + c0, t);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) dy[j] += t[j];
+                load32(B3 + row * LDX + c0, t);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) dy[j] += t[j];
+                load32(B4 + row * LDX + c0, t);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) dy[j] += t[j];
                 load32(B1 + row * LDX + c0, t);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) dy[j] += t[j];
-                load32(B3 + row * LDX + c0, x);
+                load32(B5 + row * LDX + c0, x);
             },
             [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
                 store32(Gs + row * LDX + c0, dy);      // total dy, for d(norm1_b)
@@ -951,6 +963,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             });
         __syncthreads();
         BSTAMP(5);
+        PackW<BF16, 2, 4> wo_pf;        // W_o^T fragments of P7: in flight under the column sums
+        pack_issue(wo_pf, w.out_proj_wtp, wave * 2, 4, 0);
         // P6: column sums (norm1_w, norm1_b, out_proj_b)
         if (tid < 128) {
             pl[384 + tid] = colsum_lds(B4, 0, S, tid);
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.out_proj_wtp, wave * 2, 4, 0, B2, r, q, lane);
+            gemm_packed<BF16, 2, NT, 4>(acc, wo_pf, B2, r, q);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -976,6 +990,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                         make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
         }
         BSTAMP(6);
+        PackW<BF16, 3, 4> wq_pf;        // first half of the W_in fragments of P9: in flight under the x_in recompute
+        pack_issue(wq_pf, w.in_proj_wp, wave * 6, 4, 0);
         // P8: recompute the layer input x_in -> Gs
         if (l == 0) {
             load_block(Gs, p.saved_pre + tok0 * FD);
@@ -1024,8 +1040,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             {
                 f32x4 (&a0)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[0]);
                 f32x4 (&a1)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[3]);
-                gemm_pack_lds<BF16, 3, NT, 4>(a0, w.in_proj_wp, wave * 6, 4, 0, Gs, r, q, lane);
-                gemm_pack_lds<BF16, 3, NT, 4>(a1, w.in_proj_wp, wave * 6 + 3, 4, 0, Gs, r, q, lane);
+                PackW<BF16, 3, 4> wq2;
+                pack_issue(wq2, w.in_proj_wp, wave * 6 + 3, 4, 0);      // second half streams in under the first half's MFMAs
+                gemm_packed<BF16, 3, NT, 4>(a0, wq_pf, Gs, r, q);
+                gemm_packed<BF16, 3, NT, 4>(a1, wq2, Gs, r, q);
             }
             __syncthreads();
 #pragma unroll
@@ -1094,12 +1112,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 float inv = 1.f / sum;
                 int query = qt * 16 + r;
                 float dl = 0.f;
+                float ksv[NT][4];                      // keep-scale of this query column, computed once
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float pv = pt[kt][qt][e] * inv;
                         float ks = keep(query, kt * 16 + 4 * q + e);
+                        ksv[kt][e] = ks;
                         pt[kt][qt][e] = pv;
                         dpt[kt][qt][e] *= ks;          // mask .* dP^T
                         dl += pv * dpt[kt][qt][e];
@@ -1113,8 +1133,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int e = 0; e < 4; ++e) {
                         float pv = pt[kt][qt][e];
                         dpt[kt][qt][e] = pv * (dpt[kt][qt][e] - dl) * scale;                      // dS^T (scaled)
-                        if (w.attn_thresh) pv *= keep(query, kt * 16 + 4 * q + e);
-                        pt[kt][qt][e] = pv;                                                        // dropped P^T
+                        pt[kt][qt][e] = pv * ksv[kt][e];                                           // dropped P^T
                     }
             }
             // O^T = V^T (P^T .* mask) -> attn_o (HBM);  dQ^T = K^T dS^T
@@ -1227,6 +1246,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
         __syncthreads();
         BSTAMP(9);
+        PackW<BF16, 2, 4> wi_pf;        // W_in^T fragments (dQ part) of P12: in flight under the column sums
+        pack_issue(wi_pf, w.in_proj_wtp, wave * 2, 12, 0);
         // P11: in_proj_b partials
         if (tid < 128) {
             pl[768 + tid] = colsum_lds(B4, 0, S, tid);
@@ -1242,9 +1263,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 0, B4, r, q, lane);
-            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 4, B5, r, q, lane);
-            gemm_pack_lds<BF16, 2, NT, 4>(acc, w.in_proj_wtp, wave * 2, 12, 8, Gs, r, q, lane);
+            PackW<BF16, 2, 4> wi2, wi3;
+            pack_issue(wi2, w.in_proj_wtp, wave * 2, 12, 4);
+            gemm_packed<BF16, 2, NT, 4>(acc, wi_pf, B4, r, q);
+            pack_issue(wi3, w.in_proj_wtp, wave * 2, 12, 8);
+            gemm_packed<BF16, 2, NT, 4>(acc, wi2, B5, r, q);
+            gemm_packed<BF16, 2, NT, 4>(acc, wi3, Gs, r, q);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll

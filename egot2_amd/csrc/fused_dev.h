@@ -341,6 +341,36 @@ __device__ __forceinline__ void gemm_pack_lds(f32x4 (&acc)[NTI][NT], const void*
     }
 }
 
+// The same GEMM with its weight fetch split off: pack_issue() early (before the LayerNorm / column-sum / barrier work that
+// precedes the GEMM phase, so the L2 round trip of the fragments is hidden under it), gemm_packed() where the operands are
+// ready. One wave per SIMD: nothing else hides that latency.
+template <bool BF16, int NTI, int NKB> struct PackW { WRaw<BF16> v[NTI][NKB]; };
+template <bool BF16, int NTI, int NKB>
+__device__ __forceinline__ void pack_issue(PackW<BF16, NTI, NKB>& w, const void* pack, int tile0, int nkb_total, int kb0) {
+    int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NTI; ++i)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) w.v[i][kb] = load_w<BF16>(pack, tile0 + i, nkb_total, kb0 + kb, ln);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool BF16, int NTI, int NT, int NKB>
+__device__ __forceinline__ void gemm_packed(f32x4 (&acc)[NTI][NT], PackW<BF16, NTI, NKB>& w, const float* ldsB, int r, int q) {
+    pin_all(w.v);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        Frag<BF16> b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(ldsB + (t * 16 + r) * LDX + kb * 32, q);
+#pragma unroll
+        for (int i = 0; i < NTI; ++i) {
+            Frag<BF16> a = w_frag<BF16>(w.v[i][kb]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+        }
+    }
+}
+
 // A-operand fragment gathered from a token-major LDS block: element (i = column c0 + r, k = token row of the
 // K-block that starts at row k0): 8 ds_read_b32. Rows are clamped to rmax (callers zero the matching B rows).
 template <bool BF16>
