@@ -43,25 +43,25 @@ __device__ __forceinline__ f32x4 mfma(const bf16x8& a, const bf16x8& b, const f3
 // copy `rows` token rows of one head (dh bf16 each, global row stride ld elements) into an LDS image with row stride RS
 // bytes; rows [rows, SP) are zero-filled. All of a thread's loads are issued before its first LDS store (one exposed
 // memory latency per image set instead of one per 16-byte chunk).
-template <int DH, int SP>
-struct ImageRegs { uint4 v[(SP * (DH / 8) + 255) / 256]; };
-template <int DH, int SP>
-__device__ __forceinline__ void image_fetch(ImageRegs<DH, SP>& R, const bf16_t* src, int ld, int rows) {
-    constexpr int CH = DH / 8, NIT = (SP * CH + 255) / 256;
+template <int DH, int SP, int NTH = 256>
+struct ImageRegs { uint4 v[(SP * (DH / 8) + NTH - 1) / NTH]; };
+template <int DH, int SP, int NTH = 256>
+__device__ __forceinline__ void image_fetch(ImageRegs<DH, SP, NTH>& R, const bf16_t* src, int ld, int rows) {
+    constexpr int CH = DH / 8, NIT = (SP * CH + NTH - 1) / NTH;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int i = threadIdx.x + it * 256;
+        const int i = threadIdx.x + it * NTH;
         const int row = i / CH, c = i % CH;
         R.v[it] = make_uint4(0, 0, 0, 0);
         if (i < SP * CH && row < rows) R.v[it] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + c * 8);
     }
 }
-template <int DH, int SP>
-__device__ __forceinline__ void image_store(const ImageRegs<DH, SP>& R, unsigned char* img) {
-    constexpr int RS = DH * 2 + 32, CH = DH / 8, NIT = (SP * CH + 255) / 256;
+template <int DH, int SP, int NTH = 256>
+__device__ __forceinline__ void image_store(const ImageRegs<DH, SP, NTH>& R, unsigned char* img) {
+    constexpr int RS = DH * 2 + 32, CH = DH / 8, NIT = (SP * CH + NTH - 1) / NTH;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int i = threadIdx.x + it * 256;
+        const int i = threadIdx.x + it * NTH;
         const int row = i / CH, c = i % CH;
         if (i < SP * CH) *reinterpret_cast<uint4*>(img + row * RS + c * 16) = R.v[it];
     }
@@ -153,9 +153,10 @@ __global__ __launch_bounds__(256) void wide_attn_fwd_kernel(WideAttnParams p) {
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------
+// NKT = 8 (S <= 128): 512 threads, one query tile (pass T) and one key tile (pass N) per wave, two waves per SIMD.
 template <int DH, int NKT>
-__global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
-    constexpr int RS = DH * 2 + 32, SP = NKT * 16, NKB = DH / 32, NCT = DH / 16;
+__global__ __launch_bounds__(NKT * 64) void wide_attn_bwd_kernel(WideAttnParams p) {
+    constexpr int RS = DH * 2 + 32, SP = NKT * 16, NKB = DH / 32, NCT = DH / 16, NW = NKT, NTH = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Qimg = smem;
     unsigned char* Kimg = Qimg + SP * RS;
@@ -168,24 +169,24 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (size_t)b * S * ld + h * DH;
     {
-        ImageRegs<DH, SP> rq, rk, rv, rd;
-        image_fetch<DH, SP>(rq, base, ld, S);
-        image_fetch<DH, SP>(rk, base + d, ld, S);
-        image_fetch<DH, SP>(rv, base + 2 * d, ld, S);
-        image_fetch<DH, SP>(rd, p.d_out + (size_t)b * S * d + h * DH, d, S);
-        image_store<DH, SP>(rq, Qimg);
-        image_store<DH, SP>(rk, Kimg);
-        image_store<DH, SP>(rv, Vimg);
-        image_store<DH, SP>(rd, Dimg);
+        ImageRegs<DH, SP, NTH> rq, rk, rv, rd;
+        image_fetch<DH, SP, NTH>(rq, base, ld, S);
+        image_fetch<DH, SP, NTH>(rk, base + d, ld, S);
+        image_fetch<DH, SP, NTH>(rv, base + 2 * d, ld, S);
+        image_fetch<DH, SP, NTH>(rd, p.d_out + (size_t)b * S * d + h * DH, d, S);
+        image_store<DH, SP, NTH>(rq, Qimg);
+        image_store<DH, SP, NTH>(rk, Kimg);
+        image_store<DH, SP, NTH>(rv, Vimg);
+        image_store<DH, SP, NTH>(rd, Dimg);
     }
-    for (int i = threadIdx.x; i < SP; i += 256) lse_s[i] = i < S ? p.lse[(size_t)bh * S + i] : 0.f;
+    for (int i = threadIdx.x; i < SP; i += NTH) lse_s[i] = i < S ? p.lse[(size_t)bh * S + i] : 0.f;
     __syncthreads();
     const float scale = rsqrtf((float)DH);
     const int nt = (S + 15) / 16;
     bf16_t* gq = p.d_qkv + (size_t)b * S * ld + h * DH;
 
     // ---- pass T: rows = key, cols = query; this wave's query tiles
-    for (int qt = wave; qt < nt; qt += 4) {
+    for (int qt = wave; qt < nt; qt += NW) {
         const int query = qt * 16 + r;
         bf16x8 qf[NKB], df[NKB];
 #pragma unroll
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
                 a[e] = pv; c[e] = dm;
             }
             pt[kt] = a; dpt[kt] = c;
+            __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of tile kt + 1 behind this tile (register budget)
         }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
             const unsigned char* k0 = Kimg + (kb2 * 32 + 4 * g + (r >> 2)) * RS + 8 * (r & 3);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dq[ct] = mfma(rd_tr2(k0 + ct * 32, k0 + 16 * RS + ct * 32), sf, dq[ct]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (query < S) {
             bf16_t* o = gq + (size_t)query * ld + 4 * g;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
     __syncthreads();
 
     // ---- pass N: rows = query, cols = key; this wave's key tiles
-    for (int kt = wave; kt < nt; kt += 4) {
+    for (int kt = wave; kt < nt; kt += NW) {
         const int key = kt * 16 + r;
         bf16x8 kf[NKB], vf[NKB];
 #pragma unroll
@@ -271,6 +274,7 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
                 c[e] = pv * (ks * c[e] - dq4[e]) * scale;         // dS
             }
             pn[qt] = a; dsn[qt] = c;
+            __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 dk[NCT], dv[NCT];
 #pragma unroll
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(256) void wide_attn_bwd_kernel(WideAttnParams p) {
                 dv[ct] = mfma(rd_tr2(Dimg + roff + ct * 32, Dimg + roff + 16 * RS + ct * 32), pf, dv[ct]);
                 dk[ct] = mfma(rd_tr2(Qimg + roff + ct * 32, Qimg + roff + 16 * RS + ct * 32), sf, dk[ct]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (key < S) {
             bf16_t* o = gq + (size_t)key * ld + 4 * g;
@@ -312,7 +317,7 @@ static int launch_attn(const WideAttnParams& p, bool bwd, hipStream_t st) {
         attr[bwd] = true;
     }
     timing_begin(bwd ? TIMER_WIDE_ATTN_BWD : TIMER_WIDE_ATTN_FWD, st);
-    if (bwd) hipLaunchKernelGGL((wide_attn_bwd_kernel<DH, NKT>), dim3(p.B * p.H), dim3(256), lds, st, p);
+    if (bwd) hipLaunchKernelGGL((wide_attn_bwd_kernel<DH, NKT>), dim3(p.B * p.H), dim3(NKT * 64), lds, st, p);
     else hipLaunchKernelGGL((wide_attn_fwd_kernel<DH, NKT>), dim3(p.B * p.H), dim3(256), lds, st, p);
     timing_end(bwd ? TIMER_WIDE_ATTN_BWD : TIMER_WIDE_ATTN_FWD, st);
     EGX_LAUNCH_CHECK();

@@ -116,7 +116,9 @@ bool wide_ok(const egx_config* cfg, const egx_segment* segs, int B) {
     (void)B;
     if (cfg->compute != EGX_BF16) return false;
     const int d = cfg->d_model, dff = cfg->d_ff;
-    if (d < 256 || d % 128 != 0 || dff % 128 != 0 || d > 1024 || cfg->n_layers < 1 || cfg->n_layers > 64) return false;
+    // impl = auto keeps d_model = 128 on the per-clip / fp32-storage kernels (the wide path's extra bf16 roundings sit at the
+    // 1e-2 bound there); impl = wide may force it
+    if ((d < 256 && cfg->impl != EGX_IMPL_WIDE) || d % 128 != 0 || dff % 128 != 0 || d > 1024 || cfg->n_layers < 1 || cfg->n_layers > 64) return false;
     if (cfg->n_heads <= 0 || d % cfg->n_heads != 0) return false;
     int S = 0;
     for (int i = 0; i < cfg->n_segments; ++i) {

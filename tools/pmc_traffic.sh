@@ -36,7 +36,7 @@ for name, d in out.items():
     f = d.get("FETCH_SIZE_KiB_per_launch_raw", 0.0) * 1024 * 2      # gfx950: half-counted
     w = d.get("WRITE_SIZE_KiB_per_launch_raw", 0.0) * 1024
     res[name] = {"read_bytes": f, "write_bytes": w, "traffic_bytes": f + w, "launches": d["launches"], **d}
-json.dump({"dtype": dt, "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half count) + WRITE_SIZE KiB x 1024", "kernels": res},
+json.dump({"dtype": dt, "workload": {"config": "c2", "batch": 256, "frames": 15, "layers": 1}, "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half count) + WRITE_SIZE KiB x 1024", "kernels": res},
           open(f"gpurun_out/pmc_{dt}.json", "w"), indent=1)
 for name, d in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes"])[:12]:
     print(f"{name[:60]:60s} n={d['launches']:4d} read {d['read_bytes']/1e6:9.2f} MB  write {d['write_bytes']/1e6:9.2f} MB")
