@@ -247,7 +247,10 @@ int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
     // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves, 4-stage ring) below
-    return nt_big(p.M, p.N) ? launch_nt<256, 3>(p, st) : launch_nt<128, 4>(p, st);
+    if (nt_big(p.M, p.N)) return launch_nt<256, 3>(p, st);
+    static int small_stages = -1;      // tuning aid: EGX_WIDE_SMALL_STAGES = 2 -> two workgroups per CU with two stages each
+    if (small_stages < 0) { const char* e = getenv("EGX_WIDE_SMALL_STAGES"); small_stages = e ? atoi(e) : 2; }
+    return small_stages == 2 ? launch_nt<128, 2>(p, st) : launch_nt<128, 4>(p, st);
 }
 
 // ---- TN ---------------------------------------------------------------------------------------------------------------

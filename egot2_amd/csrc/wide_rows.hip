@@ -214,7 +214,7 @@ __global__ __launch_bounds__(1024) void wide_ln_bwd_reduce_kernel(const float* _
 }
 
 static int ln_bwd_blocks(int rows) {
-    int blocks = cdiv(rows, 64);          // >= 16 rows per wave
+    int blocks = cdiv(rows, 16);          // >= 4 rows per wave; at most 1024 partial rows to reduce
     if (blocks > 1024) blocks = 1024;
     return blocks < 1 ? 1 : blocks;
 }

@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 shapes = [(0, 32768, 768, 768), (0, 32768, 2304, 768), (0, 32768, 2048, 768), (0, 32768, 768, 2048), (0, 32768, 768, 2304),
           (0, 8192, 768, 8192), (2, 768, 768, 32768), (2, 2304, 768, 32768), (2, 2048, 768, 32768), (2, 768, 2048, 32768),
-          (2, 768, 8192, 8192), (0, 11520, 256, 256), (0, 12288, 512, 2048), (0, 12288, 2048, 512)]
+          (2, 768, 8192, 8192), (0, 11520, 256, 256), (0, 12288, 512, 2048), (0, 12288, 2048, 512), (0, 12288, 512, 512),
+          (0, 12288, 1536, 512), (0, 4096, 512, 8192), (0, 11520, 768, 256), (0, 11520, 2048, 256), (0, 11520, 256, 2048)]
 for layout, M, N, K in shapes:
     if layout == 0:
         A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16()
