@@ -27,7 +27,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md. "f32s" (fp32 operands split into three bf16 parts, six bf16 MFMAs
+# per K-block) is bounded by the bf16 pipe at six instructions per algorithmic K-block: 2500 / 6.
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -54,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=15)
     ap.add_argument("--layers", type=int, default=0, help="0 = the configuration's own depth")
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="default: f32 for c1/c2, bf16 for c3..c5 (BASELINE.json)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32s"], help="default: f32 for c1/c2, bf16 for c3..c5 (BASELINE.json)")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")

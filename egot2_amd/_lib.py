@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
 EGX_ABI_VERSION = 7
 EGX_MAX_SEGMENTS = 8
-EGX_F32, EGX_BF16 = 0, 1
+EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
 
 _fp = C.c_void_p  # all device pointers travel as raw addresses

@@ -49,6 +49,15 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+// two fp32 -> one packed bf16 pair (a in the low half) by ONE v_cvt_pk_bf16_f32: the scalar casts above compile to a
+// conversion per element plus a merge
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+
 // Counter-based dropout RNG: a 64-bit (seed, site) key and a (row, column) element index -> 16 uniform bits.
 // Forward and backward regenerate identical masks; nothing is stored. One 32-bit hash serves the two columns of a
 // pair (2c, 2c+1), so a lane that owns adjacent columns pays one integer-multiply round per two elements (the

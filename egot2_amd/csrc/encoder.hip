@@ -55,7 +55,7 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
     EGX_CHECK(cfg->d_model > 0 && cfg->d_model % 4 == 0 && cfg->d_model <= 1024, "d_model=%d unsupported (multiple of 4, <= 1024)", cfg->d_model);
     EGX_CHECK(cfg->n_heads > 0 && cfg->d_model % cfg->n_heads == 0, "d_model=%d not divisible by n_heads=%d", cfg->d_model, cfg->n_heads);
     EGX_CHECK(cfg->d_ff > 0 && cfg->d_ff % 4 == 0, "d_ff=%d must be a positive multiple of 4", cfg->d_ff);
-    EGX_CHECK(cfg->compute == EGX_F32 || cfg->compute == EGX_BF16, "compute=%d unknown", cfg->compute);
+    EGX_CHECK(cfg->compute == EGX_F32 || cfg->compute == EGX_BF16 || cfg->compute == EGX_F32_SPLIT, "compute=%d unknown", cfg->compute);
     EGX_CHECK(B > 0, "empty batch (B=%d)", B);
     pl.B = B; pl.d = cfg->d_model; pl.H = cfg->n_heads; pl.dff = cfg->d_ff; pl.L = cfg->n_layers; pl.nseg = cfg->n_segments;
     int S = 0;
@@ -140,7 +140,7 @@ struct FusedPackLayout {
 static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segment* segs, const Plan& pl, char* base) {
     FusedPackLayout L;
     memset(&L, 0, sizeof(L));
-    int bf = cfg->compute == EGX_BF16;
+    int bf = cfg->compute;      // packed element format follows the compute mode (fused_dev.h)
     size_t cur = 0;
     auto take_p = [&](int R, int K) -> void* { void* q = base ? base + cur : nullptr; cur += align_up(packed_bytes(R, K, bf), 256); return q; };
     for (int i = 0; i < pl.nseg; ++i) L.proj[i] = take_p(pl.d, segs[i].d_in);
@@ -296,16 +296,16 @@ int egx_timing_read(int which, double* total_ms, int* count) { return timing_rea
 
 // Unit-test hook for the fused FFN weight-gradient kernel. scratch: packed W1 + packed W2^T + slabs.
 size_t egx_ffn_dw_scratch(int N, int d_ff, int compute) {
-    int bf = compute == EGX_BF16;
+    int bf = compute;
     return 2 * align_up(packed_bytes(d_ff, 128, bf), 256) + ffn_dw_scratch_bytes(N, d_ff, nullptr);
 }
 int egx_ffn_dw(const float* x1, const float* g, const float* W1, const float* b1, const float* W2, int N, int S, int d_ff,
                float p_drop, uint64_t seed, float* dW1, float* db1, float* dW2, int compute, void* scratch, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    int bf = compute == EGX_BF16;
+    int bf = compute;
     PackParams pk;
     memset(&pk, 0, sizeof(pk));
-    pk.bf16 = bf;
+    pk.mode = bf;
     char* cur = (char*)scratch;
     pk.d[0].src = W1; pk.d[0].dst = cur; pk.d[0].R = d_ff; pk.d[0].K = 128; pk.d[0].ld = 128; pk.d[0].transpose = 0;
     cur += align_up(packed_bytes(d_ff, 128, bf), 256);
@@ -408,7 +408,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         // rewrite the weights into MFMA-fragment order (once per forward; they live behind the saved activations)
         PackParams pk;
         memset(&pk, 0, sizeof(pk));
-        pk.bf16 = comp == EGX_BF16;
+        pk.mode = comp;
         pk.seed_advance = (cfg->advance_seed && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
         FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
         auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose) -> const void* {

@@ -63,11 +63,11 @@ struct PackDesc {
 constexpr int PACK_MAX = 40;
 struct PackParams {
     PackDesc d[PACK_MAX];
-    int n, bf16;
+    int n, mode;                // CM_F32 / CM_BF16 / CM_SPLIT (fused_dev.h): element format of the packed fragments
     uint64_t* seed_advance;     // optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed)
 };
 int pack_weights(PackParams& pp, hipStream_t st);
-static inline size_t packed_bytes(int R, int K, int bf16) { return (size_t)R * K * (bf16 ? 2 : 4); }
+static inline size_t packed_bytes(int R, int K, int mode) { return (size_t)R * K * (mode == 1 ? 2 : mode == 2 ? 6 : 4); }
 
 struct FfnDwParams {
     const float* x1;      // [N][128] FFN input (post-LN1)

@@ -41,9 +41,17 @@ __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
             int row = t * 16 + r, k = kb * 32 + half * 16 + 4 * q + j;
             v[half * 4 + j] = d.transpose ? d.src[(size_t)k * d.ld + row] : d.src[(size_t)row * d.ld + k];
         }
-    if (pp.bf16) {
+    if (pp.mode == CM_BF16) {
         uint4 o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         reinterpret_cast<uint4*>(d.dst)[(size_t)local * 64 + lane] = o;
+    } else if (pp.mode == CM_SPLIT) {
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+        uint4* pl = reinterpret_cast<uint4*>(d.dst) + (size_t)local * 192;
+        pl[lane] = make_uint4(h[0], h[1], h[2], h[3]);
+        pl[64 + lane] = make_uint4(m[0], m[1], m[2], m[3]);
+        pl[128 + lane] = make_uint4(l[0], l[1], l[2], l[3]);
     } else {
         float4* pl = reinterpret_cast<float4*>(d.dst) + (size_t)local * 128;
         pl[lane] = make_float4(v[0], v[1], v[2], v[3]);
@@ -76,7 +84,7 @@ int debug_read_stamps(unsigned long long* out, int n) {
 }
 
 // ---- forward kernel -------------------------------------------------------------------------------
-template <bool BF16, int NT>
+template <int CM, int NT>
 __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SP = NT * 16;                 // padded token count
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             if (s.k0 >= p.seg[s.sgi].d_in) { s.k0 = 0; s.t0 += 16; if (s.t0 >= p.seg[s.sgi].T) { s.t0 = 0; ++s.sgi; } }
             return s;
         };
-        auto issue = [&](const Step& s, Raw (&rb)[4], WRaw<BF16> (&ra0)[4], WRaw<BF16> (&ra1)[4]) {
+        auto issue = [&](const Step& s, Raw (&rb)[4], WRaw<CM> (&ra0)[4], WRaw<CM> (&ra1)[4]) {
             const FusedSeg& sg = p.seg[s.sgi];
             int trow = s.t0 + r;
             bool tv = trow < sg.T;
@@ -128,20 +136,20 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             for (int j = 0; j < 4; ++j) {
                 int k = s.k0 + 32 * j;       // d_in % 128 == 0; rows >= T read row 0 and are discarded at the store
                 rb[j] = load_raw(frow + k, q);
-                ra0[j] = load_w<BF16>(sg.proj_wp, wave * 2 + 0, nkb, k / 32, lane);
-                ra1[j] = load_w<BF16>(sg.proj_wp, wave * 2 + 1, nkb, k / 32, lane);
+                ra0[j] = load_w<CM>(sg.proj_wp, wave * 2 + 0, nkb, k / 32, lane);
+                ra1[j] = load_w<CM>(sg.proj_wp, wave * 2 + 1, nkb, k / 32, lane);
             }
         };
         f32x4 acc[2];
-        auto compute = [&](const Step& s, Raw (&rb)[4], WRaw<BF16> (&ra0)[4], WRaw<BF16> (&ra1)[4]) {
+        auto compute = [&](const Step& s, Raw (&rb)[4], WRaw<CM> (&ra0)[4], WRaw<CM> (&ra1)[4]) {
             const FusedSeg& sg = p.seg[s.sgi];
             pin_all(rb); pin_all(ra0); pin_all(ra1);
             if (s.k0 == 0) { acc[0] = f32x4{0, 0, 0, 0}; acc[1] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                Frag<BF16> b = to_frag<BF16>(rb[j]);
-                mma<BF16>(acc[0], w_frag<BF16>(ra0[j]), b);
-                mma<BF16>(acc[1], w_frag<BF16>(ra1[j]), b);
+                Frag<CM> b = to_frag<CM>(rb[j]);
+                mma<CM>(acc[0], w_frag<CM>(ra0[j]), b);
+                mma<CM>(acc[1], w_frag<CM>(ra1[j]), b);
             }
             if (s.k0 + 128 >= sg.d_in) {
                 int trow = s.t0 + r;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         };
         Raw rbA[4], rbB[4];
-        WRaw<BF16> ra0A[4], ra1A[4], ra0B[4], ra1B[4];
+        WRaw<CM> ra0A[4], ra1A[4], ra0B[4], ra1B[4];
         Step cur{0, 0, 0};
         issue(cur, rbA, ra0A, ra1A);
         while (valid(cur)) {
@@ -223,24 +231,24 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-                WRaw<BF16> wa[3][FD / 32];
+                WRaw<CM> wa[3][FD / 32];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int kb = 0; kb < FD / 32; ++kb)
-                        wa[i][kb] = load_w<BF16>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
+                        wa[i][kb] = load_w<CM>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(wa);
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb) {
-                    Frag<BF16> b[NT];
+                    Frag<CM> b[NT];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(Xs + (t * 16 + r) * LDX + kb * 32, q);
+                    for (int t = 0; t < NT; ++t) b[t] = load_frag<CM>(Xs + (t * 16 + r) * LDX + kb * 32, q);
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
-                        Frag<BF16> a = w_frag<BF16>(wa[i][kb]);
+                        Frag<CM> a = w_frag<CM>(wa[i][kb]);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+                        for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
                     }
                 }
 #pragma unroll
@@ -282,16 +290,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             const int h = wave;
             const float scale = 0.17677669529663687f;   // 1/sqrt(32)
             f32x4 sc[NT][NT];                            // [key tile][query tile]
-            Frag<BF16> kq[NT];
+            Frag<CM> kq[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) kq[t] = load_frag<BF16>(Qs + (t * 16 + r) * LDX + h * FDH, q);
+            for (int t = 0; t < NT; ++t) kq[t] = load_frag<CM>(Qs + (t * 16 + r) * LDX + h * FDH, q);
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                Frag<BF16> a = load_frag<BF16>(Ks + (kt * 16 + r) * LDX + h * FDH, q);
+                Frag<CM> a = load_frag<CM>(Ks + (kt * 16 + r) * LDX + h * FDH, q);
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     sc[kt][qt] = f32x4{0, 0, 0, 0};
-                    mma<BF16>(sc[kt][qt], a, kq[qt]);
+                    mma<CM>(sc[kt][qt], a, kq[qt]);
                 }
             }
             // softmax over keys for every query column; this lane holds keys kt*16 + 4q + e
@@ -342,15 +350,15 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 for (int qt = 0; qt < NT; ++qt) oc[ct][qt] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kb = 0; kb < (NT + 1) / 2; ++kb) {
-                Frag<BF16> a[2];
+                Frag<CM> a[2];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) a[ct] = load_frag<BF16>(Vt + (h * FDH + ct * 16 + r) * LDV + kb * 32, q);
+                for (int ct = 0; ct < 2; ++ct) a[ct] = load_frag<CM>(Vt + (h * FDH + ct * 16 + r) * LDV + kb * 32, q);
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     f32x4 z = f32x4{0, 0, 0, 0};
-                    Frag<BF16> b = chain_frag<BF16>(sc[2 * kb][qt], (2 * kb + 1 < NT) ? sc[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+                    Frag<CM> b = chain_frag<CM>(sc[2 * kb][qt], (2 * kb + 1 < NT) ? sc[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) mma<BF16>(oc[ct][qt], a[ct], b);
+                    for (int ct = 0; ct < 2; ++ct) mma<CM>(oc[ct][qt], a[ct], b);
                 }
             }
             // write O token-major over this head's Q columns (only this wave reads/writes them)
@@ -374,24 +382,24 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            WRaw<BF16> wo[2][FD / 32];
+            WRaw<CM> wo[2][FD / 32];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb)
-                    wo[i][kb] = load_w<BF16>(w.out_proj_wp, wave * 2 + i, FD / 32, kb, lane);
+                    wo[i][kb] = load_w<CM>(w.out_proj_wp, wave * 2 + i, FD / 32, kb, lane);
             __builtin_amdgcn_sched_barrier(0);
             pin_all(wo);
 #pragma unroll
             for (int kb = 0; kb < FD / 32; ++kb) {
-                Frag<BF16> b[NT];
+                Frag<CM> b[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(Qs + (t * 16 + r) * LDX + kb * 32, q);
+                for (int t = 0; t < NT; ++t) b[t] = load_frag<CM>(Qs + (t * 16 + r) * LDX + kb * 32, q);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    Frag<BF16> a = w_frag<BF16>(wo[i][kb]);
+                    Frag<CM> a = w_frag<CM>(wo[i][kb]);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+                    for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
                 }
             }
 #pragma unroll
@@ -417,10 +425,20 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
         STAMP(5);
         // ---- LayerNorm1 in place (res1 saved to HBM for the backward)
+        // CM_SPLIT: x1 is also split into bf16 operand planes for the FFN loop (over Q / K, dead since the out-projection)
+        unsigned short* XP = reinterpret_cast<unsigned short*>(Qs);
+        constexpr int XPS = SP * LDXH;
         ln_rows(X1, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(sv_res1 + (size_t)row * FD + c0, x);
             store32(X1 + row * LDX + c0, y);
+            if constexpr (CM == CM_SPLIT) store_split32(XP, XPS, row, c0, y);
         });
+        if constexpr (CM == CM_SPLIT) {     // padded rows of the planes: zero operands
+            for (int i = tid; i < 3 * (SP - S) * (LDXH / 8); i += 256) {
+                int pl = i / ((SP - S) * (LDXH / 8)), rem = i - pl * ((SP - S) * (LDXH / 8));
+                *reinterpret_cast<uint4*>(XP + pl * XPS + (S + rem / (LDXH / 8)) * LDXH + (rem % (LDXH / 8)) * 8) = make_uint4(0, 0, 0, 0);
+            }
+        }
         __syncthreads();
 
         STAMP(6);
@@ -429,14 +447,14 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         {
             // x1 as B operand: resident in registers for bf16 (48 VGPRs); re-read from LDS per hidden block in fp32,
             // where one block's MFMAs take 12k cycles and the 24 ds_read_b128 are free
-            constexpr bool XRES = BF16;
+            constexpr bool XRES = CM == CM_BF16;
             constexpr int XR = XRES ? FD / 32 : 1;
-            Frag<BF16> xb[XR][NT];
+            Frag<CM> xb[XR][NT];
             if constexpr (XRES) {
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) xb[kb][t] = load_frag<BF16>(X1 + (t * 16 + r) * LDX + kb * 32, q);
+                    for (int t = 0; t < NT; ++t) xb[kb][t] = load_frag<CM>(X1 + (t * 16 + r) * LDX + kb * 32, q);
             }
             f32x4 y[8][NT];
 #pragma unroll
@@ -444,21 +462,21 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[i][t] = f32x4{0, 0, 0, 0};
             const int nhb = p.d_ff / 32;
-            WRaw<BF16> w1r[2][FD / 32];   // W1 rows of the current hidden block (prefetched one phase ahead)
-            WRaw<BF16> w2r[8];            // W2 columns of the current hidden block
+            WRaw<CM> w1r[2][FD / 32];   // W1 rows of the current hidden block (prefetched one phase ahead)
+            WRaw<CM> w2r[8];            // W2 columns of the current hidden block
             float4 b1r[2];
             auto issue_w1 = [&](int hb) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
 #pragma unroll
                     for (int kb = 0; kb < FD / 32; ++kb)
-                        w1r[i][kb] = load_w<BF16>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
+                        w1r[i][kb] = load_w<CM>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
                     b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb * 32 + i * 16 + 4 * q);
                 }
             };
             auto issue_w2 = [&](int hb) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) w2r[i] = load_w<BF16>(w.lin2_wp, i, nhb, hb, lane);
+                for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hb, lane);
             };
             // Every CU walks the same weights: rotate the starting hidden block per clip so that the CUs of an XCD
             // spread their L2 requests over all channels instead of hammering the same few lines in lockstep.
@@ -478,15 +496,18 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     for (int t = 0; t < NT; ++t) hacc[i][t] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb) {
-                    if constexpr (!XRES) {
+                    if constexpr (CM == CM_SPLIT) {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) xb[0][t] = load_frag<BF16>(X1 + (t * 16 + r) * LDX + kb * 32, q);
+                        for (int t = 0; t < NT; ++t) xb[0][t] = load_split_frag(XP, XPS, t * 16 + r, kb * 32, q);
+                    } else if constexpr (!XRES) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) xb[0][t] = load_frag<CM>(X1 + (t * 16 + r) * LDX + kb * 32, q);
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        Frag<BF16> a = w_frag<BF16>(w1r[i][kb]);
+                        Frag<CM> a = w_frag<CM>(w1r[i][kb]);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) mma<BF16>(hacc[i][t], a, xb[XRES ? kb : 0][t]);
+                        for (int t = 0; t < NT; ++t) mma<CM>(hacc[i][t], a, xb[XRES ? kb : 0][t]);
                     }
                 }
                 float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
@@ -523,27 +544,28 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) bits |= (hacc[i][t][e] > 0.f ? 1u : 0u) << ((i * NT + t) * 4 + e);
                 p.relu_bits[(((size_t)l * p.B + clip) * nhb + hb) * 64 + lane] = bits;
-                Frag<BF16> hbq[NT];
+                Frag<CM> hbq[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<BF16>(hacc[0][t], hacc[1][t]);
+                for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<CM>(hacc[0][t], hacc[1][t]);
                 if (p.hid_out) {        // H tiles for the weight-gradient kernel (which then skips its recompute)
-                    constexpr int ESZ = BF16 ? 2 : 4;
+                    constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
                     const int nht = p.d_ff / 16;
                     char* hb_base = (char*)p.hid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            store_hid_tile<BF16>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
+                            store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    Frag<BF16> a = w_frag<BF16>(w2r[i]);
+                    Frag<CM> a = w_frag<CM>(w2r[i]);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mma<BF16>(y[i][t], a, hbq[t]);
+                    for (int t = 0; t < NT; ++t) mma<CM>(y[i][t], a, hbq[t]);
                 }
             }
             STAMP(7);
+            if constexpr (CM == CM_SPLIT) __syncthreads();      // the partials below overwrite the operand planes
             // cross-wave reduction through LDS: wave 0 -> Xs region, waves 1..3 -> Part (aliases Q/K/V^T, now dead)
             float* mine = (wave == 0) ? Xs : Part + (wave - 1) * SP * LDX;
 #pragma unroll
@@ -677,7 +699,7 @@ bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const 
     return true;
 }
 
-template <bool BF16>
+template <int CM>
 static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     // NT = 2 (S <= 32) is not instantiated: shorter sequences run the 48-row kernel with masked padding.
     int NT = p.S <= 48 ? 3 : cdiv(p.S, 16);
@@ -687,12 +709,12 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     case N: {                                                                                                    \
         static bool attr_set = false;                                                                            \
         if (!attr_set) {                                                                                         \
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<BF16, N>),               \
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, N>),               \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             attr_set = true;                                                                                     \
         }                                                                                                        \
         timing_begin(TIMER_FUSED_FWD, st);                                                                       \
-        hipLaunchKernelGGL((fused_fwd_kernel<BF16, N>), grid, block, lds, st, p);                                \
+        hipLaunchKernelGGL((fused_fwd_kernel<CM, N>), grid, block, lds, st, p);                                \
         timing_end(TIMER_FUSED_FWD, st);                                                                         \
     } break;
     switch (NT) {
@@ -705,7 +727,7 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
 }
 
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {
-    return compute == 1 ? launch_fwd<true>(p, st) : launch_fwd<false>(p, st);
+    return compute == CM_BF16 ? launch_fwd<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT>(p, st) : launch_fwd<CM_F32>(p, st);
 }
 
 }  // namespace egx

@@ -10,6 +10,7 @@
 // Same operand convention as the forward (fused_dev.h). Reference math: autograd of
 // torch.nn.TransformerEncoderLayer as built at HHI/models/ttm/model_taskspecific.py:212-215.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
@@ -27,7 +28,7 @@ namespace egx {
 //     dW1 [hid][in]   += dH^T x1           (B gathered from the LDS tile, 8 ds_read_b32 per fragment)
 //     dW2T[hid][dout] += H^T  g
 // accumulated in registers over the whole token range and written once as fp32 slabs.
-template <bool BF16, int HT>
+template <int CM, int HT>
 __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE = 32 * LDX;             // one tensor, 32 tokens
@@ -52,16 +53,17 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 
     // packed weight fragments of this wave's hidden tiles, resident in registers for the whole token range
     // (bf16: 32 VGPRs per tile, fp32: 64; fp32 with HT > 1 re-reads them per K-block instead)
+    constexpr bool BF16 = CM == CM_BF16;
     constexpr bool WRES = BF16 || HT == 1;
     constexpr int WR = WRES ? HT : 1;
-    WRaw<BF16> w1f[WR][4], w2f[WR][4];
+    WRaw<CM> w1f[WR][4], w2f[WR][4];
     if constexpr (WRES) {
 #pragma unroll
         for (int h = 0; h < HT; ++h)
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                w1f[h][k4] = load_w<BF16>(p.w1p, htile0 + h, 4, k4, lane);
-                w2f[h][k4] = load_w<BF16>(p.w2tp, htile0 + h, 4, k4, lane);
+                w1f[h][k4] = load_w<CM>(p.w1p, htile0 + h, 4, k4, lane);
+                w2f[h][k4] = load_w<CM>(p.w2tp, htile0 + h, 4, k4, lane);
             }
     }
 
@@ -96,27 +98,27 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
             }
         }
     };
-    auto row_frag = [&](int buf_idx, int tensor, int tt, int k4) -> Frag<BF16> {
+    auto row_frag = [&](int buf_idx, int tensor, int tt, int k4) -> Frag<CM> {
         if constexpr (BF16) {
             const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (tt * 16 + r) * LDB + k4 * 32 + 4 * q;
             s4v lo = *reinterpret_cast<const s4v*>(b);
             s4v hi = *reinterpret_cast<const s4v*>(b + 16);
-            Frag<true> f;
+            Frag<CM_BF16> f;
             f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return f;
         } else {
-            return load_frag<BF16>(lds + (buf_idx * 2 + tensor) * TILE + (tt * 16 + r) * LDX + k4 * 32, q);
+            return load_frag<CM>(lds + (buf_idx * 2 + tensor) * TILE + (tt * 16 + r) * LDX + k4 * 32, q);
         }
     };
     // fragment with the 32 tokens along K for feature tile jt: element (k = token, j = feature jt*16 + r)
-    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<BF16> {
+    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<CM> {
         if constexpr (BF16) {
             const int i = lane & 15;
             const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
             typedef __attribute__((address_space(3))) s4v lds_s4v;
             s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b));
             s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + 16 * LDB));
-            Frag<true> f;
+            Frag<CM_BF16> f;
             f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return f;
         } else {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
             const int t0 = 4 * q;
             float4 a = make_float4(c[(t0 + 0) * LDX], c[(t0 + 1) * LDX], c[(t0 + 2) * LDX], c[(t0 + 3) * LDX]);
             float4 b = make_float4(c[(t0 + 16) * LDX], c[(t0 + 17) * LDX], c[(t0 + 18) * LDX], c[(t0 + 19) * LDX]);
-            return make_frag<BF16>(a, b);
+            return make_frag<CM>(a, b);
         }
     };
 
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
                 rowkey[i] = (uint32_t)(c * 64 + off);
             }
         }
-        Frag<BF16> aH[HT], aD[HT];
+        Frag<CM> aH[HT], aD[HT];
         f32x4 hc[HT][2], dc[HT][2];
 #pragma unroll
         for (int h = 0; h < HT; ++h)
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             // token-major A fragments, loaded just in time (keeps the kernel at two waves per SIMD)
-            Frag<BF16> ax[2], ag[2];
+            Frag<CM> ax[2], ag[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 ax[tt] = row_frag(cur, 0, tt, k4);
@@ -166,15 +168,15 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
                 if constexpr (!WRES) {
-                    w1f[0][k4] = load_w<BF16>(p.w1p, htile0 + h, 4, k4, lane);
-                    w2f[0][k4] = load_w<BF16>(p.w2tp, htile0 + h, 4, k4, lane);
+                    w1f[0][k4] = load_w<CM>(p.w1p, htile0 + h, 4, k4, lane);
+                    w2f[0][k4] = load_w<CM>(p.w2tp, htile0 + h, 4, k4, lane);
                 }
-                Frag<BF16> b1f = w_frag<BF16>(w1f[WRES ? h : 0][k4]);
-                Frag<BF16> b2f = w_frag<BF16>(w2f[WRES ? h : 0][k4]);
+                Frag<CM> b1f = w_frag<CM>(w1f[WRES ? h : 0][k4]);
+                Frag<CM> b2f = w_frag<CM>(w2f[WRES ? h : 0][k4]);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    mma<BF16>(hc[h][tt], ax[tt], b1f);
-                    mma<BF16>(dc[h][tt], ag[tt], b2f);
+                    mma<CM>(hc[h][tt], ax[tt], b1f);
+                    mma<CM>(dc[h][tt], ag[tt], b2f);
                 }
             }
         }
@@ -198,18 +200,18 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
                     bsum += dv;
                 }
             accB1[h] += bsum;
-            aH[h] = chain_frag<BF16>(hc[h][0], hc[h][1]);
-            aD[h] = chain_frag<BF16>(dc[h][0], dc[h][1]);
+            aH[h] = chain_frag<CM>(hc[h][0], hc[h][1]);
+            aD[h] = chain_frag<CM>(dc[h][0], dc[h][1]);
         }
         // dW accumulation: B operands with the tokens along K (transposed view of the staged tiles)
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            Frag<BF16> bx = tok_frag(cur, 0, jt);
-            Frag<BF16> bg = tok_frag(cur, 1, jt);
+            Frag<CM> bx = tok_frag(cur, 0, jt);
+            Frag<CM> bg = tok_frag(cur, 1, jt);
 #pragma unroll
             for (int h = 0; h < HT; ++h) {
-                mma<BF16>(accW1[h][jt], aD[h], bx);
-                mma<BF16>(accW2[h][jt], aH[h], bg);
+                mma<CM>(accW1[h][jt], aD[h], bx);
+                mma<CM>(accW2[h][jt], aH[h], bg);
             }
         }
         cur ^= 1;
@@ -240,9 +242,13 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 // token-along-K operand tiles (fused_dev.h store_hid_tile), so a wave's A fragments are plain coalesced 1 KB loads
 // and only the two weight-gradient GEMMs remain. K-blocks are pairs of 16-token tiles of the clip-padded token
 // grid (FUSED_TOK_TILES per clip); x1 / g rows of padding tokens are staged as zeros.
-template <bool BF16, int OCC>
+template <int CM, int OCC>
 __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) {
-    constexpr bool PF = OCC <= 2;      // OCC 3: single LDS buffer, no register prefetch, three workgroups per CU
+    constexpr bool BF16 = CM == CM_BF16;
+    constexpr bool SPLIT = CM == CM_SPLIT;
+    // OCC 3: single LDS buffer, no register prefetch, three workgroups per CU. CM_SPLIT: single buffer of three bf16
+    // planes per tensor (54 KB), two workgroups per CU.
+    constexpr bool PF = OCC <= 2 && !SPLIT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TILE = 32 * LDX;
     constexpr int ESZ = BF16 ? 2 : 4;
@@ -265,7 +271,11 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     unsigned short* ldsh = reinterpret_cast<unsigned short*>(lds);
     constexpr int TILEH = 32 * LDB;
     float4 pre[8];
-    Frag<BF16> nH, nD;
+    // the wave's H / dH operand tiles of the next K-block, as loaded (bf16: already operands; fp32 tiles: converted / split
+    // into operands after the prefetch has landed)
+    struct HidRaw { float4 a, b; };
+    struct HidRawB { uint2 a, b; };
+    typename std::conditional<BF16, HidRawB, HidRaw>::type nH, nD;
     auto gload = [&](int kb) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -279,8 +289,17 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         }
         int ta = kb * 2, tb = min(kb * 2 + 1, ntile - 1);     // a missing second tile meets zero x1 / g rows
         size_t oa = ((size_t)ta * nht + htile) * (HTILE_ELEMS * ESZ), ob = ((size_t)tb * nht + htile) * (HTILE_ELEMS * ESZ);
-        nH = load_hid_frag<BF16>((const char*)p.hs + oa, (const char*)p.hs + ob, lane);
-        nD = load_hid_frag<BF16>((const char*)p.dhs + oa, (const char*)p.dhs + ob, lane);
+        if constexpr (BF16) {
+            nH.a = reinterpret_cast<const uint2*>((const char*)p.hs + oa)[lane];
+            nH.b = reinterpret_cast<const uint2*>((const char*)p.hs + ob)[lane];
+            nD.a = reinterpret_cast<const uint2*>((const char*)p.dhs + oa)[lane];
+            nD.b = reinterpret_cast<const uint2*>((const char*)p.dhs + ob)[lane];
+        } else {
+            nH.a = reinterpret_cast<const float4*>((const char*)p.hs + oa)[lane];
+            nH.b = reinterpret_cast<const float4*>((const char*)p.hs + ob)[lane];
+            nD.a = reinterpret_cast<const float4*>((const char*)p.dhs + oa)[lane];
+            nD.b = reinterpret_cast<const float4*>((const char*)p.dhs + ob)[lane];
+        }
     };
     auto lstore = [&](int buf_idx) {
 #pragma unroll
@@ -290,27 +309,46 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             if constexpr (BF16) {
                 uint2 pk = make_uint2(pack_bf16(pre[i].x, pre[i].y), pack_bf16(pre[i].z, pre[i].w));
                 *reinterpret_cast<uint2*>(ldsh + (buf_idx * 2 + tensor) * TILEH + row * LDB + c4 * 4) = pk;
+            } else if constexpr (SPLIT) {       // split once per K-block, shared by the four waves
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split_pair(pre[i].x, pre[i].y, h0, m0, l0);
+                split_pair(pre[i].z, pre[i].w, h1, m1, l1);
+                unsigned short* d = ldsh + tensor * 3 * TILEH + row * LDB + c4 * 4;
+                *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(d + TILEH) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(d + 2 * TILEH) = make_uint2(l0, l1);
             } else {
                 *reinterpret_cast<float4*>(lds + (buf_idx * 2 + tensor) * TILE + row * LDX + c4 * 4) = pre[i];
             }
         }
     };
-    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<BF16> {
+    typedef __attribute__((address_space(3))) s4v lds_s4v;
+    auto tok_frag = [&](int buf_idx, int tensor, int jt) -> Frag<CM> {
         if constexpr (BF16) {
             const int i = lane & 15;
             const unsigned short* b = ldsh + (buf_idx * 2 + tensor) * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
-            typedef __attribute__((address_space(3))) s4v lds_s4v;
             s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b));
             s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + 16 * LDB));
-            Frag<true> f;
+            Frag<CM_BF16> f;
             f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return f;
+        } else if constexpr (SPLIT) {
+            const int i = lane & 15;
+            const unsigned short* b = ldsh + tensor * 3 * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
+            Frag<CM_SPLIT> f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * TILEH));
+                s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * TILEH + 16 * LDB));
+                f.p[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
             return f;
         } else {
             const float* c = lds + (buf_idx * 2 + tensor) * TILE + jt * 16 + r;
             const int t0 = 4 * q;
             float4 a = make_float4(c[(t0 + 0) * LDX], c[(t0 + 1) * LDX], c[(t0 + 2) * LDX], c[(t0 + 3) * LDX]);
             float4 b = make_float4(c[(t0 + 16) * LDX], c[(t0 + 17) * LDX], c[(t0 + 18) * LDX], c[(t0 + 19) * LDX]);
-            return make_frag<BF16>(a, b);
+            return make_frag<CM>(a, b);
         }
     };
 
@@ -322,13 +360,12 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             __syncthreads();            // everyone is done reading the previous K-block
         }
         lstore(cur);
-        Frag<BF16> aH = nH, aD = nD;
-        __syncthreads();
-        if (PF && kb + 1 < kb_end) gload(kb + 1);
         const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
+        Frag<CM> aH, aD;
         if constexpr (BF16) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 u = __builtin_bit_cast(u32x4, aD.v);
+            u32x4 uh = {nH.a.x, nH.a.y, nH.b.x, nH.b.y}, u = {nD.a.x, nD.a.y, nD.b.x, nD.b.y};
+            aH.v = __builtin_bit_cast(bf16x8, uh);
+            aD.v = __builtin_bit_cast(bf16x8, u);
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -337,15 +374,19 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             }
             accB1 += s0 + (has_b ? s1 : 0.f);
         } else {
-            float s0 = (aD.v[0] + aD.v[1]) + (aD.v[2] + aD.v[3]), s1 = (aD.v[4] + aD.v[5]) + (aD.v[6] + aD.v[7]);
+            float s0 = (nD.a.x + nD.a.y) + (nD.a.z + nD.a.w), s1 = (nD.b.x + nD.b.y) + (nD.b.z + nD.b.w);
             accB1 += s0 + (has_b ? s1 : 0.f);
+            aH = make_frag<CM>(nH.a, nH.b);
+            aD = make_frag<CM>(nD.a, nD.b);
         }
+        __syncthreads();
+        if (PF && kb + 1 < kb_end) gload(kb + 1);
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            Frag<BF16> bx = tok_frag(cur, 0, jt);
-            Frag<BF16> bg = tok_frag(cur, 1, jt);
-            mma<BF16>(accW1[jt], aD, bx);
-            mma<BF16>(accW2[jt], aH, bg);
+            Frag<CM> bx = tok_frag(cur, 0, jt);
+            Frag<CM> bg = tok_frag(cur, 1, jt);
+            mma<CM>(accW1[jt], aD, bx);
+            mma<CM>(accW2[jt], aH, bg);
         }
         if constexpr (PF) cur ^= 1;
     }
@@ -429,32 +470,33 @@ size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
     return (size_t)splits * ((size_t)2 * d_ff * FD + d_ff) * sizeof(float);
 }
 
-template <bool BF16>
+template <int CM>
 static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     constexpr int HT = 1;
     size_t lds = (size_t)4 * 32 * LDX * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_kernel<BF16, HT>),
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_kernel<CM, HT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
     if (p.hs) {
-        const int occ = ffn_dw_occ(true, BF16);
+        const int occ = CM == CM_SPLIT ? 2 : ffn_dw_occ(true, CM == CM_BF16);
+        if (CM == CM_SPLIT) lds = (size_t)2 * 3 * 32 * 144 * sizeof(unsigned short);
         static bool attr2_set = false;
         if (!attr2_set) {
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16, 2>),
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<CM, 2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<BF16, 3>),
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<CM, 3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr2_set = true;
         }
-        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16, 3>), grid, dim3(256), lds / 2, st, p);
-        else hipLaunchKernelGGL((ffn_dw_stored_kernel<BF16, 2>), grid, dim3(256), lds, st, p);
+        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2, st, p);
+        else hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 2>), grid, dim3(256), lds, st, p);
     } else {
-        hipLaunchKernelGGL((ffn_dw_kernel<BF16, HT>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((ffn_dw_kernel<CM, HT>), grid, dim3(256), lds, st, p);
     }
     timing_end(TIMER_FFN_DW, st);
     EGX_LAUNCH_CHECK();
@@ -467,7 +509,7 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
     EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
     int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
-    int splits = ffn_dw_splits((p.N + 31) / 32, ffn_dw_occ(p.hs != nullptr, compute == 1));
+    int splits = ffn_dw_splits((p.N + 31) / 32, (compute == CM_SPLIT && p.hs) ? 2 : ffn_dw_occ(p.hs != nullptr, compute == CM_BF16));
     p.splits = splits;
     p.kb_per_split = cdiv(nkb, splits);
     p.splits = cdiv(nkb, p.kb_per_split);
@@ -475,7 +517,7 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     p.slab_w1 = (float*)slabs;
     p.slab_w2t = p.slab_w1 + (size_t)splits * p.d_ff * FD;
     p.slab_b1 = p.slab_w2t + (size_t)splits * p.d_ff * FD;
-    int rc = compute == 1 ? launch_ffn_dw<true>(p, st) : launch_ffn_dw<false>(p, st);
+    int rc = compute == CM_BF16 ? launch_ffn_dw<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_ffn_dw<CM_SPLIT>(p, st) : launch_ffn_dw<CM_F32>(p, st);
     if (rc) return rc;
     SlabReduce3 a;
     a.slab[0] = p.slab_w1; a.out[0] = dW1; a.n[0] = (size_t)p.d_ff * FD;
@@ -513,7 +555,7 @@ int seed_advance(uint64_t* seed, hipStream_t st) {
 // G[32][64] and X[32][128] in LDS (coalesced, next block prefetched in registers); wave w owns rows 16w..16w+15 and
 // gathers its A fragment (and the 8 B fragments) transposed from the token-major tiles. Partials are atomically
 // added into the zero-initialised gradient buffers (<= `splits` adders per element).
-template <bool BF16>
+template <int CM>
 __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
     constexpr int LDG = 64 + 4, LDXS = 128 + 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LDG + 32 * LDXS)];
@@ -562,11 +604,11 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
         lstore(gt, xt);
         __syncthreads();
         if (kb + 1 < kb_end) gload(kb + 1);
-        Frag<BF16> a = gather_frag<BF16>(gt, wave * 16 + r, 0, q, 31, LDG);
+        Frag<CM> a = gather_frag<CM>(gt, wave * 16 + r, 0, q, 31, LDG);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            Frag<BF16> b = gather_frag<BF16>(xt, j * 16 + r, 0, q, 31, LDXS);
-            mma<BF16>(acc[j], a, b);
+            Frag<CM> b = gather_frag<CM>(xt, j * 16 + r, 0, q, 31, LDXS);
+            mma<CM>(acc[j], a, b);
         }
         cur ^= 1;
     }
@@ -649,8 +691,9 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t 
                   (size_t)blocks * 64 * 128 * sizeof(float), slab_bytes);
         p.slabs = (float*)slabs;
     }
-    if (compute == 1) hipLaunchKernelGGL(small_dw_kernel<true>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(small_dw_kernel<false>, dim3(blocks), dim3(256), 0, st, p);
+    if (compute == CM_BF16) hipLaunchKernelGGL(small_dw_kernel<CM_BF16>, dim3(blocks), dim3(256), 0, st, p);
+    else if (compute == CM_SPLIT) hipLaunchKernelGGL(small_dw_kernel<CM_SPLIT>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(small_dw_kernel<CM_F32>, dim3(blocks), dim3(256), 0, st, p);
     if (p.slabs) hipLaunchKernelGGL(small_dw_reduce_kernel, dim3(total_items * 8), dim3(256), 0, st, p);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -670,7 +713,7 @@ int debug_read_bstamps(unsigned long long* out, int n) {
 // One workgroup per clip. Six token-major LDS blocks (48 x 132 fp32 each) are rotated through the roles noted at
 // each phase; small per-head softmax statistics live behind them. Everything that another kernel needs
 // (operands of the weight-gradient GEMMs) is written to HBM exactly once.
-template <bool BF16>
+template <int CM>
 __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     constexpr int NT = 3;
     constexpr int SP = NT * 16;
@@ -816,20 +859,32 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         ln_rows(B5, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(w.x1_out + (tok0 + row) * FD + c0, y);      // x1 is only an operand of the weight-gradient kernel
         });
+        // CM_SPLIT: g2 (B2) is split once into bf16 operand planes for the P4 loop (over B3 / B4: dY.xhat is consumed, B4 is free)
+        unsigned short* GP = reinterpret_cast<unsigned short*>(B3 < B4 ? B3 : B4);
+        constexpr int GPS = SP * LDXH;
+        if constexpr (CM == CM_SPLIT) {
+            static_assert(3 * SP * LDXH * 2 <= 2 * BLK * 4, "operand planes must fit two LDS blocks");
+            const int row = tid >> 2, c0 = (tid & 3) * 32;
+            if (row < SP) {     // padded rows of B2 are zero
+                float g[32];
+                load32(B2 + row * LDX + c0, g);
+                store_split32(GP, GPS, row, c0, g);
+            }
+        }
         __syncthreads();
 
         BSTAMP(2);
         EGX_PHASE();
         // P4: FFN input gradient. dH^T = (W2^T g2^T) .* mask (ReLU sign bits saved by the forward); dX1^T += W1^T dH^T
         {
-            constexpr bool XRES = BF16;
+            constexpr bool XRES = CM == CM_BF16;
             constexpr int XR = XRES ? FD / 32 : 1;
-            Frag<BF16> gb[XR][NT];
+            Frag<CM> gb[XR][NT];
             if constexpr (XRES) {
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) gb[kb][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
+                    for (int t = 0; t < NT; ++t) gb[kb][t] = load_frag<CM>(B2 + (t * 16 + r) * LDX + kb * 32, q);
             }
             f32x4 dxa[8][NT];
 #pragma unroll
@@ -840,19 +895,19 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             const int nit = nhb / 4;
             const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
             auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
-            WRaw<BF16> w2r[2][FD / 32], w3r[8];
+            WRaw<CM> w2r[2][FD / 32], w3r[8];
             uint32_t relu_word;
             const uint32_t* relu_bits = p.relu_bits + ((size_t)l * p.B + clip) * (size_t)(p.d_ff / 32) * 64;
             auto issue_a = [&](int hb) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb) w2r[i][kb] = load_w<BF16>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
+                    for (int kb = 0; kb < FD / 32; ++kb) w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
                 relu_word = relu_bits[(size_t)hb * 64 + lane];
             };
             auto issue_b = [&](int hb) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) w3r[i] = load_w<BF16>(w.lin1_wtp, i, nhb, hb, lane);
+                for (int i = 0; i < 8; ++i) w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hb, lane);
             };
             issue_a(hb_of(0));
             for (int it = 0; it < nit; ++it) {
@@ -866,15 +921,18 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int t = 0; t < NT; ++t) dacc[i][t] = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int kb = 0; kb < FD / 32; ++kb) {
-                    if constexpr (!XRES) {
+                    if constexpr (CM == CM_SPLIT) {
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) gb[0][t] = load_frag<BF16>(B2 + (t * 16 + r) * LDX + kb * 32, q);
+                        for (int t = 0; t < NT; ++t) gb[0][t] = load_split_frag(GP, GPS, t * 16 + r, kb * 32, q);
+                    } else if constexpr (!XRES) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) gb[0][t] = load_frag<CM>(B2 + (t * 16 + r) * LDX + kb * 32, q);
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        Frag<BF16> a2 = w_frag<BF16>(w2r[i][kb]);
+                        Frag<CM> a2 = w_frag<CM>(w2r[i][kb]);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) mma<BF16>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
+                        for (int t = 0; t < NT; ++t) mma<CM>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
                     }
                 }
                 // W1 / W2^T fragments are dead now: fetch W1^T (its latency overlaps the mask/dropout VALU work below);
@@ -890,18 +948,18 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) dacc[i][t][e] = ((bits >> ((i * NT + t) * 4 + e)) & 1u) ? dacc[i][t][e] * dscale : 0.f;
-                Frag<BF16> dq_[NT];
+                Frag<CM> dq_[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<BF16>(dacc[0][t], dacc[1][t]);
+                for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<CM>(dacc[0][t], dacc[1][t]);
                 if (p.dhid_out) {       // dH tiles for the weight-gradient kernel
-                    constexpr int ESZ = BF16 ? 2 : 4;
+                    constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
                     const int nht = p.d_ff / 16;
                     char* hb_base = (char*)p.dhid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
-                            store_hid_tile<BF16>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), dacc[i][t], lane, S - t * 16);
+                            store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), dacc[i][t], lane, S - t * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(w3r);
@@ -909,9 +967,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    Frag<BF16> a = w_frag<BF16>(w3r[i]);
+                    Frag<CM> a = w_frag<CM>(w3r[i]);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mma<BF16>(dxa[i][t], a, dq_[t]);
+                    for (int t = 0; t < NT; ++t) mma<CM>(dxa[i][t], a, dq_[t]);
                 }
             }
         BSTAMP(3);
@@ -963,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             });
         __syncthreads();
         BSTAMP(5);
-        PackW<BF16, 2, 4> wo_pf;        // W_o^T fragments of P7: in flight under the column sums
+        PackW<CM, 2, 4> wo_pf;        // W_o^T fragments of P7: in flight under the column sums
         pack_issue(wo_pf, w.out_proj_wtp, wave * 2, 4, 0);
         // P6: column sums (norm1_w, norm1_b, out_proj_b)
         if (tid < 128) {
@@ -981,7 +1039,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            gemm_packed<BF16, 2, NT, 4>(acc, wo_pf, B2, r, q);
+            gemm_packed<CM, 2, NT, 4>(acc, wo_pf, B2, r, q);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -990,7 +1048,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                         make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
         }
         BSTAMP(6);
-        PackW<BF16, 3, 4> wq_pf;        // first half of the W_in fragments of P9: in flight under the x_in recompute
+        PackW<CM, 3, 4> wq_pf;        // first half of the W_in fragments of P9: in flight under the x_in recompute
         pack_issue(wq_pf, w.in_proj_wp, wave * 6, 4, 0);
         // P8: recompute the layer input x_in -> Gs
         if (l == 0) {
@@ -1040,10 +1098,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             {
                 f32x4 (&a0)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[0]);
                 f32x4 (&a1)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[3]);
-                PackW<BF16, 3, 4> wq2;
+                PackW<CM, 3, 4> wq2;
                 pack_issue(wq2, w.in_proj_wp, wave * 6 + 3, 4, 0);      // second half streams in under the first half's MFMAs
-                gemm_packed<BF16, 3, NT, 4>(a0, wq_pf, Gs, r, q);
-                gemm_packed<BF16, 3, NT, 4>(a1, wq2, Gs, r, q);
+                gemm_packed<CM, 3, NT, 4>(a0, wq_pf, Gs, r, q);
+                gemm_packed<CM, 3, NT, 4>(a1, wq2, Gs, r, q);
             }
             __syncthreads();
 #pragma unroll
@@ -1068,21 +1126,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             float* st_m = stat + (h * 3 + 0) * SP;
             float* st_i = stat + (h * 3 + 1) * SP;
             float* st_d = stat + (h * 3 + 2) * SP;
-            auto ldq = [&](int t) { return load_frag<BF16>(B4 + (t * 16 + r) * LDX + hc, q); };
-            auto ldk = [&](int t) { return load_frag<BF16>(B5 + (t * 16 + r) * LDX + hc, q); };
-            auto ldv = [&](int t) { return load_frag<BF16>(Gs + (t * 16 + r) * LDX + hc, q); };
-            auto ldo = [&](int t) { return load_frag<BF16>(B3 + (t * 16 + r) * LDX + hc, q); };
+            auto ldq = [&](int t) { return load_frag<CM>(B4 + (t * 16 + r) * LDX + hc, q); };
+            auto ldk = [&](int t) { return load_frag<CM>(B5 + (t * 16 + r) * LDX + hc, q); };
+            auto ldv = [&](int t) { return load_frag<CM>(Gs + (t * 16 + r) * LDX + hc, q); };
+            auto ldo = [&](int t) { return load_frag<CM>(B3 + (t * 16 + r) * LDX + hc, q); };
             // orientation T: rows = key, cols = query
             f32x4 pt[NT][NT], dpt[NT][NT];
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
-                Frag<BF16> bq = ldq(qt), bdo = ldo(qt);
+                Frag<CM> bq = ldq(qt), bdo = ldo(qt);
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     pt[kt][qt] = f32x4{0, 0, 0, 0};
                     dpt[kt][qt] = f32x4{0, 0, 0, 0};
-                    mma<BF16>(pt[kt][qt], ldk(kt), bq);      // S^T = K Q^T
-                    mma<BF16>(dpt[kt][qt], ldv(kt), bdo);    // dP^T = V dO^T
+                    mma<CM>(pt[kt][qt], ldk(kt), bq);      // S^T = K Q^T
+                    mma<CM>(dpt[kt][qt], ldv(kt), bdo);    // dP^T = V dO^T
                 }
             }
             auto keep = [&](int query, int key) -> float {   // attention-dropout keep-scale (regenerated, never stored)
@@ -1144,21 +1202,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 for (int qt = 0; qt < NT; ++qt) { oq[ct][qt] = f32x4{0, 0, 0, 0}; dqa[ct][qt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag<BF16> av[2], ak[2];
+                Frag<CM> av[2], ak[2];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    av[ct] = gather_frag<BF16>(Gs, hc + ct * 16 + r, kb * 32, q, SP - 1);
-                    ak[ct] = gather_frag<BF16>(B5, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    av[ct] = gather_frag<CM>(Gs, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    ak[ct] = gather_frag<CM>(B5, hc + ct * 16 + r, kb * 32, q, SP - 1);
                 }
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     f32x4 z = f32x4{0, 0, 0, 0};
-                    Frag<BF16> bp = chain_frag<BF16>(pt[2 * kb][qt], (2 * kb + 1 < NT) ? pt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
-                    Frag<BF16> bs = chain_frag<BF16>(dpt[2 * kb][qt], (2 * kb + 1 < NT) ? dpt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+                    Frag<CM> bp = chain_frag<CM>(pt[2 * kb][qt], (2 * kb + 1 < NT) ? pt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
+                    Frag<CM> bs = chain_frag<CM>(dpt[2 * kb][qt], (2 * kb + 1 < NT) ? dpt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
-                        mma<BF16>(oq[ct][qt], av[ct], bp);
-                        mma<BF16>(dqa[ct][qt], ak[ct], bs);
+                        mma<CM>(oq[ct][qt], av[ct], bp);
+                        mma<CM>(dqa[ct][qt], ak[ct], bs);
                     }
                 }
             }
@@ -1182,8 +1240,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     f32x4 sN = f32x4{0, 0, 0, 0}, dN = f32x4{0, 0, 0, 0};
-                    mma<BF16>(sN, ldq(qt), ldk(kt));    // S = Q K^T
-                    mma<BF16>(dN, ldo(qt), ldv(kt));    // dP = dO V^T
+                    mma<CM>(sN, ldq(qt), ldk(kt));    // S = Q K^T
+                    mma<CM>(dN, ldo(qt), ldv(kt));    // dP = dO V^T
                     int key = kt * 16 + r;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1204,21 +1262,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 for (int kt = 0; kt < NT; ++kt) { dva[ct][kt] = f32x4{0, 0, 0, 0}; dka[ct][kt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag<BF16> ad[2], aq[2];
+                Frag<CM> ad[2], aq[2];
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    ad[ct] = gather_frag<BF16>(B3, hc + ct * 16 + r, kb * 32, q, SP - 1);
-                    aq[ct] = gather_frag<BF16>(B4, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    ad[ct] = gather_frag<CM>(B3, hc + ct * 16 + r, kb * 32, q, SP - 1);
+                    aq[ct] = gather_frag<CM>(B4, hc + ct * 16 + r, kb * 32, q, SP - 1);
                 }
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) {
                     f32x4 z = f32x4{0, 0, 0, 0};
-                    Frag<BF16> bp = chain_frag<BF16>(pn[2 * kb][kt], (2 * kb + 1 < NT) ? pn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
-                    Frag<BF16> bs = chain_frag<BF16>(dsn[2 * kb][kt], (2 * kb + 1 < NT) ? dsn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
+                    Frag<CM> bp = chain_frag<CM>(pn[2 * kb][kt], (2 * kb + 1 < NT) ? pn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
+                    Frag<CM> bs = chain_frag<CM>(dsn[2 * kb][kt], (2 * kb + 1 < NT) ? dsn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct) {
-                        mma<BF16>(dva[ct][kt], ad[ct], bp);
-                        mma<BF16>(dka[ct][kt], aq[ct], bs);
+                        mma<CM>(dva[ct][kt], ad[ct], bp);
+                        mma<CM>(dka[ct][kt], aq[ct], bs);
                     }
                 }
             }
@@ -1246,7 +1304,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
         __syncthreads();
         BSTAMP(9);
-        PackW<BF16, 2, 4> wi_pf;        // W_in^T fragments (dQ part) of P12: in flight under the column sums
+        PackW<CM, 2, 4> wi_pf;        // W_in^T fragments (dQ part) of P12: in flight under the column sums
         pack_issue(wi_pf, w.in_proj_wtp, wave * 2, 12, 0);
         // P11: in_proj_b partials
         if (tid < 128) {
@@ -1263,12 +1321,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            PackW<BF16, 2, 4> wi2, wi3;
+            PackW<CM, 2, 4> wi2, wi3;
             pack_issue(wi2, w.in_proj_wtp, wave * 2, 12, 4);
-            gemm_packed<BF16, 2, NT, 4>(acc, wi_pf, B4, r, q);
+            gemm_packed<CM, 2, NT, 4>(acc, wi_pf, B4, r, q);
             pack_issue(wi3, w.in_proj_wtp, wave * 2, 12, 8);
-            gemm_packed<BF16, 2, NT, 4>(acc, wi2, B5, r, q);
-            gemm_packed<BF16, 2, NT, 4>(acc, wi3, Gs, r, q);
+            gemm_packed<CM, 2, NT, 4>(acc, wi2, B5, r, q);
+            gemm_packed<CM, 2, NT, 4>(acc, wi3, Gs, r, q);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1332,17 +1390,17 @@ int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool determi
     return 0;
 }
 
-template <bool BF16>
+template <int CM>
 static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
     size_t lds = (size_t)(6 * 48 * LDX + FH * 3 * 48) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<BF16>),
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_BWD, st);
-    hipLaunchKernelGGL((fused_bwd_kernel<BF16>), dim3(p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((fused_bwd_kernel<CM>), dim3(p.B), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -1350,7 +1408,7 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
 
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st) {
     EGX_CHECK(p.S <= 48, "fused backward: S=%d > 48", p.S);
-    return compute == 1 ? launch_bwd<true>(p, st) : launch_bwd<false>(p, st);
+    return compute == CM_BF16 ? launch_bwd<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT>(p, st) : launch_bwd<CM_F32>(p, st);
 }
 
 }  // namespace egx

@@ -11,19 +11,52 @@ constexpr int FDH = 32;        // head dim
 constexpr int LDX = FD + 4;    // token-major LDS row stride (floats)
 constexpr int LDV = 64 + 4;    // V^T row stride: keys padded to 64
 
+// ---- compute modes ------------------------------------------------------------------------------
+// CM_F32   exact v_mfma_f32_16x16x4_f32 (8 per 32-wide K-block, 32 cycles each).
+// CM_BF16  operands rounded to bf16, one v_mfma_f32_16x16x32_bf16 per K-block (16 cycles), fp32 accumulate.
+// CM_SPLIT fp32 operands split EXACTLY into three bf16 parts (x = x1 + x2 + x3, 3 x 8 significant bits) and the six products
+//          a1b1 a1b2 a2b1 a1b3 a2b2 a3b1 accumulated by six bf16 MFMAs into the fp32 accumulator. The dropped products
+//          (a2b3, a3b2, a3b3) are below 2^-23 |a||b|, the size of fp32's own product rounding: fp32-grade results at
+//          6 x 16 = 96 matrix-pipe cycles per K-block instead of 8 x 32 = 256.
+enum { CM_F32 = 0, CM_BF16 = 1, CM_SPLIT = 2 };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // ---- operand fragments --------------------------------------------------------------------------
-template <bool BF16> struct Frag { float v[8]; };
-template <> struct Frag<true> { bf16x8 v; };
+template <int CM> struct Frag { float v[8]; };
+template <> struct Frag<CM_BF16> { bf16x8 v; };
+template <> struct Frag<CM_SPLIT> { bf16x8 p[3]; };      // high, middle, low part
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x2(a, b); }
 
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> make_frag(float4 a, float4 b) {
-    Frag<BF16> f;
-    if constexpr (BF16) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// (x, y) -> three packed bf16 pairs with x = x1 + x2 + x3 exactly (round-to-nearest at each level; the last residual has
+// at most 8 significant bits, so its conversion is exact)
+__device__ __forceinline__ void split_pair(float x, float y, uint32_t& h, uint32_t& m, uint32_t& l) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    h = pack_bf16(x, y);
+    f32x2 v = {x, y};
+    f32x2 hv = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    f32x2 r = v - hv;
+    m = pack_bf16(r[0], r[1]);
+    f32x2 mv = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    f32x2 r2 = r - mv;
+    l = pack_bf16(r2[0], r2[1]);
+}
+
+template <int CM>
+__device__ __forceinline__ Frag<CM> make_frag(float4 a, float4 b) {
+    Frag<CM> f;
+    if constexpr (CM == CM_BF16) {
         u32x4 u = {pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b.x, b.y), pack_bf16(b.z, b.w)};
         f.v = __builtin_bit_cast(bf16x8, u);
+    } else if constexpr (CM == CM_SPLIT) {
+        uint32_t h[4], m[4], l[4];
+        split_pair(a.x, a.y, h[0], m[0], l[0]);
+        split_pair(a.z, a.w, h[1], m[1], l[1]);
+        split_pair(b.x, b.y, h[2], m[2], l[2]);
+        split_pair(b.z, b.w, h[3], m[3], l[3]);
+        f.p[0] = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+        f.p[1] = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+        f.p[2] = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
     } else {
         f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
         f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
@@ -32,16 +65,16 @@ __device__ __forceinline__ Frag<BF16> make_frag(float4 a, float4 b) {
 }
 
 // fragment of one row/column for the K-block that starts at p (fp32 memory, 16-byte aligned)
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> load_frag(const float* p, int q) {
+template <int CM>
+__device__ __forceinline__ Frag<CM> load_frag(const float* p, int q) {
     float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
     float4 b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
-    return make_frag<BF16>(a, b);
+    return make_frag<CM>(a, b);
 }
 
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> zero_frag() {
-    return make_frag<BF16>(make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));
+template <int CM>
+__device__ __forceinline__ Frag<CM> zero_frag() {
+    return make_frag<CM>(make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));
 }
 
 // raw (unconverted) fragment data: issued early so that many loads are in flight at once
@@ -52,8 +85,8 @@ __device__ __forceinline__ Raw load_raw(const float* p, int q) {
     x.b = *reinterpret_cast<const float4*>(p + 16 + 4 * q);
     return x;
 }
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> to_frag(const Raw& x) { return make_frag<BF16>(x.a, x.b); }
+template <int CM>
+__device__ __forceinline__ Frag<CM> to_frag(const Raw& x) { return make_frag<CM>(x.a, x.b); }
 // Pins a prefetched fragment at this program point: the loads that produce it must have been issued above (hipcc
 // otherwise sinks every load down to its convert/MFMA and waits on each one individually), and the single
 // s_waitcnt for the whole batch lands here.
@@ -69,15 +102,22 @@ __device__ __forceinline__ void pin(Raw& x) {
 //   one (bf16: uint4) or two (fp32: float4 planes) perfectly coalesced 1 KiB wave accesses.
 //   fp32: float4 plane[half][lane] = W[t*16 + r][kb*32 + half*16 + 4q .. +3]
 //   bf16: uint4  [lane]            = bf16 of the same 8 values (half 0 first)
-template <bool BF16> struct WRaw { float4 a, b; };
-template <> struct WRaw<true> { uint4 v; };
+//   split: uint4 [part][lane]           = the three bf16 parts of the same 8 values (pre-split once per step)
+template <int CM> struct WRaw { float4 a, b; };
+template <> struct WRaw<CM_BF16> { uint4 v; };
+template <> struct WRaw<CM_SPLIT> { uint4 p[3]; };
 
-template <bool BF16>
-__device__ __forceinline__ WRaw<BF16> load_w(const void* packed, int tile, int nkb, int kb, int lane) {
-    WRaw<BF16> x;
+template <int CM>
+__device__ __forceinline__ WRaw<CM> load_w(const void* packed, int tile, int nkb, int kb, int lane) {
+    WRaw<CM> x;
     size_t blk = (size_t)tile * nkb + kb;
-    if constexpr (BF16) {
+    if constexpr (CM == CM_BF16) {
         x.v = reinterpret_cast<const uint4*>(packed)[blk * 64 + lane];
+    } else if constexpr (CM == CM_SPLIT) {
+        const uint4* pl = reinterpret_cast<const uint4*>(packed) + blk * 192;
+        x.p[0] = pl[lane];
+        x.p[1] = pl[64 + lane];
+        x.p[2] = pl[128 + lane];
     } else {
         const float4* pl = reinterpret_cast<const float4*>(packed) + blk * 128;
         x.a = pl[lane];
@@ -85,21 +125,30 @@ __device__ __forceinline__ WRaw<BF16> load_w(const void* packed, int tile, int n
     }
     return x;
 }
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> w_frag(const WRaw<BF16>& x) {
-    if constexpr (BF16) {
-        Frag<true> f;
+template <int CM>
+__device__ __forceinline__ Frag<CM> w_frag(const WRaw<CM>& x) {
+    if constexpr (CM == CM_BF16) {
+        Frag<CM_BF16> f;
         f.v = __builtin_bit_cast(bf16x8, x.v);
         return f;
+    } else if constexpr (CM == CM_SPLIT) {
+        Frag<CM_SPLIT> f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) f.p[i] = __builtin_bit_cast(bf16x8, x.p[i]);
+        return f;
     } else {
-        return make_frag<false>(x.a, x.b);
+        return make_frag<CM_F32>(x.a, x.b);
     }
 }
-__device__ __forceinline__ void pin(WRaw<false>& x) {
+__device__ __forceinline__ void pin(WRaw<CM_F32>& x) {
     asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
 }
-__device__ __forceinline__ void pin(WRaw<true>& x) {
+__device__ __forceinline__ void pin(WRaw<CM_BF16>& x) {
     asm volatile("" : "+v"(x.v.x), "+v"(x.v.y), "+v"(x.v.z), "+v"(x.v.w));
+}
+__device__ __forceinline__ void pin(WRaw<CM_SPLIT>& x) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(x.p[i].x), "+v"(x.p[i].y), "+v"(x.p[i].z), "+v"(x.p[i].w));
 }
 template <class T, int N>
 __device__ __forceinline__ void pin_all(T (&x)[N]) {
@@ -115,16 +164,52 @@ __device__ __forceinline__ void pin_all(T (&x)[N][M]) {
 }
 
 
-// two consecutive 16-row C tiles of a feature-major result -> B operand of the next GEMM (K = those 32 rows)
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> chain_frag(const f32x4& t0, const f32x4& t1) {
-    return make_frag<BF16>(make_float4(t0[0], t0[1], t0[2], t0[3]), make_float4(t1[0], t1[1], t1[2], t1[3]));
+// ---- pre-split operand planes (CM_SPLIT) ------------------------------------------------------------------------------
+// A token-major fp32 LDS block that is the B operand of many MFMAs (the FFN input x1: 64 hidden blocks) is split ONCE
+// into three bf16 planes [part][rows][LDXH]; a fragment is then six ds_read_b64 and no VALU work. Row stride 272 B: the
+// 16 rows x 2 lane groups of a half-wave cover all 64 banks exactly once.
+constexpr int LDXH = FD + 8;
+__device__ __forceinline__ void store_split32(unsigned short* planes, int plane_stride, int row, int c0, const float (&v)[32]) {
+    uint32_t h[16], m[16], l[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+    unsigned short* d = planes + row * LDXH + c0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<uint4*>(d + 8 * g) = make_uint4(h[4 * g], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]);
+        *reinterpret_cast<uint4*>(d + plane_stride + 8 * g) = make_uint4(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]);
+        *reinterpret_cast<uint4*>(d + 2 * plane_stride + 8 * g) = make_uint4(l[4 * g], l[4 * g + 1], l[4 * g + 2], l[4 * g + 3]);
+    }
+}
+__device__ __forceinline__ Frag<CM_SPLIT> load_split_frag(const unsigned short* planes, int plane_stride, int row, int k0, int q) {
+    Frag<CM_SPLIT> f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const unsigned short* b = planes + i * plane_stride + row * LDXH + k0 + 4 * q;
+        uint2 lo = *reinterpret_cast<const uint2*>(b);
+        uint2 hi = *reinterpret_cast<const uint2*>(b + 16);
+        f.p[i] = __builtin_bit_cast(bf16x8, (u32x4){lo.x, lo.y, hi.x, hi.y});
+    }
+    return f;
 }
 
-template <bool BF16>
-__device__ __forceinline__ void mma(f32x4& acc, const Frag<BF16>& a, const Frag<BF16>& b) {
-    if constexpr (BF16) {
+// two consecutive 16-row C tiles of a feature-major result -> B operand of the next GEMM (K = those 32 rows)
+template <int CM>
+__device__ __forceinline__ Frag<CM> chain_frag(const f32x4& t0, const f32x4& t1) {
+    return make_frag<CM>(make_float4(t0[0], t0[1], t0[2], t0[3]), make_float4(t1[0], t1[1], t1[2], t1[3]));
+}
+
+template <int CM>
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<CM>& a, const Frag<CM>& b) {
+    if constexpr (CM == CM_BF16) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+    } else if constexpr (CM == CM_SPLIT) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[2], b.p[0], acc, 0, 0, 0);     // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], b.p[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b.p[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], b.p[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b.p[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b.p[0], acc, 0, 0, 0);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
@@ -155,7 +240,7 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
 }
 constexpr int HTILE_ELEMS = 256;   // one (16 tokens x 16 hidden units) tile
 // `tile` = start of the (token tile, hidden tile) block; tokens >= n_valid (within this 16-token tile) are stored as 0
-template <bool BF16>
+template <int CM>
 __device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int lane, int n_valid) {
     float v[4] = {c[0], c[1], c[2], c[3]};
     quad_transpose(v, lane);
@@ -167,29 +252,27 @@ __device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int l
         for (int j = 0; j < 4; ++j) v[j] = (t0 + j < n_valid) ? v[j] : 0.f;
     }
     const int dst = 4 * q + (r & 3) + 16 * (r >> 2);
-    if constexpr (BF16) {
+    if constexpr (CM == CM_BF16) {
         reinterpret_cast<uint2*>(tile)[dst] = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     } else {
         reinterpret_cast<float4*>(tile)[dst] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 // A/B operand of one K-block of 32 tokens = two consecutive 16-token tiles of one hidden tile
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> load_hid_frag(const void* tile_a, const void* tile_b, int lane) {
-    Frag<BF16> f;
-    if constexpr (BF16) {
+template <int CM>
+__device__ __forceinline__ Frag<CM> load_hid_frag(const void* tile_a, const void* tile_b, int lane) {
+    if constexpr (CM == CM_BF16) {
+        Frag<CM> f;
         uint2 a = reinterpret_cast<const uint2*>(tile_a)[lane];
         uint2 b = reinterpret_cast<const uint2*>(tile_b)[lane];
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         u32x4 u = {a.x, a.y, b.x, b.y};
         f.v = __builtin_bit_cast(bf16x8, u);
+        return f;
     } else {
         float4 a = reinterpret_cast<const float4*>(tile_a)[lane];
         float4 b = reinterpret_cast<const float4*>(tile_b)[lane];
-        f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
-        f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+        return make_frag<CM>(a, b);
     }
-    return f;
 }
 
 __device__ __forceinline__ float wsum(float v) {
@@ -317,26 +400,26 @@ __device__ __forceinline__ float colsum_lds(const float* buf, int r0, int r1, in
 }
 
 // Feature-major GEMM against a token-major LDS operand: acc[i][t] += pack(tile0 + i, kb0 + kb) * B(rows t*16.., cols kb*32..).
-template <bool BF16, int NTI, int NT, int NKB>
+template <int CM, int NTI, int NT, int NKB>
 __device__ __forceinline__ void gemm_pack_lds(f32x4 (&acc)[NTI][NT], const void* pack, int tile0, int nkb_total, int kb0,
                                               const float* ldsB, int r, int q, int lane) {
-    WRaw<BF16> wv[NTI][NKB];
+    WRaw<CM> wv[NTI][NKB];
 #pragma unroll
     for (int i = 0; i < NTI; ++i)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) wv[i][kb] = load_w<BF16>(pack, tile0 + i, nkb_total, kb0 + kb, lane);
+        for (int kb = 0; kb < NKB; ++kb) wv[i][kb] = load_w<CM>(pack, tile0 + i, nkb_total, kb0 + kb, lane);
     __builtin_amdgcn_sched_barrier(0);
     pin_all(wv);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        Frag<BF16> b[NT];
+        Frag<CM> b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(ldsB + (t * 16 + r) * LDX + kb * 32, q);
+        for (int t = 0; t < NT; ++t) b[t] = load_frag<CM>(ldsB + (t * 16 + r) * LDX + kb * 32, q);
 #pragma unroll
         for (int i = 0; i < NTI; ++i) {
-            Frag<BF16> a = w_frag<BF16>(wv[i][kb]);
+            Frag<CM> a = w_frag<CM>(wv[i][kb]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+            for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
         }
     }
 }
@@ -344,37 +427,37 @@ __device__ __forceinline__ void gemm_pack_lds(f32x4 (&acc)[NTI][NT], const void*
 // The same GEMM with its weight fetch split off: pack_issue() early (before the LayerNorm / column-sum / barrier work that
 // precedes the GEMM phase, so the L2 round trip of the fragments is hidden under it), gemm_packed() where the operands are
 // ready. One wave per SIMD: nothing else hides that latency.
-template <bool BF16, int NTI, int NKB> struct PackW { WRaw<BF16> v[NTI][NKB]; };
-template <bool BF16, int NTI, int NKB>
-__device__ __forceinline__ void pack_issue(PackW<BF16, NTI, NKB>& w, const void* pack, int tile0, int nkb_total, int kb0) {
+template <int CM, int NTI, int NKB> struct PackW { WRaw<CM> v[NTI][NKB]; };
+template <int CM, int NTI, int NKB>
+__device__ __forceinline__ void pack_issue(PackW<CM, NTI, NKB>& w, const void* pack, int tile0, int nkb_total, int kb0) {
     int ln = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NTI; ++i)
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) w.v[i][kb] = load_w<BF16>(pack, tile0 + i, nkb_total, kb0 + kb, ln);
+        for (int kb = 0; kb < NKB; ++kb) w.v[i][kb] = load_w<CM>(pack, tile0 + i, nkb_total, kb0 + kb, ln);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <bool BF16, int NTI, int NT, int NKB>
-__device__ __forceinline__ void gemm_packed(f32x4 (&acc)[NTI][NT], PackW<BF16, NTI, NKB>& w, const float* ldsB, int r, int q) {
+template <int CM, int NTI, int NT, int NKB>
+__device__ __forceinline__ void gemm_packed(f32x4 (&acc)[NTI][NT], PackW<CM, NTI, NKB>& w, const float* ldsB, int r, int q) {
     pin_all(w.v);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        Frag<BF16> b[NT];
+        Frag<CM> b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = load_frag<BF16>(ldsB + (t * 16 + r) * LDX + kb * 32, q);
+        for (int t = 0; t < NT; ++t) b[t] = load_frag<CM>(ldsB + (t * 16 + r) * LDX + kb * 32, q);
 #pragma unroll
         for (int i = 0; i < NTI; ++i) {
-            Frag<BF16> a = w_frag<BF16>(w.v[i][kb]);
+            Frag<CM> a = w_frag<CM>(w.v[i][kb]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mma<BF16>(acc[i][t], a, b[t]);
+            for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
         }
     }
 }
 
 // A-operand fragment gathered from a token-major LDS block: element (i = column c0 + r, k = token row of the
 // K-block that starts at row k0): 8 ds_read_b32. Rows are clamped to rmax (callers zero the matching B rows).
-template <bool BF16>
-__device__ __forceinline__ Frag<BF16> gather_frag(const float* buf, int c, int k0, int q, int rmax, int ld = LDX) {
+template <int CM>
+__device__ __forceinline__ Frag<CM> gather_frag(const float* buf, int c, int k0, int q, int rmax, int ld = LDX) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -382,7 +465,7 @@ __device__ __forceinline__ Frag<BF16> gather_frag(const float* buf, int c, int k
         row = row < rmax ? row : rmax;
         v[j] = buf[row * ld + c];
     }
-    return make_frag<BF16>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+    return make_frag<CM>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
 }
 
 }  // namespace egx

@@ -57,8 +57,8 @@ __device__ __forceinline__ void store_kc(typename LdsElem<BF16>::type* lds, cons
         int k = (f & 7) << 2;
         if constexpr (BF16) {
             uint2 pk;
-            pk.x = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
-            pk.y = (uint32_t)f2bf(v[i].z) | ((uint32_t)f2bf(v[i].w) << 16);
+            pk.x = pack_bf16x2(v[i].x, v[i].y);
+            pk.y = pack_bf16x2(v[i].z, v[i].w);
             *reinterpret_cast<uint2*>(lds + row * LDH + k) = pk;
         } else {
             *reinterpret_cast<float4*>(lds + row * LDF + k) = v[i];
@@ -109,11 +109,11 @@ __device__ __forceinline__ void store_mc(typename LdsElem<BF16>::type* lds, cons
         if constexpr (BF16) {
             if constexpr (KT == 4) {
                 uint2 pk;
-                pk.x = (uint32_t)f2bf(e[0]) | ((uint32_t)f2bf(e[1]) << 16);
-                pk.y = (uint32_t)f2bf(e[2]) | ((uint32_t)f2bf(e[3]) << 16);
+                pk.x = pack_bf16x2(e[0], e[1]);
+                pk.y = pack_bf16x2(e[2], e[3]);
                 *reinterpret_cast<uint2*>(lds + row * LDH + kb) = pk;
             } else {
-                uint32_t pk = (uint32_t)f2bf(e[0]) | ((uint32_t)f2bf(e[1]) << 16);
+                uint32_t pk = pack_bf16x2(e[0], e[1]);
                 *reinterpret_cast<uint32_t*>(lds + row * LDH + kb) = pk;
             }
         } else {

@@ -29,7 +29,7 @@ __device__ __forceinline__ bf16x8 rd_tr2(const unsigned char* p0, const unsigned
     bf16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return r;
 }
-__device__ __forceinline__ uint32_t pk(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pk(float a, float b) { return pack_bf16x2(a, b); }
 // two 16-row accumulator tiles (rows 4g + e on the registers) -> one 32-deep B operand
 __device__ __forceinline__ bf16x8 chain(const f32x4& t0, const f32x4& t1) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -50,7 +50,7 @@ __device__ __forceinline__ bf16x8 lds_read_tr2(const unsigned char* p0, const un
     return r;
 }
 __device__ __forceinline__ float bf2f(bf16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 // blocks sharing an XCD (id % 8) get a contiguous range of tiles (bijective for any total)
 __device__ __forceinline__ int xcd_tile(int id, int total) {

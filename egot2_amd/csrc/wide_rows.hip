@@ -18,7 +18,7 @@ __device__ __forceinline__ float wsum64(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ uint32_t pk2(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+__device__ __forceinline__ uint32_t pk2(float a, float b) { return pack_bf16x2(a, b); }
 __device__ __forceinline__ float bff(uint32_t lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 __device__ __forceinline__ int remap(int row, int T, int S, int off) { return (row / T) * S + off + (row % T); }
 

@@ -13,9 +13,11 @@ import torch
 
 from . import _lib
 from ._lib import (Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
-                   EGX_F32, EGX_BF16, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE)
+                   EGX_F32, EGX_BF16, EGX_F32_SPLIT, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE)
 
-COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16}
+# "f32s": fp32 operands split exactly into three bf16 parts, six bf16 MFMAs per K-block (fp32-grade results, fused d = 128
+# kernels only; elsewhere it computes as "f32")
+COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16, "f32s": EGX_F32_SPLIT}
 IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED, "wide": EGX_IMPL_WIDE}
 
 

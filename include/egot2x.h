@@ -33,7 +33,10 @@
  *     is hipGraph-capturable.
  *   - Return value 0 = success; non-zero = error, message via egx_last_error() (thread-local).
  *   - `compute`: EGX_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), EGX_BF16 = bf16 MFMA operands with
- *     fp32 accumulation, fp32 LayerNorm/softmax statistics, fp32 storage.
+ *     fp32 accumulation, fp32 LayerNorm/softmax statistics, fp32 storage. EGX_F32_SPLIT = fp32 operands split exactly into
+ *     three bf16 parts and multiplied by six v_mfma_f32_16x16x32_bf16 per K-block (the dropped cross terms are below fp32's
+ *     own product rounding): fp32-grade results at 2.7x the matrix rate of the fp32 MFMA. Implemented by the fused d = 128
+ *     kernels; everywhere else it means EGX_F32.
  */
 #ifndef EGOT2X_H
 #define EGOT2X_H
@@ -48,7 +51,7 @@ extern "C" {
 #define EGX_ABI_VERSION 7
 #define EGX_MAX_SEGMENTS 8
 
-enum { EGX_F32 = 0, EGX_BF16 = 1 };
+enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
 enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2, EGX_IMPL_WIDE = 3 };
 
 /* One contiguous run of tokens of the packed sequence, produced from one frozen-backbone feature
@@ -122,7 +125,7 @@ typedef struct egx_config {
     int n_layers;
     int n_segments;
     float ln_eps;
-    int compute;      /* EGX_F32 | EGX_BF16 */
+    int compute;      /* EGX_F32 | EGX_BF16 | EGX_F32_SPLIT */
     int impl;         /* EGX_IMPL_* */
     float p_drop;     /* encoder-layer dropout (attention probs, dropout1, FFN hidden, dropout2) */
     float p_pos;      /* dropout on the token-prep output (PositionalEncoding.dropout, fixed 0.1 in HHI) */
