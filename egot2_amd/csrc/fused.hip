@@ -79,6 +79,16 @@ __device__ unsigned long long g_stamps[32];
 #else
 #define STAMP(i) do { } while (0)
 #endif
+// inner-loop accounting of workgroup 0 / wave 0: LSTAMP(k) adds the time since the previous LSTAMP to slot 16 + k
+#ifdef EGX_STAMPS
+#define LSTAMP_INIT() unsigned long long lt_prev = __builtin_amdgcn_s_memtime(), lt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); lt_acc[k] += t_ - lt_prev; lt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LSTAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_stamps[16 + k_] = lt_acc[k_]; } while (0)
+#else
+#define LSTAMP_INIT() do { } while (0)
+#define LSTAMP(k) do { } while (0)
+#define LSTAMP_FLUSH() do { } while (0)
+#endif
 int debug_read_stamps(unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n > 32 ? 32 : n)) == hipSuccess ? 0 : 1;
 }
@@ -478,17 +488,23 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hb, lane);
             };
+            // CM_SPLIT: the wait for the W2 fragments moves behind the epilogue (its MFMA phases are too short to cover the fetch:
+            // 142 -> 137 us). Spreading the 50 loads of a hidden block in quarters between the MFMA groups and epilogue stages
+            // was slower (154 us): a batch of loads issues faster than the same loads one by one.
+            constexpr bool LATE_W2 = CM == CM_SPLIT;
             // Every CU walks the same weights: rotate the starting hidden block per clip so that the CUs of an XCD
             // spread their L2 requests over all channels instead of hammering the same few lines in lockstep.
             const int nit = nhb / 4;
             const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
             auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
             issue_w1(hb_of(0));
+            LSTAMP_INIT();
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
                 issue_w2(hb);                       // in flight while GEMM1 runs
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(w1r);
+                LSTAMP(0);
                 f32x4 hacc[2][NT];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -512,9 +528,11 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 }
                 float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
                 __builtin_amdgcn_sched_barrier(0);
+                LSTAMP(1);
                 if (it + 1 < nit) issue_w1(hb_of(it + 1));  // in flight while GEMM2 runs
                 __builtin_amdgcn_sched_barrier(0);
-                pin_all(w2r);
+                if constexpr (!LATE_W2) pin_all(w2r);
+                LSTAMP(2);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -557,13 +575,22 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         for (int i = 0; i < 2; ++i)
                             store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
                 }
+                if constexpr (LATE_W2) {     // the split-mode epilogue is long enough to cover the W2 fetch: wait here
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin_all(w2r);
+                }
+                LSTAMP(3);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     Frag<CM> a = w_frag<CM>(w2r[i]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mma<CM>(y[i][t], a, hbq[t]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                LSTAMP(4);
             }
+            LSTAMP_FLUSH();
             STAMP(7);
             if constexpr (CM == CM_SPLIT) __syncthreads();      // the partials below overwrite the operand planes
             // cross-wave reduction through LDS: wave 0 -> Xs region, waves 1..3 -> Part (aliases Q/K/V^T, now dead)

@@ -597,6 +597,52 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
         for (int i = 0; i < 4; ++i) { int f = tid + i * 256; *reinterpret_cast<float4*>(xt + (f >> 5) * LDXS + ((f & 31) << 2)) = px[i]; }
     };
     gload(kb_beg);
+    if constexpr (CM == CM_SPLIT) {
+        // Operands are split ONCE per K-block while staging (three bf16 planes per tile, single-buffered: 42 KB) and read back
+        // as token-along-K fragments by the hardware-transposed ds_read_b64_tr_b16: no per-wave gather or split work.
+        constexpr int LGH = 80, LXH = 144;            // halfword row strides: conflict-free transposed reads
+        constexpr int GPL = 32 * LGH, XPL = 32 * LXH;
+        unsigned short* gp = reinterpret_cast<unsigned short*>(lds);
+        unsigned short* xp = gp + 3 * GPL;
+        static_assert((3 * GPL + 3 * XPL) * 2 <= (int)sizeof(lds), "split planes must fit the staging buffer");
+        typedef short s4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s4v lds_s4v;
+        const int i16 = lane & 15;
+        auto tr_frag = [&](const unsigned short* base, int ld, int plane_stride, int c0) {
+            const unsigned short* b = base + (4 * q + (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
+            Frag<CM_SPLIT> f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * plane_stride));
+                s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * plane_stride + 16 * ld));
+                f.p[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            return f;
+        };
+        auto put = [&](unsigned short* d, int plane_stride, const float4& v) {
+            uint32_t h0, m0, l0, h1, m1, l1;
+            split_pair(v.x, v.y, h0, m0, l0);
+            split_pair(v.z, v.w, h1, m1, l1);
+            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l0, l1);
+        };
+        for (int kb = kb_beg; kb < kb_end; ++kb) {
+            if (kb > kb_beg) __syncthreads();           // everyone is done reading the previous K-block
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { int f = tid + i * 256; put(gp + (f >> 4) * LGH + ((f & 15) << 2), GPL, pg[i]); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { int f = tid + i * 256; put(xp + (f >> 5) * LXH + ((f & 31) << 2), XPL, px[i]); }
+            __syncthreads();
+            if (kb + 1 < kb_end) gload(kb + 1);
+            Frag<CM_SPLIT> a = tr_frag(gp, LGH, GPL, wave * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                Frag<CM_SPLIT> b = tr_frag(xp, LXH, XPL, j * 16);
+                mma<CM_SPLIT>(acc[j], a, b);
+            }
+        }
+    } else {
     int cur = 0;
     for (int kb = kb_beg; kb < kb_end; ++kb) {
         float* gt = lds + cur * (32 * LDG + 32 * LDXS);
@@ -611,6 +657,7 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
             mma<CM>(acc[j], a, b);
         }
         cur ^= 1;
+    }
     }
     if (p.slabs) {      // deterministic: dense tile per workgroup, summed in split order by small_dw_reduce_kernel
         float* tile = p.slabs + (size_t)blockIdx.x * (64 * 128);
@@ -939,6 +986,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 // holding all three weight sets at once overflowed the 256 arch VGPRs and spilled to scratch.
                 __builtin_amdgcn_sched_barrier(0);
                 issue_b(hb);
+                // CM_SPLIT: the dX GEMM below is too short (2.3k cycles) to cover the next block's W2^T fetch; start it here
+                if constexpr (CM == CM_SPLIT) { if (it + 1 < nit) issue_a(hb_of(it + 1)); }
                 __builtin_amdgcn_sched_barrier(0);
                 // alive bits = ReLU active AND kept by the forward's dropout: no RNG here
                 const float dscale = w.ffn_thresh ? w.drop_inv : 1.f;
@@ -963,7 +1012,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(w3r);
-                if (it + 1 < nit) issue_a(hb_of(it + 1));   // next block's W1 / W2^T stream in under the dX GEMM
+                if constexpr (CM != CM_SPLIT) { if (it + 1 < nit) issue_a(hb_of(it + 1)); }  // next block's W2^T streams in under the dX GEMM
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {

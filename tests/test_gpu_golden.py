@@ -64,10 +64,14 @@ def hip_run(c, model, feats):
     raise KeyError(c["kind"])
 
 
-@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 6e-2)])
+# "f32s" (fp32 operands split into three bf16 parts, six bf16 MFMA products per K-block) is held to the fp32 tolerances: it
+# is implemented by the fused d = 128 kernels and means "f32" everywhere else, so only the fixtures those kernels run are repeated.
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 6e-2), ("f32s", 1e-3, 1e-2)])
 @pytest.mark.parametrize("name", FIXTURES)
 def test_hip_matches_reference_fixture(egx_lib, cuda, name, compute, tol_out, tol_grad):
     c, z = load_fixture(name)
+    if compute == "f32s" and c["kind"] not in ("ttm2", "ttm3", "asd3"):
+        pytest.skip("f32s differs from f32 only on the fused d = 128 kernels")
     model = build_ours(c)
     model.load_state_dict(seeded_state_dict(model, c["wseed"]))
     model = model.to(cuda).set_compute(compute).train()

@@ -10,7 +10,7 @@ p_drop = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=p_drop)).to(dev).train()
 feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]
 names = ["zero", "proj", "ln0", "qkv", "attn", "outproj", "ln1", "ffn", "part-store", "ln2"]
-for comp in ("f32", "bf16"):
+for comp in ("f32", "f32s", "bf16"):
     m.set_compute(comp, "fused")
     with torch.no_grad():
         for _ in range(3):
@@ -21,3 +21,4 @@ for comp in ("f32", "bf16"):
     lib.egx_debug_stamps(buf, 32)
     t = list(buf)[:10]
     print(comp, "total ticks", t[9] - t[0], " ".join(f"{n}={t[i + 1] - t[i]}" for i, n in enumerate(names[:9])))
+    print("   ffn loop (wave 0): wait_w1 %d gemm1 %d wait_w2 %d epilogue %d gemm2 %d" % tuple(list(buf)[16:21]))

@@ -7,7 +7,7 @@ from egot2_amd.synth import hhi_args
 lib = _lib.load()
 dev = torch.device("cuda:0")
 names = ["load+LN2bwd", "colsum+LN1fwd", "FFN dX", "xwave-sum", "LN1bwd", "colsum+outproj", "x_in", "QKV", "attn", "inb+inproj", "tokprep"]
-for comp in ("f32", "bf16"):
+for comp in ("f32", "f32s", "bf16"):
     for p in (0.0, 0.5):
         m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=p)).to(dev).set_compute(comp, "fused").train()
         if p == 0.0:
