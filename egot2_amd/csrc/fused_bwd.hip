@@ -352,10 +352,16 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         }
     };
 
-    if (PF && kb_beg < kb_end) gload(kb_beg);
+    // CM_SPLIT: register prefetch of the next K-block over its single LDS buffer (the loads fly under this block's MFMAs).
+    // (A 2 x 4 hidden x feature tiling per wave, which halves the LDS fragment reads, was slower: 87 -> 100 us — the kernel
+    // follows its total VALU + MFMA work, and that tiling splits twice as many H / dH tiles per wave.)
+    constexpr bool PF1 = SPLIT;
+    if ((PF || PF1) && kb_beg < kb_end) gload(kb_beg);
     int cur = 0;
     for (int kb = kb_beg; kb < kb_end; ++kb) {
-        if constexpr (!PF) {
+        if constexpr (PF1) {
+            if (kb > kb_beg) __syncthreads();   // everyone is done reading the previous K-block
+        } else if constexpr (!PF) {
             gload(kb);
             __syncthreads();            // everyone is done reading the previous K-block
         }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             aD = make_frag<CM>(nD.a, nD.b);
         }
         __syncthreads();
-        if (PF && kb + 1 < kb_end) gload(kb + 1);
+        if ((PF || PF1) && kb + 1 < kb_end) gload(kb + 1);
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
             Frag<CM> bx = tok_frag(cur, 0, jt);
