@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md. "f32s" (fp32 operands split into three bf16 parts, six bf16 MFMAs
 # per K-block) is bounded by the bf16 pipe at six instructions per algorithmic K-block: 2500 / 6.
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f32s": 2500.0 / 6.0}
+DTYPE_LABEL = {"f32s": "f32 (operands split exactly into 3 bf16 parts; 6 bf16 MFMA products per K-block, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -56,7 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=15)
     ap.add_argument("--layers", type=int, default=0, help="0 = the configuration's own depth")
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32s"], help="default: f32 for c1/c2, bf16 for c3..c5 (BASELINE.json)")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32s"],
+                    help="default: f32s for c1/c2 (fp32-grade split-bf16 arithmetic; f32 = exact fp32 MFMA), bf16 for c3..c5 (BASELINE.json)")
+    ap.add_argument("--no-native-line", action="store_true", help="f32s runs: skip the reference timing of the exact fp32 MFMA path")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")
@@ -188,8 +191,12 @@ def run(args) -> int:
     from egot2_amd.train import FusedAdam
     lib = _lib.load()
 
+    # headline arithmetic of c1 / c2: fp32 operands split exactly into three bf16 parts, six bf16 MFMA products per K-block,
+    # fp32 accumulation ("f32s": fp32-grade results, tests/test_gpu_translator.py::test_split_bf16_mode_is_fp32_grade);
+    # `--dtype f32` is the exact v_mfma_f32_16x16x4_f32 path, reported beside it as `native_f32`
+    run_dtype = args.dtype or ("f32s" if args.config in ("c1", "c2") else None)
     wl = synth.make_workload(args.config, dev, batch=args.batch, frames=args.frames, layers=args.layers or None,
-                             dtype=args.dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
+                             dtype=run_dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
                              feat_dtype=args.feat_dtype, feat_frames=args.feat_frames)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
@@ -398,7 +405,7 @@ def run(args) -> int:
         "metric": metric,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype, "data": "synthetic",
+        "dtype": DTYPE_LABEL.get(dtype, dtype), "data": "synthetic",
         "trials": trials, "ms_per_step_p10": percentile(ms, 0.1), "ms_per_step_p90": percentile(ms, 0.9),
         "ms_per_step_min": min(ms), "timed_seconds": sum(dts),
         "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
@@ -420,6 +427,16 @@ def run(args) -> int:
         m2 = percentile(d2, 0.5) / args.steps * 1e3
         out["with_optimizer"] = {"optimizer": "FusedAdam(lr=5e-4), one launch over the flat parameter buffer",
                                  "ms_per_step": m2, "value": B * world / (m2 * 1e-3), "unit": "clips/s"}
+    if dtype == "f32s" and not multi and not args.no_native_line:
+        # the same step on the exact fp32 MFMA path (v_mfma_f32_16x16x4_f32), for reference
+        model.set_compute("f32", args.impl)
+        step3 = make_step(None)
+        d3 = time_trials(step3, max(3, args.warmup // 2), args.steps, max(3, trials // 2))
+        m3 = percentile(d3, 0.5) / args.steps * 1e3
+        out["native_f32"] = {"arithmetic": "v_mfma_f32_16x16x4_f32 (exact fp32 products)", "ms_per_step": m3,
+                             "value": B * world / (m3 * 1e-3), "unit": "clips/s",
+                             "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (m3 * 1e-3) / 1e12 / PEAK_TFLOPS["f32"]}
+        model.set_compute("f32s", args.impl)
     if rank == 0 and not args.no_roofline:
         model.egx_defer_small = False
         out["roofline"] = measure_roofline(torch, lib, fwd_bwd, wl, dtype)
@@ -513,8 +530,12 @@ def measure_roofline(torch, lib, step, wl, dtype):
         t = res["fused_bwd_kernel"]
         ach = flops["fused_bwd_kernel"] / t / 1e12
         traffic, traffic_src = pmc_traffic(dtype, B, wl["S"] // max(len(wl["feats"]), 1), L, "egx::fused_bwd_kernel")
+        extra = {}
+        if dtype == "f32s":
+            extra = {"peak_note": "bf16 dense MFMA peak (2500 TFLOP/s) / 6 instructions per algorithmic K-block; the exact fp32 MFMA peak "
+                                  "is 157.3 TFLOP/s", "frac_of_native_f32_mfma_peak": ach / PEAK_TFLOPS["f32"]}
         return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "unit": "TFLOP/s", "frac": ach / peak, **extra, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src,
                 "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
                 "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,

@@ -4,7 +4,7 @@ args=$1; shift
 cp egot2_amd/libegot2x.so /tmp/lib_keep.so
 for n in "$@"; do
   cp egot2_amd/_variants/lib_$n.so egot2_amd/libegot2x.so
-  python bench.py $args --no-cpu-baseline --no-optimizer-line 2>&1 | grep "^{" | python -c "
+  python bench.py $args --no-cpu-baseline --no-optimizer-line --no-native-line 2>&1 | grep "^{" | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); r = d.get('roofline') or {}

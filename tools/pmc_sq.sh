@@ -9,7 +9,7 @@ P2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_V
 i=0
 for P in "$P1" "$P2"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sq_${dt}_$i -o r -- python3 bench.py --dtype $dt --no-graph --no-cpu-baseline --no-roofline --no-optimizer-line --steps 10 --warmup 3 > gpurun_out/sq_${dt}_$i.log 2>&1
+  rocprofv3 --pmc $P --kernel-trace --output-format csv -d gpurun_out/sq_${dt}_$i -o r -- python3 bench.py --dtype $dt --no-graph --no-cpu-baseline --no-roofline --no-optimizer-line --no-native-line --steps 10 --warmup 3 > gpurun_out/sq_${dt}_$i.log 2>&1
 done
 python3 - "$dt" <<'PY'
 import csv, glob, json, sys, collections

@@ -8,7 +8,7 @@ dt=${1:-f32}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${dt}_$c -o r -- python3 bench.py --dtype $dt --no-graph --no-cpu-baseline --no-roofline --no-optimizer-line --steps 20 --warmup 5 > gpurun_out/pmc_${dt}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_${dt}_$c -o r -- python3 bench.py --dtype $dt --no-graph --no-cpu-baseline --no-roofline --no-optimizer-line --no-native-line --steps 20 --warmup 5 > gpurun_out/pmc_${dt}_$c.log 2>&1
 done
 python3 - "$dt" <<'PY'
 import csv, glob, json, sys, collections

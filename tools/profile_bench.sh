@@ -6,7 +6,7 @@ cfg=${1:-c2}; tag=${2:-prof_$cfg}; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$root"
 rm -rf gpurun_out/$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o r -- python3 bench.py --config $cfg --no-roofline --no-cpu-baseline --no-optimizer-line "$@" > gpurun_out/$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o r -- python3 bench.py --config $cfg --no-roofline --no-cpu-baseline --no-optimizer-line --no-native-line "$@" > gpurun_out/$tag.log 2>&1
 python3 - "$tag" <<'PY'
 import csv, glob, shutil, sys
 tag = sys.argv[1]
