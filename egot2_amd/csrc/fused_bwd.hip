@@ -422,7 +422,15 @@ __device__ __forceinline__ void reduce_slabs_block(const SlabReduce3& a, unsigne
     for (int k = 0; k < 3; ++k) {
         if (i < a.n[k]) {
             float4 s = *reinterpret_cast<const float4*>(a.out[k] + i);
-            for (int z = 0; z < a.nslab; ++z) {
+            int z = 0;
+            for (; z + 8 <= a.nslab; z += 8) {      // eight loads in flight, summed in slab order
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(a.slab[k] + (size_t)(z + j) * a.n[k] + i);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+            }
+            for (; z < a.nslab; ++z) {
                 float4 v = *reinterpret_cast<const float4*>(a.slab[k] + (size_t)z * a.n[k] + i);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
