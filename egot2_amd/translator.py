@@ -52,7 +52,7 @@ def encoder_layer_tensors(encoder: nn.TransformerEncoder) -> List[torch.Tensor]:
 
 
 class TranslatorMixin:
-    """Adds the HIP encoder call to an nn.Module. `egx_compute` in {"f32", "bf16"}; `egx_impl` in
+    """Adds the HIP encoder call to an nn.Module. `egx_compute` in {"f32", "bf16", "f32s"}; `egx_impl` in
     {"auto", "generic", "fused"}."""
 
     egx_compute: str = "f32"

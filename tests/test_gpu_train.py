@@ -109,10 +109,11 @@ def test_adam_kernel_semantics(egx_lib, cuda, adamw, wd):
         assert torch.allclose(x, y, rtol=2e-5, atol=2e-6), (x - y).abs().max().item()
 
 
-def test_whole_training_step_in_one_graph(egx_lib, cuda):
+@pytest.mark.parametrize("compute", ["f32", "f32s"])
+def test_whole_training_step_in_one_graph(egx_lib, cuda, compute):
     """forward + fused CE + backward + FusedAdam captured once and replayed: parameters must follow the eager run."""
     from egot2_amd.train import CrossEntropyLoss, FusedAdam
-    ref_model, m = _ttm(cuda, 3), _ttm(cuda, 3)
+    ref_model, m = _ttm(cuda, 3).set_compute(compute), _ttm(cuda, 3).set_compute(compute)
     crit = CrossEntropyLoss(torch.FloatTensor(CE_W)).to(cuda)
     feats = [f.to(cuda) for f in seeded_feats(77, [(16, 15, 256)] * 3)]
     target = torch.randint(0, 2, (16,), generator=torch.Generator().manual_seed(1)).to(cuda)
@@ -141,7 +142,7 @@ def test_whole_training_step_in_one_graph(egx_lib, cuda):
         graph.replay()
     torch.cuda.synchronize()
     # eager 1 + 3 replays = 4 steps; bring the reference to the same count
-    ref4 = _ttm(cuda, 3)
+    ref4 = _ttm(cuda, 3).set_compute(compute)
     opt4 = FusedAdam(ref4.parameters(), lr=5e-4)
     for _ in range(4):
         one_step(ref4, opt4)
@@ -261,7 +262,7 @@ def test_run_ttm_synth_plumbing_entry(egx_lib, cuda):
     spec.loader.exec_module(mod)
     for name in ("TaskFusionMFTransformer2Task", "TaskFusionMFTransformer3Task"):
         losses = mod.main(["--model", name, "--num_layers", "1", "--hidden_dim", "128", "--dropout", "0.1", "--steps", "24",
-                           "--lr", "2e-3"])
+                           "--lr", "2e-3", "--dtype", "f32s" if name.endswith("3Task") else "f32"])
         assert all(l == l for l in losses) and sum(losses[-4:]) < sum(losses[:4])
 
 
@@ -322,7 +323,7 @@ def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, ov
         assert torch.allclose(p.grad.cpu(), torch.from_numpy(grads[k]), rtol=2e-3, atol=2e-6), k
 
 
-@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("compute", ["f32", "bf16", "f32s"])
 def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute):
     """same inputs + same dropout seed => bit-identical logits and gradients across runs with
     `set_deterministic()`: the fused backward sums its split-K slabs and per-clip partial rows in a fixed order instead of

@@ -35,7 +35,7 @@ def parser():
     p.add_argument("--batch_size", type=int, default=32)
     p.add_argument("--frames", type=int, default=15)
     p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32s"])
     p.add_argument("--seed", type=int, default=0)
     return p
 
