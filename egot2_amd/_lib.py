@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 7
+EGX_ABI_VERSION = 9
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
@@ -52,7 +52,7 @@ class Config(C.Structure):
                 ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
                 ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float), ("seed_ptr", _fp),
                 ("advance_seed", C.c_int), ("zero_buf", _fp), ("zero_bytes", C.c_size_t), ("bwd_stage", C.c_int),
-                ("deterministic", C.c_int)]
+                ("deterministic", C.c_int), ("out_tokens", C.c_int)]
 
 
 # symbol -> (restype, argtypes); every symbol include/egot2x.h declares
@@ -89,6 +89,9 @@ SIGNATURES = {
     "egx_relu_mask": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
     "egx_dropout": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
     "egx_weighted_ce": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "egx_linear_ce_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "egx_linear_ce_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "egx_linear_ce_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]),
     "egx_counter_add": (C.c_int, [_fp, C.c_int64, _fp]),
     "egx_adam_step": (C.c_int, [_fp, _fp, _fp, _fp, C.c_size_t, _fp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_float, _fp]),

@@ -57,6 +57,7 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
     EGX_CHECK(cfg->d_ff > 0 && cfg->d_ff % 4 == 0, "d_ff=%d must be a positive multiple of 4", cfg->d_ff);
     EGX_CHECK(cfg->compute == EGX_F32 || cfg->compute == EGX_BF16 || cfg->compute == EGX_F32_SPLIT, "compute=%d unknown", cfg->compute);
     EGX_CHECK(B > 0, "empty batch (B=%d)", B);
+    EGX_CHECK(cfg->out_tokens >= 0, "out_tokens=%d", cfg->out_tokens);
     pl.B = B; pl.d = cfg->d_model; pl.H = cfg->n_heads; pl.dff = cfg->d_ff; pl.L = cfg->n_layers; pl.nseg = cfg->n_segments;
     int S = 0;
     for (int i = 0; i < pl.nseg; ++i) {
@@ -446,6 +447,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.ln_w = ln_w; fp.ln_b = ln_b; fp.eps = cfg->ln_eps;
         fp.nseg = pl.nseg; fp.n_layers = pl.L; fp.B = B; fp.S = S; fp.d_ff = pl.dff;
         fp.tokens_out = tokens_out;
+        fp.out_T = cfg->out_tokens > 0 ? cfg->out_tokens : S;
         if (with_head) {
             fp.head.ln_w = head->ln_w; fp.head.ln_b = head->ln_b; fp.head.W = head->W; fp.head.b = head->b; fp.head.n_out = head->n_out;
             fp.logits_out = logits_out;
@@ -463,6 +465,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     if (ferr) return 1;
     {
         bool werr;
+        EGX_CHECK(cfg->out_tokens == 0 || cfg->out_tokens == S, "out_tokens is implemented by the fused per-clip kernels only (egx_encoder_impl() == EGX_IMPL_FUSED)");
         if (use_wide(cfg, segs, pl, &werr)) {
             size_t wsv = 0, wsc = 0;
             wide_workspace(cfg, segs, B, &wsv, &wsc);
@@ -589,6 +592,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.ln_w = ln_w; bp.ln_b = ln_b; bp.eps = cfg->ln_eps;
             bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = B; bp.S = S; bp.d_ff = pl.dff;
             bp.d_tokens = d_tokens;
+            bp.out_T = cfg->out_tokens > 0 ? cfg->out_tokens : S;
             if (with_head) {
                 bp.head.ln_w = head->ln_w; bp.head.ln_b = head->ln_b; bp.head.W = head->W; bp.head.b = head->b; bp.head.n_out = head->n_out;
                 bp.d_logits = d_logits;
@@ -960,6 +964,17 @@ int egx_attention_bwd(const float* qkv, const float* out, const float* lse, cons
 int egx_weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
                     float* d_logits, void* stream) {
     return weighted_ce(logits, target, weight, B, C, loss, d_logits, (hipStream_t)stream);
+}
+
+size_t egx_linear_ce_scratch(int M, int K, int C) { return linear_ce_scratch_bytes(M, K, C); }
+int egx_linear_ce_fwd(const float* x, const float* W, const float* b, const int64_t* target, const float* weight, int M, int K,
+                      int C, float* logits, float* probs, float* d_logits, float* loss, float* correct, float* pred_label,
+                      void* scratch, void* stream) {
+    return linear_ce_fwd(x, W, b, target, weight, M, K, C, logits, probs, d_logits, loss, correct, pred_label, scratch, (hipStream_t)stream);
+}
+int egx_linear_ce_bwd(const float* x, const float* W, const float* d_logits, const float* grad_scale, int M, int K, int C,
+                      float* dx, float* dW, float* db, void* scratch, void* stream) {
+    return linear_ce_bwd(x, W, d_logits, grad_scale, M, K, C, dx, dW, db, scratch, (hipStream_t)stream);
 }
 
 int egx_counter_add(int64_t* counter, int64_t inc, void* stream) { return counter_add(counter, inc, (hipStream_t)stream); }

@@ -44,7 +44,8 @@ struct FusedFwdParams {
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
-    float* tokens_out;      // (B, S, 128) or null when only the head output is wanted
+    float* tokens_out;      // (B, out_T, 128) or null when only the head output is wanted
+    int out_T;              // tokens of every clip that leave the kernel (S, or egx_config.out_tokens)
     FusedHead head; float* logits_out;   // (B, n_out) when head.n_out > 0
     float* saved_pre;       // (B, S, 128)   projected features before the shared LN (token order)
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
@@ -122,7 +123,8 @@ struct FusedBwdParams {
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
-    const float* d_tokens;     // (B, S, 128), or null when the head is fused (then d_logits drives the backward)
+    const float* d_tokens;     // (B, out_T, 128), or null when the head is fused (then d_logits drives the backward)
+    int out_T;                 // tokens of every clip that carry an upstream gradient (S, or egx_config.out_tokens)
     FusedHead head; const float* d_logits; int head_off;   // head_off: offset of the head section in the partial row
     const float* saved_pre;    // from the forward
     const float* saved_res;

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             bool last = (l + 1 == p.n_layers);
             ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 store32(sv_res2 + (size_t)row * FD + c0, x);
-                if (last && p.tokens_out) store32(p.tokens_out + ((size_t)clip * S + row) * FD + c0, y);
+                if (last && p.tokens_out && row < p.out_T) store32(p.tokens_out + ((size_t)clip * p.out_T + row) * FD + c0, y);
                 if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
             });
         }

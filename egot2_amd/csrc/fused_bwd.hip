@@ -875,8 +875,11 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(pooled + 128 + c);
         }
         __syncthreads();
-    } else {
-        load_block(Gs, p.d_tokens + tok0 * FD);
+    } else {        // rows >= out_T carry no upstream gradient (LDS is zero there)
+        for (int i = tid; i < p.out_T * (FD / 4); i += 256) {
+            int row = i >> 5, c = (i & 31) << 2;
+            *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(p.d_tokens + ((size_t)clip * p.out_T + row) * FD + c);
+        }
     }
 
     for (int l = p.n_layers - 1; l >= 0; --l) {

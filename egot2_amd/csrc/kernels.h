@@ -95,6 +95,11 @@ int pool_head_bwd(const float* d_out, const float* pooled, int B, int S, int d, 
 int weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
                 float* dlogits, hipStream_t st);
 int counter_add(int64_t* c, int64_t inc, hipStream_t st);
+size_t linear_ce_scratch_bytes(int M, int K, int C);
+int linear_ce_fwd(const float* x, const float* W, const float* b, const int64_t* target, const float* weight, int M, int K, int C,
+                  float* logits, float* probs, float* dlogits, float* loss, float* correct, float* pred, void* scratch, hipStream_t st);
+int linear_ce_bwd(const float* x, const float* W, const float* dlogits, const float* gscale, int M, int K, int C, float* dx,
+                  float* dW, float* db, void* scratch, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, const int64_t* step, float lr, float b1, float b2,
               float eps, float wd, int decoupled, float grad_scale, hipStream_t st);
 

@@ -51,12 +51,13 @@ class EncoderSpec:
     advance_seed: bool = False   # with seed_ptr: the training forward advances the device seed in its first kernel
     defer_small: bool = False    # backward: leave the grouped small weight gradients to run_deferred() (all-reduce overlap)
     deterministic: bool = False  # backward: fixed-order reductions instead of fp32 atomics (bit-identical gradients run to run)
+    out_tokens: int = 0          # > 0: return (and take the gradient of) only the first `out_tokens` tokens of every clip
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
                       COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
                       self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0, 0,
-                      int(bool(self.deterministic)))
+                      int(bool(self.deterministic)), int(self.out_tokens))
 
 
 _scratch_cache = {}
@@ -235,6 +236,15 @@ class EncoderFn(torch.autograd.Function):
                 probe = spec.config()
                 if lib.egx_encoder_impl(C.byref(probe), segs, B) == EGX_IMPL_FUSED:
                     spec = dataclasses.replace(spec, impl="generic")
+        # first-tokens-only output: in-kernel on the fused path; elsewhere the full block is sliced here (and the gradient
+        # scattered back in backward)
+        py_slice = 0
+        if spec.out_tokens:
+            import dataclasses
+            full = dataclasses.replace(spec, out_tokens=0)
+            probe = full.config()
+            if nhead or lib.egx_encoder_impl(C.byref(probe), segs, B) != EGX_IMPL_FUSED:
+                py_slice, spec = spec.out_tokens, full
         cfg = spec.config()
         sv, sc = C.c_size_t(0), C.c_size_t(0)
         ws = lib.egx_translator_workspace if nhead else lib.egx_encoder_workspace
@@ -254,9 +264,12 @@ class EncoderFn(torch.autograd.Function):
             check(lib.egx_translator_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(tokens),
                                          None, ptr(saved), ptr(scratch), int(spec.training), seed, _stream()))
         else:
-            tokens = torch.empty((B, S, d), dtype=torch.float32, device=device)
+            tokens = torch.empty((B, spec.out_tokens or S, d), dtype=torch.float32, device=device)
             check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
                                       ptr(scratch), int(spec.training), seed, _stream()))
+            if py_slice:
+                tokens = tokens[:, :py_slice].contiguous()
+        ctx.py_slice, ctx.S = py_slice, S
         ctx.spec = spec
         ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
         ctx.fused_path = ctx.impl == EGX_IMPL_FUSED
@@ -271,6 +284,10 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_tokens):
+        if ctx.py_slice:        # gradient of the python-side slice: zeros behind the first tokens
+            full = torch.zeros((d_tokens.shape[0], ctx.S, d_tokens.shape[2]), dtype=torch.float32, device=d_tokens.device)
+            full[:, :ctx.py_slice] = d_tokens
+            d_tokens = full
         lib = _lib.load()
         spec: EncoderSpec = ctx.spec
         sv = list(ctx.saved_tensors)
@@ -638,6 +655,82 @@ def weighted_cross_entropy(logits, target, weight=None):
     Labels outside [0, C) - including F.cross_entropy's default ignore_index = -100 - contribute neither loss, weight nor
     gradient."""
     return WeightedCEFn.apply(logits, target, weight)
+
+
+_LCE_SCRATCH = {}
+
+
+def _lce_scratch(device, nbytes: int) -> torch.Tensor:
+    """Scratch of the fused classifier head: arrival counters (zero between launches) + partial sums. One per device, grown
+    on demand; a new buffer is zero-filled once (the kernels leave the counters zero again)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _LCE_SCRATCH.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _LCE_SCRATCH[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+    return t
+
+
+class LinearCEFn(torch.autograd.Function):
+    """(loss, logits, probs, pred, correct) of Linear(K -> C) followed by weighted cross-entropy, ONE launch forward and ONE backward
+    (egx_linear_ce_*): the ASD task's lossAV, HHI/tasks/asd/loss.py:11-30. Only `loss` carries gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, target, weight):
+        lib = _lib.load()
+        x, W = _dev_f32(x, "x"), _dev_f32(W, "weight")
+        if x.dim() != 2 or W.dim() != 2 or W.shape[1] != x.shape[1]:
+            raise ValueError(f"linear_cross_entropy expects x (M, K) and W (C, K), got {tuple(x.shape)} and {tuple(W.shape)}")
+        M, K = x.shape
+        Cn = W.shape[0]
+        if Cn > 8 or K not in (64, 128, 256):
+            raise ValueError(f"linear_cross_entropy supports C <= 8 classes and K in (64, 128, 256), got C={Cn}, K={K}")
+        if target.dtype != torch.int64 or target.shape != (M,) or target.device != x.device:
+            raise ValueError("target must be an int64 tensor of shape (M,) on the input's device")
+        b = _dev_f32(b, "bias") if b is not None else None
+        w = _dev_f32(weight, "class weight") if weight is not None else None
+        if w is not None and w.numel() != Cn:
+            raise ValueError("weight must have one entry per class")
+        tgt = target.contiguous()
+        logits = torch.empty((M, Cn), dtype=torch.float32, device=x.device)
+        probs = torch.empty_like(logits)
+        need = any(ctx.needs_input_grad[:3])
+        dl = torch.empty_like(logits) if need else None
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        correct = torch.empty((), dtype=torch.float32, device=x.device)
+        pred = torch.empty((M,), dtype=torch.float32, device=x.device)
+        scratch = _lce_scratch(x.device, lib.egx_linear_ce_scratch(M, K, Cn))
+        check(lib.egx_linear_ce_fwd(ptr(x), ptr(W), ptr(b) if b is not None else None, ptr(tgt), ptr(w) if w is not None else None,
+                                    M, K, Cn, ptr(logits), ptr(probs), ptr(dl) if dl is not None else None, ptr(loss), ptr(correct),
+                                    ptr(pred), ptr(scratch), _stream()))
+        ctx.has_b = b is not None
+        ctx.shape = (M, K, Cn)
+        if need:
+            ctx.save_for_backward(x, W, dl)
+        ctx.mark_non_differentiable(logits, probs, pred, correct)
+        ctx.set_materialize_grads(False)    # no zero-filled "gradients" for the four auxiliary outputs (a fill launch each)
+        return loss, logits, probs, pred, correct
+
+    @staticmethod
+    def backward(ctx, g_loss, _gl, _gp, _gr, _gc):
+        if g_loss is None:
+            return None, None, None, None, None
+        lib = _lib.load()
+        x, W, dl = ctx.saved_tensors
+        M, K, Cn = ctx.shape
+        g = g_loss.contiguous().float()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty((Cn,), dtype=torch.float32, device=x.device) if ctx.has_b else None
+        scratch = _lce_scratch(x.device, lib.egx_linear_ce_scratch(M, K, Cn))
+        check(lib.egx_linear_ce_bwd(ptr(x), ptr(W), ptr(dl), ptr(g), M, K, Cn, ptr(dx) if dx is not None else None, ptr(dW),
+                                    ptr(db) if db is not None else None, ptr(scratch), _stream()))
+        return dx, dW if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, None, None
+
+
+def linear_cross_entropy(x, W, b, target, weight=None):
+    """(loss, logits, probs, pred, correct): F.cross_entropy(F.linear(x, W, b), target, weight=weight) plus softmax(logits),
+    round(softmax)[:, 1] and the number of rows where that equals the label, in one launch (lossAV, HHI/tasks/asd/loss.py:17-30)."""
+    return LinearCEFn.apply(x, W, b, target, weight)
 
 
 # ---- EgoT2-g sequence decoder pieces (SURVEY.md §8f row F1; kernels in csrc/decoder.hip) ------------------------------

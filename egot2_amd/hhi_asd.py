@@ -70,9 +70,10 @@ class TaskFusionMFTransformer3Task(TaskFusion3Task, TranslatorMixin):
                 for f, k in zip(feats, (2, 0, 1))]
         tokens = self._egx_encode(feats, segs, encoder=self.transformer_encoder, ln=self.ln,
                                   projs=[self.proj_asd, self.proj_ttm, self.proj_lam], task_embed=self.task_embed,
-                                  pos_table=self.pos_embed.pe, p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p)
+                                  pos_table=self.pos_embed.pe, p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p,
+                                  out_tokens=asd_out.shape[1])     # x[0:D] of model_taskspecific.py:156-158, without the copy
         N, D = asd_out.shape[0], asd_out.shape[1]
-        return tokens[:, 0:D, :].reshape(N * D, -1)
+        return tokens.reshape(N * D, -1)
 
     def forward(self, video, video_asd, audio, audio_asd):
         with torch.no_grad():
@@ -85,3 +86,25 @@ class TaskFusionMFTransformer3Task(TaskFusion3Task, TranslatorMixin):
             lam_out = self.lam_model(video, middle=True)
             ttm_out = self.ttm_model(video, audio, middle=True)
         return self.forward_features(ttm_out, lam_out, asd_out)
+
+
+class lossAV(nn.Module):
+    """Drop-in for the ASD task's classifier + criterion, HHI/tasks/asd/loss.py:11-30: `FC = Linear(dim, 2)` and
+    `CrossEntropyLoss(weight=[1, 4])` with the same attribute names (checkpoint keys `FC.weight`, `FC.bias`,
+    `criterion.weight`) and the same return values. With labels the whole forward (logits, loss, softmax scores, rounded
+    labels, number of correct frames) is one launch and its backward one launch (`functional.linear_cross_entropy`); the
+    stock modules take ~10 launches and cost 15 % of the ASD translator step."""
+
+    def __init__(self, dim: int = 256):
+        super().__init__()
+        self.criterion = nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 4]))
+        self.FC = nn.Linear(dim, 2)
+
+    def forward(self, x, labels=None):
+        from . import functional as F_egx
+        x = x.squeeze(1)
+        if labels is None:      # inference: scores of class 1 as a numpy vector, as the reference returns them
+            z = F_egx.linear(x, self.FC.weight, self.FC.bias, "f32")
+            return z[:, 1].t().reshape(-1).detach().cpu().numpy()
+        nloss, _, predScore, predLabel, correctNum = F_egx.linear_cross_entropy(x, self.FC.weight, self.FC.bias, labels, self.criterion.weight)
+        return nloss, predScore, predLabel, correctNum

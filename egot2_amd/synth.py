@@ -91,17 +91,16 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
         model = model.to(device).set_compute(dtype or "bf16", impl).train()
         feats = [_randn(gen, (B, T, 256), device) for _ in range(3)]
         target = torch.randint(0, 2, (B * T,), generator=gen).to(device)
-        # the classifier lives outside the model: lossAV.FC = Linear(dim, 2) + CE(weight [1, 4]), HHI/tasks/asd/loss.py:11-30
-        fc = torch.nn.Linear(128, 2).to(device)
-        crit = CrossEntropyLoss(torch.FloatTensor([1.0, 4.0])).to(device)
-        comp = dtype or "bf16"
-        loss_fn = lambda: crit(F_egx.linear(model.forward_features(*feats), fc.weight, fc.bias, comp), target)   # noqa: E731
+        # the classifier lives outside the model: lossAV = Linear(dim, 2) + CE(weight [1, 4]) + scores, HHI/tasks/asd/loss.py:11-30
+        # (video_task_taskspecific.py:24,33: nloss, _, _, prec = self.lossAV.forward(outsAV, labels))
+        head = hhi_asd.lossAV(128).to(device)
+        loss_fn = lambda: head(model.forward_features(*feats), target)[0]   # noqa: E731
         segs = [(T, 256, True)] * 3
         fl = encoder_flops(B, segs, 128, 2048, L)
         desc = (f"configs[2]: ASD 3-task translator, {L} layers d=128 h=4 d_ff=2048, B={B}/GPU T={T} S={3 * T}, per-frame "
-                f"output (B*T, d) + lossAV.FC + weighted CE, dropout={p}")
+                f"output (B*T, d) + lossAV (FC + weighted CE + scores, one launch each way), dropout={p}")
         d, S = 128, 3 * T
-        model.extra_params = list(fc.parameters())
+        model.extra_params = list(head.FC.parameters())
     elif name == "c4":
         from . import hoi_lta
         L = layers or 4

@@ -87,8 +87,9 @@ class TranslatorMixin:
     def _egx_encode(self, feats: Sequence[torch.Tensor], segments: List[SegmentSpec], *, encoder: nn.TransformerEncoder,
                     ln: nn.LayerNorm, projs: Sequence[Optional[nn.Linear]], task_embed: Optional[torch.Tensor],
                     pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0,
-                    head=None) -> torch.Tensor:
-        """head = (nn.LayerNorm, nn.Linear): evaluate the pooled head with the encoder and return logits (B, n_out)."""
+                    head=None, out_tokens: int = 0) -> torch.Tensor:
+        """head = (nn.LayerNorm, nn.Linear): evaluate the pooled head with the encoder and return logits (B, n_out).
+        out_tokens = T > 0: return only the first T tokens of every clip, (B, T, d) (in-kernel on the fused path)."""
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
@@ -101,7 +102,8 @@ class TranslatorMixin:
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
                            head_n_out=head[1].out_features if head is not None else 0,
                            advance_seed=seed_dev is not None and bool(self.training),   # fresh masks per (replayed) step
-                           defer_small=bool(self.egx_defer_small), deterministic=bool(self.egx_deterministic))
+                           defer_small=bool(self.egx_defer_small), deterministic=bool(self.egx_deterministic),
+                           out_tokens=int(out_tokens))
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:

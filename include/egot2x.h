@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 7
+#define EGX_ABI_VERSION 9
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -148,6 +148,11 @@ typedef struct egx_config {
                                  same inputs and seed give bit-identical gradients run to run. Honoured by the fused per-clip
                                  kernels; the wide bf16 path is always deterministic; the shape-generic kernels keep their
                                  atomic reductions. */
+    int out_tokens;           /* 0 = the whole sequence. T > 0: only the first T tokens of every clip leave the encoder
+                                 (tokens_out is (B, T, d)) and only they receive an upstream gradient (d_tokens is (B, T, d)) —
+                                 the ASD translator returns its first segment, HHI/models/asd/model_taskspecific.py:156-158;
+                                 without this the caller slices (copy) and autograd zero-fills and scatters the gradient.
+                                 Fused per-clip kernels only (egx_encoder_impl() == EGX_IMPL_FUSED); an error elsewhere. */
 } egx_config;
 
 int egx_abi_version(void);
@@ -280,6 +285,20 @@ int egx_seed_advance(uint64_t* seed, void* stream);
  * Replaces nn.CrossEntropyLoss(weight=[0.266, 0.734]) and its backward, HHI/tasks/ttm/video_task_2loader.py:21-22,34. */
 int egx_weighted_ce(const float* logits, const int64_t* target, const float* weight, int B, int C, float* loss,
                     float* d_logits, void* stream);
+/* Classifier head of the ASD task in one launch each way: logits = x W^T + b; loss = weighted CE(logits, target) as above;
+ * probs = softmax(logits) (optional), pred_label = round(probs[:, 1]) (M, optional), *correct = number of rows with
+ * pred_label == target (optional), d_logits = d loss / d logits (optional). x (M, K) fp32, W (C, K), b (C) or NULL, C <= 8, K a multiple of 64. Replaces lossAV.forward,
+ * HHI/tasks/asd/loss.py:11-30 (nn.Linear(dim, 2) + nn.CrossEntropyLoss(weight=[1, 4]) + softmax / round / count), whose
+ * separate launches cost 15 % of the ASD translator step. `scratch`: egx_linear_ce_scratch(M, K, C) bytes, ZERO before the
+ * first use (arrival counters; every launch leaves them zero again). Sums run in a fixed order (deterministic).
+ * Backward: dx = g * d_logits W (optional), dW = g * d_logits^T x, db = g * colsum(d_logits) (db optional), g = *grad_scale
+ * (device scalar, NULL = 1). K in {64, 128, 256}. */
+size_t egx_linear_ce_scratch(int M, int K, int C);
+int egx_linear_ce_fwd(const float* x, const float* W, const float* b, const int64_t* target, const float* weight, int M, int K,
+                      int C, float* logits, float* probs, float* d_logits, float* loss, float* correct, float* pred_label,
+                      void* scratch, void* stream);
+int egx_linear_ce_bwd(const float* x, const float* W, const float* d_logits, const float* grad_scale, int M, int K, int C,
+                      float* dx, float* dW, float* db, void* scratch, void* stream);
 /* *counter += inc on the stream (device-resident step count of the optimizer). */
 int egx_counter_add(int64_t* counter, int64_t inc, void* stream);
 /* One Adam (decoupled = 0) / AdamW (decoupled = 1) update of n fp32 elements with torch.optim semantics:

@@ -5,7 +5,7 @@ import copy
 import pytest
 import torch
 
-from tests.util import hhi_args, seeded_feats, seeded_state_dict
+from tests.util import hhi_args, rel_err, seeded_feats, seeded_state_dict
 
 pytestmark = pytest.mark.gpu
 CE_W = [0.266, 0.734]
@@ -351,3 +351,65 @@ def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute
     for k in a[1]:
         assert torch.equal(a[1][k], b[1][k]), k
         assert torch.allclose(a[1][k], c[1][k], rtol=2e-3, atol=1e-6), k
+
+
+@pytest.mark.parametrize("M,K,C,weighted", [(3840, 128, 2, True), (45, 128, 2, True), (1, 64, 2, False), (1000, 256, 5, True), (70000, 128, 2, True)])
+def test_fused_linear_cross_entropy_matches_torch(egx_lib, cuda, M, K, C, weighted):
+    """egx_linear_ce_*: Linear + weighted CE (+ softmax scores and the correct-frame count of lossAV) in one launch each way
+    against torch's F.linear / F.cross_entropy autograd, including ignored labels and a non-unit upstream gradient."""
+    from egot2_amd import functional as F_egx
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(cuda).requires_grad_(True)
+    W = (torch.randn(C, K, generator=g) * 0.2).to(cuda).requires_grad_(True)
+    b = torch.randn(C, generator=g).to(cuda).requires_grad_(True)
+    y = torch.randint(0, C, (M,), generator=g)
+    if M > 10:
+        y[3] = -100                                   # F.cross_entropy's default ignore_index
+    y = y.to(cuda)
+    w = torch.tensor([1.0, 4.0, 0.5, 2.0, 3.0][:C], device=cuda) if weighted else None
+    loss, logits, probs, pred, correct = F_egx.linear_cross_entropy(x, W, b, y, w)
+    (loss * 1.7).backward()
+    xr, Wr, br = (t.detach().clone().requires_grad_(True) for t in (x, W, b))
+    zr = torch.nn.functional.linear(xr, Wr, br)
+    lr = torch.nn.functional.cross_entropy(zr, y, weight=w)
+    (lr * 1.7).backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(logits, zr, rtol=1e-5, atol=1e-5)
+    assert abs(loss.item() - lr.item()) < 1e-5 * max(1.0, abs(lr.item()))
+    assert torch.allclose(probs, torch.softmax(zr, dim=-1), rtol=1e-5, atol=1e-6)
+    assert torch.equal(pred, torch.round(torch.softmax(zr, dim=-1))[:, 1])
+    assert correct.item() == (pred == y).sum().item()
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-4, atol=1e-7)
+    assert rel_err(W.grad, Wr.grad) < 1e-5 and rel_err(b.grad, br.grad) < 1e-5
+    # fixed-order sums: a second run is bit-identical
+    x2, W2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, W, b))
+    l2 = F_egx.linear_cross_entropy(x2, W2, b2, y, w)[0]
+    (l2 * 1.7).backward()
+    assert torch.equal(l2, loss) and torch.equal(W2.grad, W.grad) and torch.equal(b2.grad, b.grad)
+
+
+def test_lossAV_mirror_matches_the_stock_modules(egx_lib, cuda):
+    """hhi_asd.lossAV against nn.Linear + nn.CrossEntropyLoss(weight=[1, 4]) + softmax / round / count as written in
+    HHI/tasks/asd/loss.py:11-30, with a shared state_dict (same parameter and buffer names)."""
+    from egot2_amd import hhi_asd
+    torch.manual_seed(3)
+    ours = hhi_asd.lossAV(128).to(cuda)
+    fc = torch.nn.Linear(128, 2).to(cuda)
+    crit = torch.nn.CrossEntropyLoss(weight=torch.FloatTensor([1, 4])).to(cuda)
+    assert set(ours.state_dict()) == {"criterion.weight", "FC.weight", "FC.bias"}
+    fc.load_state_dict({"weight": ours.FC.weight.detach(), "bias": ours.FC.bias.detach()})
+    x = torch.randn(705, 1, 128, device=cuda)
+    y = torch.randint(0, 2, (705,), device=cuda)
+    xo, xs = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    nloss, score, label, num = ours(xo, y)
+    nloss.backward()
+    z = fc(xs.squeeze(1))
+    ref = crit(z, y)
+    ref.backward()
+    assert abs(nloss.item() - ref.item()) < 1e-5
+    assert torch.allclose(score, torch.softmax(z, -1), atol=1e-6)
+    assert torch.equal(label, torch.round(torch.softmax(z, -1))[:, 1]) and num.item() == (label == y).sum().item()
+    assert torch.allclose(xo.grad, xs.grad, rtol=1e-4, atol=1e-8)
+    assert rel_err(ours.FC.weight.grad, fc.weight.grad) < 1e-5 and rel_err(ours.FC.bias.grad, fc.bias.grad) < 1e-5
+    import numpy as np
+    assert np.allclose(ours(x), z[:, 1].detach().cpu().numpy(), atol=1e-5)

@@ -163,3 +163,42 @@ def test_bf16_matches_fp32_under_the_same_dropout_masks(egx_lib, cuda, impl):
     errs = {k: rel_err(b[1][k], a[1][k]) for k in a[1]}
     bad = {k: v for k, v in errs.items() if not v < 8e-2}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("compute", ["f32", "f32s", "bf16"])
+def test_first_tokens_only_output_matches_the_slice(egx_lib, cuda, compute):
+    """egx_config.out_tokens (ASD: only the first segment leaves the encoder, HHI/models/asd/model_taskspecific.py:156-158):
+    the fused kernels emit / take the gradient of the first T tokens directly. Same kernels, same compute mode, with the full
+    block sliced in Python instead: outputs are bit-identical, gradients equal to accumulation-order noise. The shape-generic
+    path (which always slices in Python) must agree as well."""
+    from egot2_amd import hhi_asd
+    from egot2_amd.functional import SegmentSpec
+    B, T = 37, 15
+    feats = [f.to(cuda) for f in seeded_feats(91, [(B, T, 256)] * 3)]
+    w = torch.randn(B * T, 128, generator=torch.Generator().manual_seed(5)).to(cuda)
+
+    def sliced_in_python(m, ttm_out, lam_out, asd_out):
+        fs = [asd_out, ttm_out, lam_out]
+        segs = [SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=True, add_row=k, pos_row0=0) for f, k in zip(fs, (2, 0, 1))]
+        tokens = m._egx_encode(fs, segs, encoder=m.transformer_encoder, ln=m.ln, projs=[m.proj_asd, m.proj_ttm, m.proj_lam],
+                               task_embed=m.task_embed, pos_table=m.pos_embed.pe, p_drop=m.dp_rate, p_pos=m.pos_embed.dropout.p)
+        assert tokens.shape == (B, 3 * T, 128)
+        return tokens[:, :T].reshape(B * T, -1)
+
+    res = {}
+    for tag, impl, fn in (("kernel", "fused", None), ("python", "fused", sliced_in_python), ("generic", "generic", None)):
+        m = hhi_asd.TaskFusionMFTransformer3Task(hhi_args(num_layers=2, dropout=0.0))
+        m.load_state_dict(seeded_state_dict(m, 17))
+        m = m.to(cuda).set_compute(compute, impl).train()
+        m.pos_embed.dropout.p = 0.0
+        out = fn(m, *feats) if fn else m.forward_features(*feats)
+        assert out.shape == (B * T, 128)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        res[tag] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(res["kernel"][0], res["python"][0])
+    assert set(res["kernel"][1]) == set(res["python"][1]) == set(res["generic"][1])
+    for k, g in res["python"][1].items():
+        assert rel_err(res["kernel"][1][k], g) < 1e-5, k
+    tol = 2e-2 if compute == "bf16" else 1e-4
+    assert torch.allclose(res["kernel"][0], res["generic"][0], rtol=tol, atol=tol)
