@@ -61,28 +61,40 @@ __device__ __forceinline__ int xcd_tile(int id, int total) {
 }  // namespace
 
 // ---- NT ---------------------------------------------------------------------------------------------------------------
-// BM x 128 output tile, BM / 64 x 2 waves. D LDS stages form a ring: stage kt + D - 1 is issued while stage kt is consumed,
-// a counted s_waitcnt leaves the newer stages in flight across the barrier (the L2 / HBM latency of a tile is several times
-// the 32 MFMAs a wave runs per K step, so a single prefetched stage leaves the matrix pipe waiting).
-template <int BM, int D>
-__global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams p, int ntM, int ntN) {
-    constexpr int NW = BM / 32;                      // waves
-    constexpr int WM = BM / 64;                      // waves along m
-    constexpr int SB = (BM + TBN) * TBK * 2;         // stage bytes
-    constexpr int NB = TBN / 8 / NW;                 // B-tile staging instructions per wave (8 rows each)
+// BM x BN output tile, (BM / WTM) x (BN / 64) waves of WTM x 64 each. D LDS stages form a ring: stage kt + D - 1 is issued
+// while stage kt is consumed, a counted s_waitcnt leaves the newer stages in flight across the barrier (the L2 / HBM latency
+// of a tile is several times the MFMAs a wave runs per K step, so a single prefetched stage leaves the matrix pipe waiting).
+// Variants: 256 x 128 (wave 64 x 64, 3 stages) and 128 x 128 (2 stages, two workgroups per CU) fetch 11.4 B per kFLOP
+// through L2 -> LDS, which caps them near 700 TFLOP/s (measured: the L2 -> CU path delivers ~6.5 TB/s to 256 CUs running
+// them); 256 x 256 (wave 128 x 64, 2 stages of 64 KB) fetches 7.6 B per kFLOP.
+template <int N> __device__ __forceinline__ void wait_vm() {
+    if constexpr (N == 0) EGX_WAIT_VM(0);
+    else if constexpr (N == 6) EGX_WAIT_VM(6);
+    else if constexpr (N == 8) EGX_WAIT_VM(8);
+    else if constexpr (N == 12) EGX_WAIT_VM(12);
+    else if constexpr (N == 16) EGX_WAIT_VM(16);
+    else static_assert(N == 0, "add the s_waitcnt immediate");
+}
+template <int BM, int BN, int WTM, int D>
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_nt_kernel(WideGemmParams p, int ntM, int ntN) {
+    constexpr int WM = BM / WTM;                     // waves along m
+    constexpr int NW = WM * (BN / 64);               // waves
+    constexpr int TJ = WTM / 16;                     // 16-row tiles of X per wave (4 W tiles of 16 columns)
+    constexpr int SB = (BM + BN) * TBK * 2;          // stage bytes
+    constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;   // staging instructions per wave (8 rows = 1 KiB each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, ntM * ntN);
-    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * TBN;
+    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * BN;
 
-    // staging: wave w copies rows [32w, 32w + 32) of the X tile and [8 NB w, + 8 NB) of the W tile, 8 rows (1 KiB) per instruction
+    // staging: wave w copies rows [8 NA w, + 8 NA) of the X tile and [8 NB w, + 8 NB) of the W tile
     const int srow = lane >> 3;                       // row within the 8-row group == (row & 7)
     const int lch = (lane & 7) ^ srow;                // logical 16-byte chunk this lane fetches
-    const bf16_t* srcA[4];
+    const bf16_t* srcA[NA];
     const bf16_t* srcB[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int gm = m0 + (wave * 4 + j) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
+    for (int j = 0; j < NA; ++j) {
+        int gm = m0 + (wave * NA + j) * 8 + srow; gm = gm < p.M ? gm : p.M - 1;
         srcA[j] = p.A + (size_t)gm * p.lda + lch * 8;
     }
 #pragma unroll
@@ -91,11 +103,11 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams 
         srcB[j] = p.B + (size_t)gn * p.ldb + lch * 8;
     }
     auto stage = [&](int kt, int buf) {
-        unsigned char* sa = smem + buf * SB + wave * 4096;
+        unsigned char* sa = smem + buf * SB + wave * NA * 1024;
         unsigned char* sb = smem + buf * SB + BM * TBK * 2 + wave * NB * 1024;
         const int k0 = kt * TBK;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(srcA[j] + k0, sa + j * 1024);
+        for (int j = 0; j < NA; ++j) glds16(srcA[j] + k0, sa + j * 1024);
 #pragma unroll
         for (int j = 0; j < NB; ++j) glds16(srcB[j] + k0, sb + j * 1024);
     };
@@ -103,14 +115,14 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams 
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
     // fragment byte offsets inside a stage: rows of X (m) / W (n); chunk (s * 4 + g) ^ (row & 7), row & 7 == r & 7
-    const int offX = (wm * 64 + r) * 128, offW = BM * TBK * 2 + (wn * 64 + r) * 128;
+    const int offX = (wm * WTM + r) * 128, offW = BM * TBK * 2 + (wn * 64 + r) * 128;
     const int c0 = ((0 * 4 + g) ^ (r & 7)) * 16, c1 = ((1 * 4 + g) ^ (r & 7)) * 16;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     const int nk = p.K / TBK;
 #pragma unroll
@@ -119,9 +131,9 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams 
     int buf = 0, nbuf = D - 1;                       // buffer of stage kt / of stage kt + D - 1
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt must have landed; the (up to D - 2) stages issued after it may stay in flight
-        if (D >= 4 && kt + 2 < nk) { if (NB == 4) EGX_WAIT_VM(16); else EGX_WAIT_VM(12); }
-        else if (D >= 3 && kt + 1 < nk) { if (NB == 4) EGX_WAIT_VM(8); else EGX_WAIT_VM(6); }
-        else EGX_WAIT_VM(0);
+        if (D >= 4 && kt + 2 < nk) wait_vm<2 * (NA + NB)>();
+        else if (D >= 3 && kt + 1 < nk) wait_vm<NA + NB>();
+        else wait_vm<0>();
         ring_barrier();
         if (kt + D - 1 < nk) stage(kt + D - 1, nbuf);
         const unsigned char* st = smem + buf * SB;
@@ -130,27 +142,30 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams 
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int cs = s ? c1 : c0;
-            bf16x8 fw[4], fx[4];
+            bf16x8 fw[4], fx[TJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) fw[i] = lds_read128(st + offW + i * 2048 + cs);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fx[j] = lds_read128(st + offX + j * 2048 + cs);
+            for (int j = 0; j < TJ; ++j) fx[j] = lds_read128(st + offX + j * 2048 + cs);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // epilogue: lane (r, g) of tile (i, j) holds C[m0 + wm*64 + j*16 + r][n0 + wn*64 + i*16 + 4g .. +3]
-    float cs_part[4][4];
+    // epilogue: lane (r, g) of tile (i, j) holds C[m0 + wm*WTM + j*16 + r][n0 + wn*64 + i*16 + 4g .. +3]
+    constexpr int JG = WTM / 64;                     // 64-row groups of a wave: one column-sum partial row each
+    float cs_part[JG][4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int jg = 0; jg < JG; ++jg)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cs_part[i][e] = 0.f;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + r;
+            for (int e = 0; e < 4; ++e) cs_part[jg][i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + r;
         const bool mv = m < p.M;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -187,70 +202,83 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_nt_kernel(WideGemmParams 
                 uint2 o = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
                 *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = o;
                 if (p.colsum) {     // sums of the values as stored (bf16-rounded), so that db == colsum(stored dY) exactly
-                    cs_part[i][0] += bf2f((bf16_t)(o.x & 0xffffu)); cs_part[i][1] += bf2f((bf16_t)(o.x >> 16));
-                    cs_part[i][2] += bf2f((bf16_t)(o.y & 0xffffu)); cs_part[i][3] += bf2f((bf16_t)(o.y >> 16));
+                    cs_part[j / 4][i][0] += bf2f((bf16_t)(o.x & 0xffffu)); cs_part[j / 4][i][1] += bf2f((bf16_t)(o.x >> 16));
+                    cs_part[j / 4][i][2] += bf2f((bf16_t)(o.y & 0xffffu)); cs_part[j / 4][i][3] += bf2f((bf16_t)(o.y >> 16));
                 }
             } else if (p.colsum) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) cs_part[i][e] += v[e];
+                for (int e = 0; e < 4; ++e) cs_part[j / 4][i][e] += v[e];
             }
         }
     }
     if (p.colsum) {      // one partial row per 64 output rows: [ceil(M / 64)][N]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int jg = 0; jg < JG; ++jg) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s = cs_part[i][e];
-                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-                cs_part[i][e] = s;
-            }
-        if (r == 0) {
-            const int prow = m0 / 64 + wm;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + i * 16 + 4 * g;
-                if (n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)prow * p.N + n) =
-                    make_float4(cs_part[i][0], cs_part[i][1], cs_part[i][2], cs_part[i][3]);
+                for (int e = 0; e < 4; ++e) {
+                    float s = cs_part[jg][i][e];
+                    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                    cs_part[jg][i][e] = s;
+                }
+            if (r == 0) {
+                const int prow = m0 / 64 + wm * JG + jg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + wn * 64 + i * 16 + 4 * g;
+                    if (n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)prow * p.N + n) =
+                        make_float4(cs_part[jg][i][0], cs_part[jg][i][1], cs_part[jg][i][2], cs_part[jg][i][3]);
+                }
             }
         }
     }
 }
 
-template <int BM, int D>
+template <int BM, int BN, int WTM, int D>
 static int launch_nt(const WideGemmParams& p, hipStream_t st) {
-    constexpr int LDS = D * (BM + TBN) * TBK * 2;
+    constexpr int LDS = D * (BM + BN) * TBK * 2;
+    constexpr int THREADS = (BM / WTM) * (BN / 64) * 64;
     static bool attr = false;
     if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_kernel<BM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_kernel<BM, BN, WTM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int ntM = cdiv(p.M, BM), ntN = cdiv(p.N, TBN);
+    const int ntM = cdiv(p.M, BM), ntN = cdiv(p.N, BN);
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL((wide_gemm_nt_kernel<BM, D>), dim3(ntM * ntN), dim3(BM * 2), LDS, st, p, ntM, ntN);
+    hipLaunchKernelGGL((wide_gemm_nt_kernel<BM, BN, WTM, D>), dim3(ntM * ntN), dim3(THREADS), LDS, st, p, ntM, ntN);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
 }
 
-static bool nt_big(int M, int N) {
+// tile choice. 256 x 256 (EGX_WIDE_TILE=512 forces it, =256 / =128 force the others): N a multiple of 256 and at least 3.5
+// rounds of tiles over the 256 CUs (its 1.5x lower operand traffic is worth nothing in a half-empty last round)
+static int nt_variant(int M, int N) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("EGX_WIDE_TILE"); force = e ? atoi(e) : 0; }
-    return force ? force == 256 : (long)cdiv(M, 256) * cdiv(N, TBN) >= 512;
+    if (force == 512) return 2;
+    if (force == 256) return 1;
+    if (force == 128) return 0;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    if (N % 256 == 0 && t256 >= 896) return 2;
+    return (long)cdiv(M, 256) * cdiv(N, TBN) >= 512 ? 1 : 0;
 }
 // rows of the `colsum` partial buffer written by wide_gemm_nt for an (M, N) output: one per 64 output rows of every tile
-int wide_gemm_nt_colsum_rows(int M, int N) { return nt_big(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }
+int wide_gemm_nt_colsum_rows(int M, int N) { return nt_variant(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }
 
 int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     EGX_CHECK(p.A && p.B && (p.Cf || p.Cb), "wide_gemm_nt: null operand");
     EGX_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "wide_gemm_nt: empty problem %dx%dx%d", p.M, p.N, p.K);
     EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
-    // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves, 4-stage ring) below
-    if (nt_big(p.M, p.N)) return launch_nt<256, 3>(p, st);
+    const int v = nt_variant(p.M, p.N);
+    if (v == 2) return launch_nt<256, 256, 128, 2>(p, st);
+    // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves) below
+    if (v == 1) return launch_nt<256, 128, 64, 3>(p, st);
     static int small_stages = -1;      // tuning aid: EGX_WIDE_SMALL_STAGES = 2 -> two workgroups per CU with two stages each
     if (small_stages < 0) { const char* e = getenv("EGX_WIDE_SMALL_STAGES"); small_stages = e ? atoi(e) : 2; }
-    return small_stages == 2 ? launch_nt<128, 2>(p, st) : launch_nt<128, 4>(p, st);
+    return small_stages == 2 ? launch_nt<128, 128, 64, 2>(p, st) : launch_nt<128, 128, 64, 4>(p, st);
 }
 
 // ---- TN ---------------------------------------------------------------------------------------------------------------
