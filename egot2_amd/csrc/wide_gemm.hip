@@ -282,18 +282,22 @@ int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
 }
 
 // ---- TN ---------------------------------------------------------------------------------------------------------------
-// BM x 128 output tile (BM = 128 / 256 columns of dY against 128 columns of X), BM / 64 x 2 waves, ring of D stages as above.
-// A stage holds BM / 128 dY images and one X image, each [64 tokens][128 columns] (256-byte rows).
-template <int BM, int D>
-__global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
-    constexpr int NW = BM / 32, WM = BM / 64, NI = BM / 128 + 1;     // waves, waves along m, images per stage
+// BM x BN output tile (BM columns of dY against BN columns of X), (BM / WTM) x (BN / 64) waves of WTM x 64, ring of D stages
+// as above. A stage holds BM / 128 dY images and BN / 128 X images, each [64 tokens][128 columns] (256-byte rows).
+// Variants: 256 x 128 / 128 x 128 (wave 64 x 64) and 256 x 256 (wave 128 x 64, 2 stages): 1.5x fewer operand bytes per FLOP.
+template <int BM, int BN, int WTM, int D>
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
+    constexpr int WM = BM / WTM, NW = WM * (BN / 64);               // waves along m, waves
+    constexpr int NIY = BM / 128, NIX = BN / 128, NI = NIY + NIX;   // images per stage
+    constexpr int TJ = WTM / 16;
     constexpr int IMG = TBK * 128 * 2;                              // 16 KB
     constexpr int SB = NI * IMG;
     constexpr int PER = NI * 16 / NW;                               // staging instructions per wave per stage
+    static_assert(NI * 16 % NW == 0, "staging instructions must divide among the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = xcd_tile(blockIdx.x, ntM * ntN);
-    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * TBN;
+    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * BN;
     const int split = blockIdx.y;
     const int kbeg = split * kps, kend = min(p.K, kbeg + kps);
 
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams 
         const int sw = (row & 3) | (((row >> 3) & 1) << 2);
         rowS[j] = row;
         colS[j] = (pch ^ sw) * 16 + half * 8;
-        const bool isx = img == NI - 1;
-        baseS[j] = isx ? p.B + n0 : p.A + m0 + img * 128;
+        const bool isx = img >= NIY;
+        baseS[j] = isx ? p.B + n0 + (img - NIY) * 128 : p.A + m0 + img * 128;
         ldS[j] = isx ? p.ldb : p.lda;
     }
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zero_page) + slot * 16;
@@ -328,13 +332,14 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams 
     // transposed reads: lane supplies row 8g + (r >> 2) (+4) of the 32-token slice, 4 columns 4 * (r & 3) of its 16-wide tile
     const int swz = (r >> 2) | ((g & 1) << 2);
     const int rowoff = (8 * g + (r >> 2)) * 256 + 8 * (r & 3);
-    const int imgY = (wm >> 1) * IMG, cY = (wm & 1) * 4, imgX = (NI - 1) * IMG;
+    const int imgY = ((wm * WTM) / 128) * IMG, cY = ((wm * WTM) % 128) / 16;
+    const int imgX = (NIY + (wn >> 1)) * IMG, cX = (wn & 1) * 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][TJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     const int nk = (kend - kbeg + TBK - 1) / TBK;
 #pragma unroll
@@ -342,9 +347,9 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams 
         if (s0 < nk) stage(kbeg + s0 * TBK, s0);
     int buf = 0, nbuf = D - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        if (D >= 4 && kt + 2 < nk) { if (PER == 8) EGX_WAIT_VM(16); else EGX_WAIT_VM(12); }
-        else if (D >= 3 && kt + 1 < nk) { if (PER == 8) EGX_WAIT_VM(8); else EGX_WAIT_VM(6); }
-        else EGX_WAIT_VM(0);
+        if (D >= 4 && kt + 2 < nk) wait_vm<2 * PER>();
+        else if (D >= 3 && kt + 1 < nk) wait_vm<PER>();
+        else wait_vm<0>();
         ring_barrier();
         if (kt + D - 1 < nk) stage(kbeg + (kt + D - 1) * TBK, nbuf);
         const unsigned char* sy = smem + buf * SB + imgY;              // dY image: [64 tokens][128 m]
@@ -353,27 +358,27 @@ __global__ __launch_bounds__(BM * 2, 1) void wide_gemm_tn_kernel(WideGemmParams 
         nbuf = nbuf + 1 == D ? 0 : nbuf + 1;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 fx[4], fy[4];
+            bf16x8 fx[4], fy[TJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // MFMA A operand: X^T rows n = wn*64 + i*16 + r
-                const unsigned char* q0 = sx + s * 32 * 256 + rowoff + (((wn * 4 + i) ^ swz) * 32);
+                const unsigned char* q0 = sx + s * 32 * 256 + rowoff + (((cX + i) ^ swz) * 32);
                 fx[i] = lds_read_tr2(q0, q0 + 4 * 256);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {       // MFMA B operand: dY columns m = wm*64 + j*16 + r
+            for (int j = 0; j < TJ; ++j) {      // MFMA B operand: dY columns m = wm*WTM + j*16 + r
                 const unsigned char* q0 = sy + s * 32 * 256 + rowoff + (((cY + j) ^ swz) * 32);
                 fy[j] = lds_read_tr2(q0, q0 + 4 * 256);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);
         }
     }
     float* out = slabs + (size_t)split * slab_stride;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + r;
+    for (int j = 0; j < TJ; ++j) {
+        const int m = m0 + wm * WTM + j * 16 + r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + wn * 64 + i * 16 + 4 * g;
@@ -400,13 +405,24 @@ __global__ __launch_bounds__(256) void wide_slab_reduce_kernel(const float* __re
     }
 }
 
-static bool tn_big(int M) { return M % 256 == 0; }
-// Split count over the token axis: one workgroup per CU is resident (ring of 3 x 48 KB), so the kernel runs in
+// tile variant of a TN problem: 2 = 256 x 256, 1 = 256 x 128, 0 = 128 x 128 (EGX_WIDE_TN_TILE = 512 / 256 / 128 forces one)
+static int tn_variant(int M, int N) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("EGX_WIDE_TN_TILE"); force = e ? atoi(e) : 0; }
+    const bool ok2 = M % 256 == 0 && N % 256 == 0, ok1 = M % 256 == 0;
+    if (force == 512 && ok2) return 2;
+    if (force == 256 && ok1) return 1;
+    if (force == 128) return 0;
+    if (ok2 && (long)(M / 256) * (N / 256) >= 9) return 2;      // fewer tiles: the finer variants split the tokens less
+    return ok1 ? 1 : 0;
+}
+// Split-K count: every workgroup runs one tile over K / splits tokens; the launch lasts about
 // ceil(tiles * splits / 256) rounds of K / splits tokens each; more splits also mean more fp32 slab traffic
 // (2 x 4 bytes per output element per split against ~6 TB/s). Pick the cheapest count under that model.
 static int tn_splits(int M, int N, int K, int* kps_out) {
-    const int tiles = (M / (tn_big(M) ? 256 : 128)) * (N / TBN);
-    const double step_us = 0.9;                         // one 64-token K step of a resident workgroup, measured
+    const int v = tn_variant(M, N);
+    const int tiles = (M / (v ? 256 : 128)) * (N / (v == 2 ? 256 : TBN));
+    const double step_us = v == 2 ? 1.5 : 0.9;         // one 64-token K step of a resident workgroup, measured
     const double slab_us = 8.0 * M * N / 6.0e6;         // write + read of one slab
     int best = 1;
     double best_t = 1e30;
@@ -427,17 +443,18 @@ size_t wide_gemm_tn_scratch(int M, int N, int K) {
     return (size_t)tn_splits(M, N, K, nullptr) * M * N * sizeof(float);
 }
 
-template <int BM, int D>
+template <int BM, int BN, int WTM, int D>
 static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs, size_t slab_stride, hipStream_t st) {
-    constexpr int LDS = D * (BM / 128 + 1) * TBK * 128 * 2;
+    constexpr int LDS = D * (BM / 128 + BN / 128) * TBK * 128 * 2;
+    constexpr int THREADS = (BM / WTM) * (BN / 64) * 64;
     static bool attr = false;
     if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_kernel<BM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_kernel<BM, BN, WTM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int ntM = p.M / BM, ntN = p.N / TBN;
+    const int ntM = p.M / BM, ntN = p.N / BN;
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, D>), dim3(ntM * ntN, splits), dim3(BM * 2), LDS, st, p, ntM, ntN, kps, slabs, slab_stride);
+    hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, BN, WTM, D>), dim3(ntM * ntN, splits), dim3(THREADS), LDS, st, p, ntM, ntN, kps, slabs, slab_stride);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -450,8 +467,10 @@ int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st) {
     int kps = 0;
     const int splits = tn_splits(p.M, p.N, p.K, &kps);
     const size_t slab_stride = (size_t)p.M * p.N;
-    if (tn_big(p.M)) { if (launch_tn<256, 3>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
-    else if (launch_tn<128, 4>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1;
+    const int v = tn_variant(p.M, p.N);
+    if (v == 2) { if (launch_tn<256, 256, 128, 2>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
+    else if (v == 1) { if (launch_tn<256, 128, 64, 3>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
+    else if (launch_tn<128, 128, 64, 4>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1;
     const size_t n4 = slab_stride / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
