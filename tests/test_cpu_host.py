@@ -431,3 +431,16 @@ def test_hoi_backbone_without_reference_tree_or_factory_raises():
              PRETRAIN=NS(PNR_CFG="pnr.yaml", OSCC_CFG=None))
     with pytest.raises(ImportError, match="register_backbone_factory"):
         hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+
+
+def test_lossAV_mirror_has_the_reference_interface():
+    """hhi_asd.lossAV (HHI/tasks/asd/loss.py:11-30): constructor argument, parameter / buffer names and the criterion's class
+    weights, checked without a GPU; the fused kernels behind forward() are covered by the GPU suite."""
+    import torch
+    from egot2_amd import hhi_asd
+    m = hhi_asd.lossAV(128)
+    assert set(m.state_dict()) == {"criterion.weight", "FC.weight", "FC.bias"}
+    assert tuple(m.FC.weight.shape) == (2, 128) and m.criterion.weight.tolist() == [1.0, 4.0]
+    assert hhi_asd.lossAV().FC.in_features == 256
+    with pytest.raises(Exception):          # the HIP path fails loudly on CPU tensors instead of falling back
+        m(torch.randn(4, 1, 128), torch.zeros(4, dtype=torch.int64))
