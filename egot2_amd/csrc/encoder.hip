@@ -35,7 +35,7 @@ struct Plan {
     LayerOff layer[64];
     size_t saved_bytes = 0;
     // scratch
-    size_t s_dA = 0, s_dB = 0, s_dqkv = 0, s_dhid = 0, s_slab = 0, slab_bytes = 0;
+    size_t s_dA = 0, s_dB = 0, s_dqkv = 0, s_dhid = 0, s_slab = 0, slab_bytes = 0, s_det = 0, det_bytes = 0;
     size_t scratch_bytes = 0;
 };
 
@@ -108,6 +108,8 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
         if (segs[i].proj_w) upd(pl.d, segs[i].d_in, B * segs[i].T);
     pl.slab_bytes = slab;
     pl.s_slab = take(sc, slab);
+    pl.det_bytes = cfg->deterministic ? generic_det_scratch_bytes(B, pl.d, pl.dff) : 0;
+    pl.s_det = take(sc, pl.det_bytes);
     pl.scratch_bytes = sc;
     return 0;
 }
@@ -725,6 +727,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     const int d = pl.d, S = pl.S, comp = cfg->compute, dff = pl.dff;
     const int N = (int)pl.N;
     if (cfg->zero_buf && cfg->zero_bytes) EGX_HIP(hipMemsetAsync(cfg->zero_buf, 0, cfg->zero_bytes, st));
+    // deterministic mode: every cross-workgroup sum below goes through partial buffers and fixed-order reductions
+    DetScope det_scope(cfg->deterministic ? (char*)scratch + pl.s_det : nullptr, pl.det_bytes);
     if (with_head) {
         const float* tk = cfptr(saved, align_up(pl.saved_bytes, 256));
         const float* pooled = tk + (size_t)N * d;

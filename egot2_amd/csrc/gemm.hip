@@ -324,7 +324,7 @@ int gemm(int layout, GemmParams p, int compute, int accumulate, void* scratch, s
     int final_ldc = p.ldc;
     bool use_slabs = false;
     // small accumulate-into outputs (<= 256k floats): split-K blocks add straight into C, no slab round trip
-    if (!getenv("EGX_NO_ATOMIC_DW") && accumulate && layout == 2 && (size_t)p.M * p.N <= 262144 && !p.bias && !p.residual && !p.mask && !p.relu && !p.drop_thresh) {
+    if (!det_on() && !getenv("EGX_NO_ATOMIC_DW") && accumulate && layout == 2 && (size_t)p.M * p.N <= 262144 && !p.bias && !p.residual && !p.mask && !p.relu && !p.drop_thresh) {
         p.atomic = 1;
     } else if (splits > 1 || accumulate) {
         size_t need = (size_t)splits * p.M * p.N * sizeof(float);

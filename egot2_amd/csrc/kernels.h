@@ -25,6 +25,16 @@ struct GemmParams {
     size_t slab_stride = 0;            // set by gemm()
 };
 
+// Deterministic mode of the shape-generic kernels (egx_config.deterministic): while a DetScope is alive on this thread, the
+// cross-workgroup sums that normally use fp32 atomics (split-K weight gradients, LayerNorm / bias / head parameter gradients)
+// go through partial buffers in `buf` and fixed-order reductions instead. `buf` must hold generic_det_scratch_bytes().
+struct DetScope {
+    DetScope(void* buf, size_t bytes);
+    ~DetScope();
+};
+bool det_on();
+size_t generic_det_scratch_bytes(int B, int d, int d_ff);
+
 // layout: 0 NT, 1 NN, 2 TN (see gemm.hip). compute: 0 fp32 MFMA, 1 bf16 MFMA.
 int gemm(int layout, GemmParams p, int compute, int accumulate, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int layout, int M, int N, int K);

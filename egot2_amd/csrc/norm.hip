@@ -92,7 +92,7 @@ int layernorm_fwd(const LnFwdParams& p, hipStream_t st) {
 
 // ---- LayerNorm backward -----------------------------------------------------------------------
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p, float* __restrict__ part) {
     __shared__ float red[3][4][64 * NV];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -153,11 +153,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     for (int c = threadIdx.x; c < d; c += 256) {
         float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        if (p.dw) atomicAdd(p.dw + c, sw);
-        if (p.db) atomicAdd(p.db + c, sb);
-        if (p.dadd) atomicAdd(p.dadd + c, sb);
+        if (part) {         // deterministic mode: [block][2][d] partials, summed in block order by det_reduce_rows
+            part[((size_t)blockIdx.x * 2) * d + c] = sw;
+            part[((size_t)blockIdx.x * 2 + 1) * d + c] = sb;
+        } else {
+            if (p.dw) atomicAdd(p.dw + c, sw);
+            if (p.db) atomicAdd(p.db + c, sb);
+            if (p.dadd) atomicAdd(p.dadd + c, sb);
+        }
     }
     (void)aa;
+}
+
+// ---- deterministic mode plumbing ------------------------------------------------------------------
+static thread_local void* g_det_buf = nullptr;
+static thread_local size_t g_det_bytes = 0;
+static thread_local int g_det_depth = 0;
+DetScope::DetScope(void* buf, size_t bytes) { if (buf && bytes) { g_det_buf = buf; g_det_bytes = bytes; ++g_det_depth; } }
+DetScope::~DetScope() { if (g_det_depth > 0 && --g_det_depth == 0) { g_det_buf = nullptr; g_det_bytes = 0; } }
+bool det_on() { return g_det_depth > 0; }
+constexpr int DET_LN_BLOCKS = 256, DET_COLSUM_ROWBLOCKS = 64;
+size_t generic_det_scratch_bytes(int B, int d, int d_ff) {
+    size_t ln = (size_t)DET_LN_BLOCKS * 2 * d;
+    size_t cs = (size_t)DET_COLSUM_ROWBLOCKS * (size_t)(d_ff > 3 * d ? d_ff : 3 * d);
+    size_t ph = (size_t)B * ((size_t)64 * d + 64 + 2 * (size_t)d);
+    size_t m = ln > cs ? ln : cs;
+    return (m > ph ? m : ph) * sizeof(float);
+}
+// out[c] += sum_t part[t * stride + c], t < nt, in order of t
+__global__ __launch_bounds__(256) void det_reduce_rows_kernel(const float* __restrict__ part, size_t stride, int nt, int cols, float* __restrict__ out) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    int t = 0;
+    for (; t + 8 <= nt; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(t + u) * stride + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; t < nt; ++t) s += part[(size_t)t * stride + c];
+    out[c] += s;
+}
+static int det_reduce_rows(const float* part, size_t stride, int nt, int cols, float* out, hipStream_t st) {
+    if (!out || cols <= 0 || nt <= 0) return 0;
+    hipLaunchKernelGGL(det_reduce_rows_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, st, part, stride, nt, cols, out);
+    EGX_LAUNCH_CHECK();
+    return 0;
 }
 
 int layernorm_bwd(const LnBwdParams& p, hipStream_t st) {
@@ -166,19 +209,29 @@ int layernorm_bwd(const LnBwdParams& p, hipStream_t st) {
     int nv = cdiv(p.d, 64);
     int blocks = min(cdiv(p.rows, 4 * 8), 256);
     if (blocks < 1) blocks = 1;
+    float* part = nullptr;
+    if (det_on() && (p.dw || p.db || p.dadd)) {
+        EGX_CHECK((size_t)blocks * 2 * p.d * sizeof(float) <= g_det_bytes, "layernorm_bwd: deterministic scratch too small");
+        part = (float*)g_det_buf;
+    }
     dim3 g(blocks), b(256);
-    if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, g, b, 0, st, p);
-    else if (nv <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, g, b, 0, st, p);
-    else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, g, b, 0, st, p);
-    else if (nv <= 12) hipLaunchKernelGGL(ln_bwd_kernel<12>, g, b, 0, st, p);
-    else hipLaunchKernelGGL(ln_bwd_kernel<16>, g, b, 0, st, p);
+    if (nv <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, g, b, 0, st, p, part);
+    else if (nv <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, g, b, 0, st, p, part);
+    else if (nv <= 8) hipLaunchKernelGGL(ln_bwd_kernel<8>, g, b, 0, st, p, part);
+    else if (nv <= 12) hipLaunchKernelGGL(ln_bwd_kernel<12>, g, b, 0, st, p, part);
+    else hipLaunchKernelGGL(ln_bwd_kernel<16>, g, b, 0, st, p, part);
     EGX_LAUNCH_CHECK();
+    if (part) {
+        if (det_reduce_rows(part, (size_t)2 * p.d, blocks, p.d, p.dw, st)) return 1;
+        if (det_reduce_rows(part + p.d, (size_t)2 * p.d, blocks, p.d, p.db, st)) return 1;
+        if (det_reduce_rows(part + p.d, (size_t)2 * p.d, blocks, p.d, p.dadd, st)) return 1;
+    }
     return 0;
 }
 
 // ---- column sums (bias gradients) -------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
-                                                      float* __restrict__ out, int rows_per_block) {
+                                                      float* __restrict__ out, int rows_per_block, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -190,7 +243,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         for (int r = r0 + wave; r < r1; r += 4) s += x[(size_t)r * ld + c];
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (wave == 0 && c < cols) {
+        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (part) part[(size_t)blockIdx.y * cols + c] = v;      // deterministic mode: one partial row per row block
+        else atomicAdd(out + c, v);
+    }
 }
 
 int colsum_accum(const float* x, int rows, int cols, int ld, float* out, hipStream_t st) {
@@ -198,9 +255,16 @@ int colsum_accum(const float* x, int rows, int cols, int ld, float* out, hipStre
     int cb = cdiv(cols, 64);
     int want = max(1, 1024 / cb);
     int rpb = max(32, cdiv(rows, want));
+    float* part = nullptr;
+    if (det_on()) {
+        rpb = max(rpb, cdiv(rows, DET_COLSUM_ROWBLOCKS));
+        EGX_CHECK((size_t)cdiv(rows, rpb) * cols * sizeof(float) <= g_det_bytes, "colsum: deterministic scratch too small");
+        part = (float*)g_det_buf;
+    }
     dim3 g(cb, cdiv(rows, rpb));
-    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, x, rows, cols, ld, out, rpb);
+    hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, x, rows, cols, ld, out, rpb, part);
     EGX_LAUNCH_CHECK();
+    if (part) return det_reduce_rows(part, (size_t)cols, (int)g.y, cols, out, st);
     return 0;
 }
 
@@ -322,7 +386,10 @@ __global__ __launch_bounds__(256) void pool_head_bwd_kernel(const float* __restr
                                                              int S, int d, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                              float eps, const float* __restrict__ W, int n_out,
                                                              float* __restrict__ d_tokens, float* __restrict__ d_ln_w,
-                                                             float* __restrict__ d_ln_b, float* __restrict__ d_W, float* __restrict__ d_b) {
+                                                             float* __restrict__ d_ln_b, float* __restrict__ d_W, float* __restrict__ d_b,
+                                                             float* __restrict__ part) {
+    // deterministic mode: this clip's contributions go to part[b][n_out * d | n_out | d (ln_w) | d (ln_b)]
+    float* pw = part ? part + (size_t)blockIdx.x * ((size_t)n_out * d + n_out + 2 * (size_t)d) : nullptr;
     __shared__ float xh[PH_MAXD];   // normalised pooled (or pooled when no LN)
     __shared__ float dy[PH_MAXD];   // gradient w.r.t. head input y
     __shared__ float red[4];
@@ -348,13 +415,19 @@ __global__ __launch_bounds__(256) void pool_head_bwd_kernel(const float* __restr
             for (int o = 0; o < n_out; ++o) g += go[o] * W[(size_t)o * d + c];
             float yv = ln_w ? x * ln_w[c] + ln_b[c] : x;
             if (d_W)
-                for (int o = 0; o < n_out; ++o) atomicAdd(d_W + (size_t)o * d + c, go[o] * yv);
+                for (int o = 0; o < n_out; ++o) {
+                    if (pw) pw[(size_t)o * d + c] = go[o] * yv;
+                    else atomicAdd(d_W + (size_t)o * d + c, go[o] * yv);
+                }
         } else {
             g = go[c];
         }
         dy[c] = g;
     }
-    if (W && d_b && threadIdx.x < n_out) atomicAdd(d_b + threadIdx.x, go[threadIdx.x]);
+    if (W && d_b && threadIdx.x < n_out) {
+        if (pw) pw[(size_t)n_out * d + threadIdx.x] = go[threadIdx.x];
+        else atomicAdd(d_b + threadIdx.x, go[threadIdx.x]);
+    }
     __syncthreads();
     float inv_s = 1.f / (float)S;
     if (ln_w) {
@@ -363,8 +436,13 @@ __global__ __launch_bounds__(256) void pool_head_bwd_kernel(const float* __restr
             float g = dy[c] * ln_w[c];
             s1 += g;
             s2 += g * xh[c];
-            if (d_ln_w) atomicAdd(d_ln_w + c, dy[c] * xh[c]);
-            if (d_ln_b) atomicAdd(d_ln_b + c, dy[c]);
+            if (pw) {
+                pw[(size_t)n_out * d + n_out + c] = dy[c] * xh[c];
+                pw[(size_t)n_out * d + n_out + d + c] = dy[c];
+            } else {
+                if (d_ln_w) atomicAdd(d_ln_w + c, dy[c] * xh[c]);
+                if (d_ln_b) atomicAdd(d_ln_b + c, dy[c]);
+            }
         }
         s1 = block_sum(s1, red) / (float)d;
         s2 = block_sum(s2, red) / (float)d;
@@ -396,9 +474,21 @@ int pool_head_bwd(const float* d_out, const float* pooled, int B, int S, int d, 
     EGX_CHECK(d <= PH_MAXD, "pool_head: d=%d exceeds %d", d, PH_MAXD);
     EGX_CHECK(!W || (n_out >= 1 && n_out <= 64), "pool_head: n_out=%d out of range 1..64", n_out);
     if (B <= 0) return 0;
+    float* part = nullptr;
+    const size_t prow = (size_t)n_out * d + n_out + 2 * (size_t)d;
+    if (det_on() && W && ln_w) {
+        EGX_CHECK((size_t)B * prow * sizeof(float) <= g_det_bytes, "pool_head_bwd: deterministic scratch too small");
+        part = (float*)g_det_buf;
+    }
     hipLaunchKernelGGL(pool_head_bwd_kernel, dim3(B), dim3(256), 0, st, d_out, pooled, S, d, ln_w, ln_b, eps, W, n_out,
-                       d_tokens, d_ln_w, d_ln_b, d_W, d_b);
+                       d_tokens, d_ln_w, d_ln_b, d_W, d_b, part);
     EGX_LAUNCH_CHECK();
+    if (part) {
+        if (det_reduce_rows(part, prow, B, n_out * d, d_W, st)) return 1;
+        if (det_reduce_rows(part + (size_t)n_out * d, prow, B, n_out, d_b, st)) return 1;
+        if (det_reduce_rows(part + (size_t)n_out * d + n_out, prow, B, d, d_ln_w, st)) return 1;
+        if (det_reduce_rows(part + (size_t)n_out * d + n_out + d, prow, B, d, d_ln_b, st)) return 1;
+    }
     return 0;
 }
 

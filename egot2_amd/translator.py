@@ -68,7 +68,9 @@ class TranslatorMixin:
 
     def set_deterministic(self, on: bool = True):
         """Bit-identical gradients run to run (same inputs, same seed): the fused per-clip backward replaces its fp32-atomic
-        cross-workgroup sums by fixed-order slab reductions; the wide bf16 path is deterministic by construction."""
+        cross-workgroup sums by fixed-order slab reductions, the shape-generic backward routes split-K weight gradients and
+        LayerNorm / bias / pooled-head parameter gradients through partial buffers with ordered sums; the wide bf16 path is
+        deterministic by construction."""
         self.egx_deterministic = bool(on)
         return self
 

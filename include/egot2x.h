@@ -146,8 +146,9 @@ typedef struct egx_config {
     int deterministic;        /* != 0: every cross-workgroup sum of the BACKWARD runs in a fixed order (split-K slabs and
                                  per-clip partial rows reduced by one workgroup per output instead of fp32 atomics), so the
                                  same inputs and seed give bit-identical gradients run to run. Honoured by the fused per-clip
-                                 kernels; the wide bf16 path is always deterministic; the shape-generic kernels keep their
-                                 atomic reductions. */
+                                 kernels and the shape-generic kernels (split-K slabs, LayerNorm / bias / pooled-head partial
+                                 buffers with ordered sums; pass the same flag to the workspace query: it sizes their scratch);
+                                 the wide bf16 path is always deterministic. */
     int out_tokens;           /* 0 = the whole sequence. T > 0: only the first T tokens of every clip leave the encoder
                                  (tokens_out is (B, T, d)) and only they receive an upstream gradient (d_tokens is (B, T, d)) —
                                  the ASD translator returns its first segment, HHI/models/asd/model_taskspecific.py:156-158;

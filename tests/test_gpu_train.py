@@ -323,12 +323,14 @@ def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, ov
         assert torch.allclose(p.grad.cpu(), torch.from_numpy(grads[k]), rtol=2e-3, atol=2e-6), k
 
 
-@pytest.mark.parametrize("compute", ["f32", "bf16", "f32s"])
-def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute):
+@pytest.mark.parametrize("compute,impl", [("f32", "fused"), ("bf16", "fused"), ("f32s", "fused"), ("f32", "generic"), ("bf16", "generic")])
+def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute, impl):
     """same inputs + same dropout seed => bit-identical logits and gradients across runs with
     `set_deterministic()`: the fused backward sums its split-K slabs and per-clip partial rows in a fixed order instead of
-    fp32 atomics. The result must still match the default (atomic) mode to accumulation-order noise. B = 300 clips: more
-    than one round of workgroups, several token splits per weight-gradient problem."""
+    fp32 atomics; the shape-generic backward routes its split-K weight gradients through slabs and its LayerNorm / bias /
+    pooled-head parameter gradients through partial buffers with ordered sums. The result must still match the default
+    (atomic) mode to accumulation-order noise. B = 300 clips: more than one round of workgroups, several token splits per
+    weight-gradient problem."""
     B = 300
     feats = [f.to(cuda) for f in seeded_feats(55, [(B, 15, 256)] * 3)]
     target = (torch.arange(B, device=cuda) * 7) % 2
@@ -339,7 +341,7 @@ def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute
         from egot2_amd import hhi_ttm
         m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=2, dropout=0.5))
         m.load_state_dict(seeded_state_dict(m, 9))
-        m = m.to(cuda).set_compute(compute, "fused").set_deterministic(det).train()
+        m = m.to(cuda).set_compute(compute, impl).set_deterministic(det).train()
         m._egx_step = 0
         logits = m.forward_features(*feats)
         torch.nn.functional.cross_entropy(logits, target, weight=w).backward()
