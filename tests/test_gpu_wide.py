@@ -268,3 +268,39 @@ def test_feature_handoff_bf16_and_frame_pooling(egx_lib, cuda):
     m.set_compute("f32")
     with pytest.raises(_lib.EgxError, match="wide bf16 path"):
         m.forward_features(p16[0], p16[1], act, l16)
+
+
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 6e-2)])
+def test_hoi_egot2g_encoder_real_dimensions(egx_lib, cuda, compute, tol_out, tol_grad):
+    """BASELINE.json configs[4], HOI EgoT2-g at its real width: d = 512, 8 heads of 64, 3 layers
+    (HOI/models/multitask/video_model_builder.py:70-77); both prompt layouts of encode() (pnr: 16 + 16 + 8 + 8 = 48 tokens with
+    the SlowFast pathways projected separately; lta: per-clip PNR / OSCC frames + action + LTA features) against the oracle.
+    bf16 runs on the wide path, f32 on the shape-generic kernels."""
+    from tests.test_oracle_golden import build_ours, fixture_feats
+    c = dict(kind="hoig", B=3, n=3, L=3, d=512, h=8, wseed=211, fseed=212)
+    model = build_ours(c)
+    sd = seeded_state_dict(model, c["wseed"])
+    model.load_state_dict(sd)
+    model = model.to(cuda).set_compute(compute).train()
+    model.pos_embed.dropout.p = 0.0
+    feats = fixture_feats(c)
+    fd = [f.to(cuda) for f in feats]
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    outs = [model.encode_features("pnr", *fd[:4]), model.encode_features("lta_verb", *fd[4:])]
+    assert outs[0].shape == (48, 3, 512)
+    (lin(outs[0]) + lin(outs[1])).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    f64 = [f.double() for f in feats]
+    refs = [tr.hoi_g_encode(sd64, 8, "pnr", *f64[:4]), tr.hoi_g_encode(sd64, 8, "lta_verb", *f64[4:])]
+    (lin(refs[0]) + lin(refs[1])).backward()
+    for o, r in zip(outs, refs):
+        assert (o.detach().cpu().double() - r.detach()).abs().max().item() < tol_out * max(1.0, r.abs().max().item())
+    errs = {}
+    for k, p in model.named_parameters():
+        r = sd64[k].grad if k in sd64 else None
+        if r is None or p.grad is None:
+            continue
+        errs[k] = (p.grad.detach().cpu().double() - r).norm().item() / (r.norm().item() + 1e-12)
+    assert len(errs) > 30
+    bad = {k: v for k, v in errs.items() if not v < tol_grad}
+    assert not bad, bad
