@@ -202,3 +202,37 @@ def test_first_tokens_only_output_matches_the_slice(egx_lib, cuda, compute):
         assert rel_err(res["kernel"][1][k], g) < 1e-5, k
     tol = 2e-2 if compute == "bf16" else 1e-4
     assert torch.allclose(res["kernel"][0], res["generic"][0], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("compute,tol_out,tol_grad", [("bf16", 1e-2, 8e-2), ("f32s", 1e-3, 1e-2)])
+def test_asd_translator_at_bench_size_with_its_head(egx_lib, cuda, compute, tol_out, tol_grad):
+    """BASELINE.json configs[2] at the size bench.py times it: 256 clips, T = 15, two layers, per-frame output through the
+    lossAV head (fused Linear + weighted CE), against the oracle's translator followed by torch's fp64 Linear / cross_entropy."""
+    from egot2_amd import hhi_asd
+    B, T = 256, 15
+    m = hhi_asd.TaskFusionMFTransformer3Task(hhi_args(num_layers=2))
+    sd = seeded_state_dict(m, 71)
+    m.load_state_dict(sd)
+    m = m.to(cuda).set_compute(compute).train()
+    m.pos_embed.dropout.p = 0.0
+    torch.manual_seed(72)
+    head = hhi_asd.lossAV(128).to(cuda)
+    feats = seeded_feats(73, [(B, T, 256)] * 3)
+    y = torch.randint(0, 2, (B * T,), generator=torch.Generator().manual_seed(74))
+    nloss, score, label, num = head(m.forward_features(*[f.to(cuda) for f in feats]), y.to(cuda))
+    nloss.backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    W = head.FC.weight.detach().double().cpu().requires_grad_(True)
+    b = head.FC.bias.detach().double().cpu().requires_grad_(True)
+    x = tr.asd_forward(sd64, 4, *[f.double() for f in feats])
+    z = torch.nn.functional.linear(x, W, b)
+    ref = torch.nn.functional.cross_entropy(z, y, weight=torch.tensor([1.0, 4.0], dtype=torch.float64))
+    ref.backward()
+    assert abs(nloss.item() - ref.item()) < tol_out
+    assert (score.double().cpu() - torch.softmax(z.detach(), -1)).abs().max().item() < tol_out
+    errs = {k: rel_err(p.grad, sd64[k].grad) for k, p in m.named_parameters() if p.grad is not None and sd64[k].grad is not None}
+    errs["FC.weight"] = rel_err(head.FC.weight.grad, W.grad)
+    errs["FC.bias"] = rel_err(head.FC.bias.grad, b.grad)
+    bad = {k: v for k, v in errs.items() if not v < tol_grad}
+    assert len(errs) > 20 and not bad, bad
