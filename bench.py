@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--layers", type=int, default=0, help="0 = the configuration's own depth")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32s"],
                     help="default: f32s for c1/c2 (fp32-grade split-bf16 arithmetic; f32 = exact fp32 MFMA), bf16 for c3..c5 (BASELINE.json)")
+    ap.add_argument("--graph-collectives", action="store_true", help="N > 1 (or --force-dist): capture the gradient all-reduce(s) inside the step's hipGraph")
     ap.add_argument("--no-native-line", action="store_true", help="f32s runs: skip the reference timing of the exact fp32 MFMA path")
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
@@ -322,6 +323,22 @@ def run(args) -> int:
     def make_step(with_opt):
         """fwd + loss + bwd (+ gradient all-reduce over RCCL when world > 1) (+ Adam)."""
         place_optimizer(with_opt)
+        if args.graph_collectives and use_graph and (multi or args.force_dist):
+            # opt-in: the WHOLE step incl. the RCCL collectives as one hipGraph (RCCL kernels are capturable); no host work
+            # between the backward, the exchange and the update. Not the default: a failed capture of a collective cannot
+            # be recovered from reliably inside a multi-rank job.
+            model.egx_defer_small = bool(overlap)
+
+            def body():
+                fwd_bwd()
+                if overlap:
+                    ddp.allreduce_gradients_overlapped(F_egx.run_deferred, params, force=args.force_dist)
+                else:
+                    ddp.allreduce_gradients(params, force=args.force_dist)
+                if with_opt:
+                    with_opt.step()
+            gr = capture(body)
+            return gr.replay
         if overlap:
             # graph 1: forward + loss + backward up to the grouped small weight gradients; graph 2: those. The all-reduce
             # of everything else runs on RCCL's stream while graph 2 executes, then the late region follows.
