@@ -666,6 +666,9 @@ def _lce_scratch(device, nbytes: int) -> torch.Tensor:
     key = device.index if device.index is not None else torch.cuda.current_device()
     t = _LCE_SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # a buffer created inside a capture would live in that graph's private pool
+            raise RuntimeError("linear_cross_entropy: run one eager step at this problem size before capturing it in a graph")
         t = _LCE_SCRATCH[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
     return t
 
