@@ -104,17 +104,18 @@ __device__ __forceinline__ void pin(Raw& x) {
 //   bf16: uint4  [lane]            = bf16 of the same 8 values (half 0 first)
 //   split: uint4 [part][lane]           = the three bf16 parts of the same 8 values (pre-split once per step)
 template <int CM> struct WRaw { float4 a, b; };
-template <> struct WRaw<CM_BF16> { uint4 v; };
-template <> struct WRaw<CM_SPLIT> { uint4 p[3]; };
+// (128-bit vector members: a fragment stays ONE register tuple from the load to the MFMA operand)
+template <> struct WRaw<CM_BF16> { u32x4 v; };
+template <> struct WRaw<CM_SPLIT> { u32x4 p[3]; };
 
 template <int CM>
 __device__ __forceinline__ WRaw<CM> load_w(const void* packed, int tile, int nkb, int kb, int lane) {
     WRaw<CM> x;
     size_t blk = (size_t)tile * nkb + kb;
     if constexpr (CM == CM_BF16) {
-        x.v = reinterpret_cast<const uint4*>(packed)[blk * 64 + lane];
+        x.v = reinterpret_cast<const u32x4*>(packed)[blk * 64 + lane];
     } else if constexpr (CM == CM_SPLIT) {
-        const uint4* pl = reinterpret_cast<const uint4*>(packed) + blk * 192;
+        const u32x4* pl = reinterpret_cast<const u32x4*>(packed) + blk * 192;
         x.p[0] = pl[lane];
         x.p[1] = pl[64 + lane];
         x.p[2] = pl[128 + lane];
@@ -143,12 +144,12 @@ __device__ __forceinline__ Frag<CM> w_frag(const WRaw<CM>& x) {
 __device__ __forceinline__ void pin(WRaw<CM_F32>& x) {
     asm volatile("" : "+v"(x.a.x), "+v"(x.a.y), "+v"(x.a.z), "+v"(x.a.w), "+v"(x.b.x), "+v"(x.b.y), "+v"(x.b.z), "+v"(x.b.w));
 }
-__device__ __forceinline__ void pin(WRaw<CM_BF16>& x) {
-    asm volatile("" : "+v"(x.v.x), "+v"(x.v.y), "+v"(x.v.z), "+v"(x.v.w));
+__device__ __forceinline__ void pin(WRaw<CM_BF16>& x) {      // one 128-bit operand: pinning the four dwords separately made
+    asm volatile("" : "+v"(x.v));                             // the compiler re-pack them with v_mov before every MFMA
 }
 __device__ __forceinline__ void pin(WRaw<CM_SPLIT>& x) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(x.p[i].x), "+v"(x.p[i].y), "+v"(x.p[i].z), "+v"(x.p[i].w));
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(x.p[i]));
 }
 template <class T, int N>
 __device__ __forceinline__ void pin_all(T (&x)[N]) {
