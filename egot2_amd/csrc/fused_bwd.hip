@@ -1192,10 +1192,20 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             float* st_m = stat + (h * 3 + 0) * SP;
             float* st_i = stat + (h * 3 + 1) * SP;
             float* st_d = stat + (h * 3 + 2) * SP;
-            auto ldq = [&](int t) { return load_frag<CM>(B4 + (t * 16 + r) * LDX + hc, q); };
-            auto ldk = [&](int t) { return load_frag<CM>(B5 + (t * 16 + r) * LDX + hc, q); };
-            auto ldv = [&](int t) { return load_frag<CM>(Gs + (t * 16 + r) * LDX + hc, q); };
-            auto ldo = [&](int t) { return load_frag<CM>(B3 + (t * 16 + r) * LDX + hc, q); };
+            // the head's Q, K, V, dO row fragments are loaded (CM_SPLIT: split) ONCE and kept in registers: both passes below use
+            // each of them three times, and a reload through the LDS statistics stores in between cannot be elided
+            Frag<CM> fq[NT], fk[NT], fv[NT], fdo[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fq[t] = load_frag<CM>(B4 + (t * 16 + r) * LDX + hc, q);
+                fk[t] = load_frag<CM>(B5 + (t * 16 + r) * LDX + hc, q);
+                fv[t] = load_frag<CM>(Gs + (t * 16 + r) * LDX + hc, q);
+                fdo[t] = load_frag<CM>(B3 + (t * 16 + r) * LDX + hc, q);
+            }
+            auto ldq = [&](int t) -> const Frag<CM>& { return fq[t]; };
+            auto ldk = [&](int t) -> const Frag<CM>& { return fk[t]; };
+            auto ldv = [&](int t) -> const Frag<CM>& { return fv[t]; };
+            auto ldo = [&](int t) -> const Frag<CM>& { return fdo[t]; };
             // orientation T: rows = key, cols = query
             f32x4 pt[NT][NT], dpt[NT][NT];
 #pragma unroll

@@ -8,7 +8,7 @@ for n in "$@"; do
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); r = d.get('roofline') or {}
-    print('$n', d['dtype'], round(d['ms_per_step'], 4), round(r.get('avg_launch_us') or 0, 1), {k: round(v['avg_launch_us'], 1) for k, v in (r.get('other_kernels') or {}).items()})
+    print('$n', d['dtype'][:5], round(d['ms_per_step'], 4), round(r.get('avg_launch_us') or 0, 1), {k: round(v['avg_launch_us'], 1) for k, v in (r.get('other_kernels') or {}).items()})
 "
 done
 cp /tmp/lib_keep.so egot2_amd/libegot2x.so
