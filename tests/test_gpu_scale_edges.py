@@ -32,14 +32,14 @@ def test_long_validation_sequence_matches_oracle(egx_lib, cuda):
         assert (g - r).norm().item() <= 1e-2 * r.norm().item() + 1e-6, k
 
 
-@pytest.mark.parametrize("B", [6144])
-def test_huge_batch_on_fused_kernels(egx_lib, cuda, B):
+@pytest.mark.parametrize("B,compute", [(6144, "f32"), (6144, "f32s")])
+def test_huge_batch_on_fused_kernels(egx_lib, cuda, B, compute):
     """B = 6144 clips: H tiles 2.4 GB + dH tiles 2.4 GB (size_t arithmetic everywhere). Logits of the big batch must
     equal the logits of the same clips in batches of 256 (clips are independent), gradients must equal the sum."""
     from egot2_amd import hhi_ttm
     m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=1))
     m.load_state_dict(seeded_state_dict(m, 23))
-    m = m.to(cuda).train()
+    m = m.to(cuda).set_compute(compute).train()
     m.pos_embed.dropout.p = 0.0
     g = torch.Generator().manual_seed(5)
     feats = [torch.randn(B, 15, 256, generator=g).to(cuda) for _ in range(3)]
