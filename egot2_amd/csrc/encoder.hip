@@ -265,14 +265,14 @@ static int linear_nt(const float* x, const float* W, const float* bias, float* y
 
 // dx[M,K] = dy[M,N] W[N,K]  (+ mask/scale, + residual)
 static int linear_dx(const float* dy, const float* W, float* dx, int M, int N, int K, const float* mask, float mask_scale,
-                     const float* residual, int compute, hipStream_t st) {
+                     const float* residual, int compute, hipStream_t st, void* slab = nullptr, size_t slab_bytes = 0) {
     GemmParams g;
     g.A = dy; g.B = W; g.C = dx;
     g.M = M; g.N = K; g.K = N;
     g.lda = N; g.ldb = K; g.ldc = K;
     g.mask = mask; g.ldm = K; g.mask_scale = mask_scale;
     g.residual = residual; g.ldr = K;
-    return gemm(1, g, compute, 0, nullptr, 0, st);
+    return gemm(1, g, compute, 0, slab, slab_bytes, st);    // slab scratch (optional): lets a skinny dx split its reduction
 }
 
 // dW[N,K] += dy[M,N]^T x[M,K]
@@ -905,7 +905,7 @@ int egx_linear_residual_fwd(const float* x, const float* W, const float* b, cons
 int egx_gelu_fwd(const float* z, float* h, size_t n, void* stream) { return gelu_fwd(z, h, n, (hipStream_t)stream); }
 int egx_gelu_bwd(const float* z, const float* dh, float* dz, size_t n, void* stream) { return gelu_bwd(z, dh, dz, n, (hipStream_t)stream); }
 
-size_t egx_linear_bwd_scratch(int M, int N, int K) { return gemm_scratch_bytes(2, N, K, M); }
+size_t egx_linear_bwd_scratch(int M, int N, int K) { return size_max(gemm_scratch_bytes(2, N, K, M), gemm_scratch_bytes(1, M, K, N)); }
 
 int egx_linear_bwd(const float* dy, const float* x, const float* W, float* dx, float* dW, float* db, int M, int N, int K,
                    int compute, void* scratch, void* stream) {
@@ -918,7 +918,7 @@ int egx_linear_bwd(const float* dy, const float* x, const float* W, float* dx, f
     }
     if (dx) {
         EGX_CHECK(W, "linear_bwd: dx needs W");
-        if (linear_dx(dy, W, dx, M, N, K, nullptr, 1.f, nullptr, compute, st)) return 1;
+        if (linear_dx(dy, W, dx, M, N, K, nullptr, 1.f, nullptr, compute, st, scratch, scratch ? egx_linear_bwd_scratch(M, N, K) : 0)) return 1;
     }
     return 0;
 }

@@ -295,10 +295,13 @@ static void choose_tiles(int layout, int M, int N, int K, bool& big, int& splits
     int bm = big ? 128 : 64;
     int tiles = cdiv(M, bm) * cdiv(N, bm);
     splits = (layout == 2) ? pick_splits(tiles, K) : 1;
+    // skinny input gradients with a long reduction (dx of a wide classifier head: 256 x 768 over K = 11 860 classes is 48
+    // workgroups of 186 K-steps): split K there too when the caller provides slab scratch (see gemm())
+    if (layout == 1 && tiles < 128 && K >= 2048) splits = pick_splits(tiles, K);
 }
 
 size_t gemm_scratch_bytes(int layout, int M, int N, int K) {
-    if (layout != 2) return 0;
+    if (layout == 0) return 0;
     bool big; int splits;
     choose_tiles(layout, M, N, K, big, splits);
     return (size_t)splits * (size_t)M * (size_t)N * sizeof(float);
@@ -320,6 +323,9 @@ int gemm(int layout, GemmParams p, int compute, int accumulate, void* scratch, s
 
     bool big; int splits;
     choose_tiles(layout, p.M, p.N, p.K, big, splits);
+    if (layout == 1 && splits > 1 &&
+        (!scratch || scratch_bytes < (size_t)splits * p.M * p.N * sizeof(float) || p.bias || p.residual || p.mask || p.relu || p.drop_thresh || p.ldc != p.N))
+        splits = 1;         // split-K needs slab scratch and a plain epilogue: otherwise the single-pass kernel
     float* final_C = p.C;
     int final_ldc = p.ldc;
     bool use_slabs = false;
