@@ -35,6 +35,12 @@ int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st);
 
 // dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32
 int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st);
+// the same for many matrices in one launch: wide_cast_add() queues (and flushes a full batch), wide_cast_flush() launches
+struct WideCastDesc { const float* src; bf16_t* dst; bf16_t* dst_t; int R, C, ld, first_block; };
+constexpr int WIDE_CAST_MAX = 40;
+struct WideCastBatch { WideCastDesc d[WIDE_CAST_MAX]; int n = 0, blocks = 0; };
+int wide_cast_add(WideCastBatch& b, const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st);
+int wide_cast_flush(WideCastBatch& b, hipStream_t st);
 
 // dst[r][c] = bf16(mean_{j < pool} src[r * pool + j][c]); src fp32 or bf16 (R * pool, C), dst (R, C) bf16. C % 8 == 0.
 int wide_pool_cast(const void* src, int src_bf16, int R, int pool, int C, bf16_t* dst, hipStream_t st);

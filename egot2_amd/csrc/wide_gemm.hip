@@ -510,6 +510,56 @@ __global__ __launch_bounds__(256) void wide_cast_kernel(const float* __restrict_
     }
 }
 
+// several casts in one launch (all weights of a forward: 4 per layer + the projections were 19 launches of ~5 us at C4)
+__global__ __launch_bounds__(256) void wide_cast_batch_kernel(WideCastBatch b) {
+    __shared__ bf16_t tile[64][66];
+    int di = 0;
+    while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].first_block) ++di;
+    const WideCastDesc& q = b.d[di];
+    const int local = blockIdx.x - q.first_block, nbx = (q.C + 63) / 64;
+    const int r0 = (local / nbx) * 64, c0 = (local % nbx) * 64;
+    const int R = q.R, C = q.C;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rr = r0 + ty + 16 * i, cc = c0 + 4 * tx;
+        float4 v = make_float4(0, 0, 0, 0);
+        if (rr < R && cc < C) v = *reinterpret_cast<const float4*>(q.src + (size_t)rr * q.ld + cc);
+        const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+        if (q.dst && rr < R && cc < C) *reinterpret_cast<uint2*>(q.dst + (size_t)rr * C + cc) = make_uint2(lo, hi);
+        tile[ty + 16 * i][4 * tx + 0] = (bf16_t)(lo & 0xffffu); tile[ty + 16 * i][4 * tx + 1] = (bf16_t)(lo >> 16);
+        tile[ty + 16 * i][4 * tx + 2] = (bf16_t)(hi & 0xffffu); tile[ty + 16 * i][4 * tx + 3] = (bf16_t)(hi >> 16);
+    }
+    if (!q.dst_t) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int cc = c0 + ty + 16 * i, rr = r0 + 4 * tx;           // output row = source column
+        if (cc < C && rr < R) {
+            bf16_t a = tile[4 * tx + 0][ty + 16 * i], bb = tile[4 * tx + 1][ty + 16 * i];
+            bf16_t c = tile[4 * tx + 2][ty + 16 * i], d = tile[4 * tx + 3][ty + 16 * i];
+            *reinterpret_cast<uint2*>(q.dst_t + (size_t)cc * R + rr) = make_uint2((uint32_t)a | ((uint32_t)bb << 16), (uint32_t)c | ((uint32_t)d << 16));
+        }
+    }
+}
+int wide_cast_add(WideCastBatch& b, const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st) {
+    EGX_CHECK(src && (dst || dst_t), "wide_cast: null pointer");
+    EGX_CHECK(C % 4 == 0 && ld % 4 == 0 && (!dst_t || R % 4 == 0), "wide_cast: %dx%d needs multiples of 4", R, C);
+    if (R <= 0 || C <= 0) return 0;
+    if (b.n == WIDE_CAST_MAX && wide_cast_flush(b, st)) return 1;
+    WideCastDesc& q = b.d[b.n++];
+    q.src = src; q.R = R; q.C = C; q.ld = ld; q.dst = dst; q.dst_t = dst_t; q.first_block = b.blocks;
+    b.blocks += cdiv(C, 64) * cdiv(R, 64);
+    return 0;
+}
+int wide_cast_flush(WideCastBatch& b, hipStream_t st) {
+    if (!b.n) return 0;
+    hipLaunchKernelGGL(wide_cast_batch_kernel, dim3(b.blocks), dim3(256), 0, st, b);
+    EGX_LAUNCH_CHECK();
+    b.n = 0; b.blocks = 0;
+    return 0;
+}
+
 int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st) {
     EGX_CHECK(src && (dst || dst_t), "wide_cast: null pointer");
     EGX_CHECK(C % 4 == 0 && ld % 4 == 0 && (!dst_t || R % 4 == 0), "wide_cast: %dx%d needs multiples of 4", R, C);

@@ -148,6 +148,20 @@ int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float
     // token preparation
     float* x0 = at<float>(saved, pl.layer[0].x32);
     bf16_t* x0_16 = at<bf16_t>(saved, pl.layer[0].x16);
+    {   // every weight of this forward -> bf16 (W for the forward, W^T for the input gradients), one launch
+        WideCastBatch cb;
+        for (int i = 0; i < pl.nseg; ++i)
+            if (segs[i].proj_w && wide_cast_add(cb, segs[i].proj_w, d, segs[i].d_in, segs[i].d_in, at<bf16_t>(saved, pl.seg_w[i]), nullptr, st)) return 1;
+        for (int l = 0; l < pl.L; ++l) {
+            const WLayer& o = pl.layer[l];
+            const egx_layer& w = layers[l];
+            if (wide_cast_add(cb, w.in_proj_w, 3 * d, d, d, at<bf16_t>(saved, o.w_in), at<bf16_t>(saved, o.w_in_t), st)) return 1;
+            if (wide_cast_add(cb, w.out_proj_w, d, d, d, at<bf16_t>(saved, o.w_o), at<bf16_t>(saved, o.w_o_t), st)) return 1;
+            if (wide_cast_add(cb, w.lin1_w, dff, d, d, at<bf16_t>(saved, o.w1), at<bf16_t>(saved, o.w1_t), st)) return 1;
+            if (wide_cast_add(cb, w.lin2_w, d, dff, dff, at<bf16_t>(saved, o.w2), at<bf16_t>(saved, o.w2_t), st)) return 1;
+        }
+        if (wide_cast_flush(cb, st)) return 1;
+    }
     for (int i = 0; i < pl.nseg; ++i) {
         const egx_segment& sg = segs[i];
         const int rows = B * sg.T;
@@ -157,7 +171,6 @@ int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float
             const bool in_place = sg.feat_bf16 && sg.pool <= 1;
             const bf16_t* f16 = in_place ? reinterpret_cast<const bf16_t*>(sg.feat) : at<bf16_t>(saved, pl.seg_feat16[i]);
             float* po = at<float>(saved, pl.seg_pre[i]);
-            if (wide_cast(sg.proj_w, d, sg.d_in, sg.d_in, w16, nullptr, st)) return 1;
             if (!in_place && wide_pool_cast(sg.feat, sg.feat_bf16, rows, sg.pool > 1 ? sg.pool : 1, sg.d_in, at<bf16_t>(saved, pl.seg_feat16[i]), st)) return 1;
             WideGemmParams g;
             g.A = f16; g.B = w16; g.M = rows; g.N = d; g.K = sg.d_in; g.lda = sg.d_in; g.ldb = sg.d_in;
@@ -182,10 +195,6 @@ int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float
         const egx_layer& w = layers[l];
         bf16_t* w_in = at<bf16_t>(saved, o.w_in); bf16_t* w_o = at<bf16_t>(saved, o.w_o);
         bf16_t* w1 = at<bf16_t>(saved, o.w1); bf16_t* w2 = at<bf16_t>(saved, o.w2);
-        if (wide_cast(w.in_proj_w, 3 * d, d, d, w_in, at<bf16_t>(saved, o.w_in_t), st)) return 1;
-        if (wide_cast(w.out_proj_w, d, d, d, w_o, at<bf16_t>(saved, o.w_o_t), st)) return 1;
-        if (wide_cast(w.lin1_w, dff, d, d, w1, at<bf16_t>(saved, o.w1_t), st)) return 1;
-        if (wide_cast(w.lin2_w, d, dff, dff, w2, at<bf16_t>(saved, o.w2_t), st)) return 1;
         const float* x32 = cat<float>(saved, o.x32);
         const bf16_t* x16 = cat<bf16_t>(saved, o.x16);
         const bool last = l + 1 == pl.L;
