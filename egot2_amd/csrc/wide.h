@@ -31,7 +31,13 @@ struct WideGemmParams {
 size_t wide_gemm_tn_scratch(int M, int N, int K);
 int wide_gemm_nt(const WideGemmParams& p, hipStream_t st);
 int wide_gemm_nt_colsum_rows(int M, int N);     // rows of WideGemmParams::colsum written for an (M, N) output
-int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st);
+// `defer`: do not launch the slab reduction, queue it (then `scratch` must be a region of its own, wide_gemm_tn_scratch bytes,
+// untouched until wide_reduce_flush() has run)
+struct WideReduceDesc { const float* slabs; float* C; size_t stride; int splits, ldc, M, N, accumulate, first_block, blocks; };
+constexpr int WIDE_REDUCE_MAX = 40;
+struct WideReduceBatch { WideReduceDesc d[WIDE_REDUCE_MAX]; int n = 0, total_blocks = 0; };
+int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer = nullptr);
+int wide_reduce_flush(WideReduceBatch& b, hipStream_t st);
 
 // dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32
 int wide_cast(const float* src, int R, int C, int ld, bf16_t* dst, bf16_t* dst_t, hipStream_t st);
