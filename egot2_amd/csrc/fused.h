@@ -51,7 +51,8 @@ struct FusedFwdParams {
     float* saved_res;       // (2L, B, S, 128) pre-LN residual sums: [2l] = res1, [2l+1] = res2
     uint32_t* relu_bits;    // (L, B, d_ff/32, 64) "alive" bits of the FFN hidden: ReLU active AND kept by dropout (24 per lane)
     void* hid_out;          // optional (L, B, 3, d_ff/16) tiles of the FFN hidden activation (after ReLU and dropout) in
-                            // ffn_dw's token-along-K operand order (fused_dev.h store_hid_tile); fp32 or bf16 elements
+                            // the layout store_hid_tile writes (fp32: ffn_dw's token-along-K operand order; bf16 / split:
+                            // accumulator order, transposed by the weight-gradient kernel's LDS reads); fp32 or bf16 elements
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };

@@ -265,11 +265,15 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) { accW1[j] = f32x4{0, 0, 0, 0}; accW2[j] = f32x4{0, 0, 0, 0}; }
     float accB1 = 0.f;
+    float accB4[4] = {0.f, 0.f, 0.f, 0.f};      // CM_BF16: db1 partials of hidden units 4q..4q+3 over this lane's token
 
     constexpr int LDB = 144;
     typedef short s4v __attribute__((ext_vector_type(4)));
     unsigned short* ldsh = reinterpret_cast<unsigned short*>(lds);
     constexpr int TILEH = 32 * LDB;
+    // per-wave staging of the H / dH tiles (accumulator layout -> token-along-K fragments), behind the x1 / g images
+    constexpr int XG_BYTES = SPLIT ? 2 * 3 * TILEH * 2 : (PF ? 4 : 2) * 32 * LDX * 4;      // as allocated by launch_ffn_dw
+    unsigned short* tstage = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(lds) + XG_BYTES);
     float4 pre[8];
     // the wave's H / dH operand tiles of the next K-block, as loaded (bf16: already operands; fp32 tiles: converted / split
     // into operands after the prefetch has landed)
@@ -368,22 +372,57 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         lstore(cur);
         const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
         Frag<CM> aH, aD;
-        if constexpr (BF16) {
-            u32x4 uh = {nH.a.x, nH.a.y, nH.b.x, nH.b.y}, u = {nD.a.x, nD.a.y, nD.b.x, nD.b.y};
-            aH.v = __builtin_bit_cast(bf16x8, uh);
-            aD.v = __builtin_bit_cast(bf16x8, u);
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                s0 += __uint_as_float(u[j] << 16) + __uint_as_float(u[j] & 0xffff0000u);
-                s1 += __uint_as_float(u[2 + j] << 16) + __uint_as_float(u[2 + j] & 0xffff0000u);
-            }
-            accB1 += s0 + (has_b ? s1 : 0.f);
-        } else {
+        if constexpr (!BF16) {
             float s0 = (nD.a.x + nD.a.y) + (nD.a.z + nD.a.w), s1 = (nD.b.x + nD.b.y) + (nD.b.z + nD.b.w);
             accB1 += s0 + (has_b ? s1 : 0.f);
             aH = make_frag<CM>(nH.a, nH.b);
             aD = make_frag<CM>(nD.a, nD.b);
+        } else {
+            // CM_BF16: tiles arrive in accumulator layout (lane = token r, 4 hidden units 4q..4q+3). Stage this wave's two
+            // K-blocks ([32 tokens][16 hidden] bf16, unpadded 32-byte rows: writes and transposed reads are conflict-free) and
+            // read them back token-along-K. db1: per-lane sums over the tokens, reduced across the 16 token lanes at the end.
+            // (The code below also handles three-part staging; CM_SPLIT does not use it, see store_hid_tile.)
+            constexpr int NPL = SPLIT ? 3 : 1;
+            unsigned short* wt = tstage + wave * (2 * NPL * 512);      // [tensor][part][32][16] halfwords
+            auto put = [&](int tensor, int half, auto ra) {
+                unsigned short* d = wt + tensor * NPL * 512 + (half * 16 + r) * 16 + 4 * q;
+                if constexpr (BF16) {
+                    *reinterpret_cast<uint2*>(d) = (half && !has_b) ? make_uint2(0, 0) : ra;
+                } else {
+                    float4 v = (half && !has_b) ? make_float4(0, 0, 0, 0) : ra;
+                    uint32_t h0, m0, l0, h1, m1, l1;
+                    split_pair(v.x, v.y, h0, m0, l0);
+                    split_pair(v.z, v.w, h1, m1, l1);
+                    *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(d + 512) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(d + 1024) = make_uint2(l0, l1);
+                }
+            };
+            put(0, 0, nH.a); put(0, 1, nH.b); put(1, 0, nD.a); put(1, 1, nD.b);
+            if constexpr (BF16) {
+                accB4[0] += __uint_as_float(nD.a.x << 16) + (has_b ? __uint_as_float(nD.b.x << 16) : 0.f);
+                accB4[1] += __uint_as_float(nD.a.x & 0xffff0000u) + (has_b ? __uint_as_float(nD.b.x & 0xffff0000u) : 0.f);
+                accB4[2] += __uint_as_float(nD.a.y << 16) + (has_b ? __uint_as_float(nD.b.y << 16) : 0.f);
+                accB4[3] += __uint_as_float(nD.a.y & 0xffff0000u) + (has_b ? __uint_as_float(nD.b.y & 0xffff0000u) : 0.f);
+            } else {
+                accB4[0] += nD.a.x + (has_b ? nD.b.x : 0.f); accB4[1] += nD.a.y + (has_b ? nD.b.y : 0.f);
+                accB4[2] += nD.a.z + (has_b ? nD.b.z : 0.f); accB4[3] += nD.a.w + (has_b ? nD.b.w : 0.f);
+            }
+            auto get = [&](int tensor) {
+                const int i = lane & 15;
+                const unsigned short* b = wt + tensor * NPL * 512 + (4 * q + (i >> 2)) * 16 + 4 * (i & 3);
+                Frag<CM> f;
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) {
+                    s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * 512));
+                    s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * 512 + 16 * 16));
+                    if constexpr (SPLIT) f.p[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    else f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                return f;
+            };
+            aH = get(0);
+            aD = get(1);
         }
         __syncthreads();
         if ((PF || PF1) && kb + 1 < kb_end) gload(kb + 1);
@@ -407,10 +446,20 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
             make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
     }
-    float bs = accB1;
-    bs += __shfl_xor(bs, 16, 64);
-    bs += __shfl_xor(bs, 32, 64);
-    if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+    if constexpr (!BF16) {
+        float bs = accB1;
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float bs = accB4[e];
+            bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64); bs += __shfl_xor(bs, 4, 64); bs += __shfl_xor(bs, 8, 64);
+            accB4[e] = bs;
+        }
+        if (r == 0) *reinterpret_cast<float4*>(p.slab_b1 + (size_t)split * p.d_ff + htile * 16 + 4 * q) = make_float4(accB4[0], accB4[1], accB4[2], accB4[3]);
+    }
 }
 
 // Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised. The same launch can
@@ -499,16 +548,18 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     if (p.hs) {
         const int occ = CM == CM_SPLIT ? 2 : ffn_dw_occ(true, CM == CM_BF16);
         if (CM == CM_SPLIT) lds = (size_t)2 * 3 * 32 * 144 * sizeof(unsigned short);
+        // + per-wave staging of the H / dH tiles (4 waves x 2 tensors x parts x 1 KB)
+        const size_t tstage_bytes = CM == CM_BF16 ? (size_t)4 * 2 * 1024 : 0;
         static bool attr2_set = false;
         if (!attr2_set) {
             EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<CM, 2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + tstage_bytes)));
             EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_stored_kernel<CM, 3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + tstage_bytes)));
             attr2_set = true;
         }
-        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2, st, p);
-        else hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 2>), grid, dim3(256), lds, st, p);
+        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2 + tstage_bytes, st, p);
+        else hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 2>), grid, dim3(256), lds + tstage_bytes, st, p);
     } else {
         hipLaunchKernelGGL((ffn_dw_kernel<CM, HT>), grid, dim3(256), lds, st, p);
     }

@@ -241,9 +241,24 @@ __device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
 }
 constexpr int HTILE_ELEMS = 256;   // one (16 tokens x 16 hidden units) tile
 // `tile` = start of the (token tile, hidden tile) block; tokens >= n_valid (within this 16-token tile) are stored as 0
+// CM_BF16: the tile leaves in ACCUMULATOR layout ([lane = token + 16 * (hidden / 4)][hidden % 4]: no transpose, no DPP
+// traffic in the FFN loops); the weight-gradient kernel turns it into token-along-K fragments with the hardware transposed
+// LDS read (ds_read_b64_tr_b16) it uses for its other operand anyway (bf16 step 0.259 -> 0.252 ms). fp32 MFMA operands
+// cannot take that route (16-bit transposes only), and in CM_SPLIT the three-part staging it needs costs the
+// weight-gradient kernel more (+10 us) than the FFN loops save (-4 us): both keep the quad-transposed tile.
 template <int CM>
 __device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int lane, int n_valid) {
     float v[4] = {c[0], c[1], c[2], c[3]};
+    if constexpr (CM == CM_BF16) {
+        if (__builtin_amdgcn_readfirstlane(n_valid) < 16) {
+            asm volatile("" ::: "memory");
+            const bool ok = (lane & 15) < n_valid;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+        }
+        reinterpret_cast<uint2*>(tile)[lane] = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+        return;
+    }
     quad_transpose(v, lane);
     const int r = lane & 15, q = lane >> 4;
     const int t0 = 4 * (r >> 2);
