@@ -175,8 +175,13 @@ static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
 static size_t fused_hid_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return align_up(fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
 }
-static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+// split mode: the FFN input x1 of every layer as three bf16 planes (L, 3, N, d), behind the hidden tiles
+static bool split_planes(const egx_config* cfg) { return cfg->compute == EGX_F32_SPLIT && store_hidden(); }
+static size_t fused_x1p_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_hid_offset(cfg, segs, pl) + fused_hid_total(cfg, pl);
+}
+static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.N * pl.d * 6, 256) : 0);
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
@@ -192,8 +197,9 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     memset(&s, 0, sizeof(s));
     size_t cur = 0;
     size_t nd = pl.N * pl.d * 4;
+    size_t nd3 = nd / 2 * 3;        // g2 leaves as three bf16 parts in split mode (6 B per element)
     for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
-        s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd); s.attn_o[l] = take(cur, nd);
+        s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd3); s.attn_o[l] = take(cur, nd);
         s.g1[l] = take(cur, nd); s.x_in[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
     }
     for (int i = 0; i < pl.nseg; ++i) s.dseg[i] = take(cur, (size_t)pl.B * segs[i].T * pl.d * 4);
@@ -458,6 +464,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.saved_res = (float*)saved + (size_t)N * d;
         fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
         fp.hid_out = store_hidden() ? (char*)saved + fused_hid_offset(cfg, segs, pl) : nullptr;
+        fp.x1p_out = split_planes(cfg) ? (unsigned short*)((char*)saved + fused_x1p_offset(cfg, segs, pl)) : nullptr;
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
@@ -604,6 +611,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.saved_res = (const float*)saved + (size_t)N * d;
             bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
             bp.dhid_out = store_hidden() ? (char*)scratch + SC.dhid : nullptr;
+            bp.xg_planes = split_planes(cfg) ? 1 : 0;
             EGX_CHECK(cfg->zero_bytes % 16 == 0 && (((uintptr_t)cfg->zero_buf) & 15) == 0, "zero_buf must be 16-byte aligned and sized");
             bp.zero_buf = (float*)cfg->zero_buf; bp.zero_n = cfg->zero_buf ? cfg->zero_bytes / 4 : 0;
             bp.partials = fptr(scratch, SC.partials); bp.P = SC.P;
@@ -660,6 +668,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, pl) + lo;
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
                         fp.B = B;
+                        fp.xg_planes = bp.xg_planes;
+                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * N * d * 6);
                     }
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr, cfg->deterministic != 0)) return 1;
                     rp_pending = false;

@@ -53,6 +53,8 @@ struct FusedFwdParams {
     void* hid_out;          // optional (L, B, 3, d_ff/16) tiles of the FFN hidden activation (after ReLU and dropout) in
                             // the layout store_hid_tile writes (fp32: ffn_dw's token-along-K operand order; bf16 / split:
                             // accumulator order, transposed by the weight-gradient kernel's LDS reads); fp32 or bf16 elements
+    unsigned short* x1p_out;    // optional, CM_SPLIT: (L, 3, B*S, 128) the FFN input x1 as the three bf16 parts the FFN loop multiplies
+                                // (the backward then skips its LayerNorm1 recompute; ffn_dw reads these planes)
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };
@@ -82,6 +84,7 @@ struct FfnDwParams {
     const uint64_t* seed_ptr; int layer;                       // device-resident seed (see FusedFwdParams)
     // stored-operand variant: H and dH tiles written by the clip-parallel kernels (no recompute, no weights needed)
     const void* hs; const void* dhs; int B;
+    int xg_planes;        // x1 / g hold three bf16 planes [part][N][128] (the CM_SPLIT operands, split by the backward kernel)
     float* slab_w1; float* slab_w2t; float* slab_b1;           // set by ffn_dw()
     int splits, kb_per_split;
 };
@@ -107,7 +110,8 @@ struct FusedBwdLayer {
     uint64_t attn_key, res1_key, ffn_key, res2_key;
     uint32_t attn_thresh, res_thresh, ffn_thresh;
     float drop_inv;
-    // per-token tensors handed to the weight-gradient kernels, all (B*S, .) token-major fp32
+    // per-token tensors handed to the weight-gradient kernels, all (B*S, .) token-major fp32 (g2_out: three bf16 planes
+    // [part][B*S][128] when FusedBwdParams::xg_planes is set)
     float* x1_out; float* g2_out; float* attn_o_out; float* g1_out; float* x_in_out; float* dqkv_out;
 };
 
@@ -130,6 +134,8 @@ struct FusedBwdParams {
     const float* saved_pre;    // from the forward
     const float* saved_res;
     const uint32_t* relu_bits;
+    int xg_planes;          // CM_SPLIT: g2_out leaves pre-split (what ffn_dw_stored_kernel<CM_SPLIT> reads) and x1_out is not
+                            // written at all: the forward has saved x1 in that form (FusedFwdParams::x1p_out)
     void* dhid_out;         // optional gradient of the FFN pre-activation, same tile layout as FusedFwdParams::hid_out
     float* zero_buf; size_t zero_n;   // optional: floats the kernel zero-fills first (the caller's flat gradient buffer)
     float* partials; int P;

@@ -195,12 +195,13 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     __syncthreads();
     STAMP(1);
     // save pre-LN projections (token order) and apply the shared LN + embeddings
+    store_block(p.saved_pre + (size_t)clip * S * FD, Xs, S);
+    __syncthreads();
     ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
         int sgi = 0;
         while (sgi + 1 < p.nseg && row >= p.seg[sgi + 1].off) ++sgi;
         const FusedSeg& sg = p.seg[sgi];
         int t = row - sg.off;
-        store32(p.saved_pre + ((size_t)clip * S + row) * FD + c0, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (sg.add_vec) {
@@ -438,10 +439,15 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         // CM_SPLIT: x1 is also split into bf16 operand planes for the FFN loop (over Q / K, dead since the out-projection)
         unsigned short* XP = reinterpret_cast<unsigned short*>(Qs);
         constexpr int XPS = SP * LDXH;
+        store_block(sv_res1, X1, S);
+        __syncthreads();
         ln_rows(X1, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-            store32(sv_res1 + (size_t)row * FD + c0, x);
             store32(X1 + row * LDX + c0, y);
-            if constexpr (CM == CM_SPLIT) store_split32(XP, XPS, row, c0, y);
+            if constexpr (CM == CM_SPLIT) {
+                uint32_t h[16], m[16], lo[16];
+                split32(y, h, m, lo);
+                store_parts32(XP + row * LDXH + c0, (size_t)XPS, h, m, lo);
+            }
         });
         if constexpr (CM == CM_SPLIT) {     // padded rows of the planes: zero operands
             for (int i = tid; i < 3 * (SP - S) * (LDXH / 8); i += 256) {
@@ -450,6 +456,19 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         }
         __syncthreads();
+        if constexpr (CM == CM_SPLIT) {
+            // x1 leaves for the weight-gradient kernel in the same three parts ((L, 3, N, 128) bf16): dense 16-byte pieces in
+            // lane order out of the LDS planes (stores from the LayerNorm lanes, 64 B per lane and part, cost the kernel 10 us)
+            if (p.x1p_out) {
+                const size_t plane = (size_t)p.B * S * FD;
+                unsigned short* dst = p.x1p_out + (size_t)l * 3 * plane + (size_t)clip * S * FD;
+                for (int i = tid; i < 3 * S * (FD / 8); i += 256) {
+                    int part = i / (S * (FD / 8)), rem = i - part * (S * (FD / 8));
+                    int row = rem >> 4, c8 = rem & 15;
+                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(XP + part * XPS + row * LDXH + c8 * 8);
+                }
+            }
+        }
 
         STAMP(6);
         EGX_PHASE();
@@ -631,8 +650,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
         {
             bool last = (l + 1 == p.n_layers);
+            store_block(sv_res2, X1, S);        // the LayerNorm below leaves X1 alone
             ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-                store32(sv_res2 + (size_t)row * FD + c0, x);
                 if (last && p.tokens_out && row < p.out_T) store32(p.tokens_out + ((size_t)clip * p.out_T + row) * FD + c0, y);
                 if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
             });

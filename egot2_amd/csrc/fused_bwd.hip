@@ -280,16 +280,34 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     struct HidRaw { float4 a, b; };
     struct HidRawB { uint2 a, b; };
     typename std::conditional<BF16, HidRawB, HidRaw>::type nH, nD;
+    // CM_SPLIT: x1 / g arrive as three bf16 planes ([part][N][128], written by the clip-parallel kernels); a thread moves two rows x
+    // 16 B of every (tensor, part) image: no split work here (the 32 workgroups of a token range used to repeat it)
+    uint4 prs[SPLIT ? 12 : 1];
     auto gload = [&](int kb) {
+        if constexpr (SPLIT) {
+            const size_t plane = (size_t)p.N * FD;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int f = tid + i * 256;
-            int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
-            int tile = kb * 2 + (row >> 4);
-            int clip = tile / FUSED_TOK_TILES;
-            int tok = (tile - clip * FUSED_TOK_TILES) * 16 + (row & 15);
-            const float* src = (tensor ? p.g : p.x1) + ((size_t)clip * p.S + tok) * FD + c4 * 4;
-            pre[i] = (tile < ntile && tok < p.S) ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
+            for (int i = 0; i < 12; ++i) {
+                const int tp = i >> 1, tensor = tp / 3, part = tp - tensor * 3;
+                const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
+                int tile = kb * 2 + (row >> 4);
+                int clip = tile / FUSED_TOK_TILES;
+                int tok = (tile - clip * FUSED_TOK_TILES) * 16 + (row & 15);
+                const unsigned short* src = reinterpret_cast<const unsigned short*>(tensor ? p.g : p.x1) + part * plane +
+                                            ((size_t)clip * p.S + tok) * FD + c8 * 8;
+                prs[i] = (tile < ntile && tok < p.S) ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int f = tid + i * 256;
+                int tensor = f >> 10, row = (f & 1023) >> 5, c4 = f & 31;
+                int tile = kb * 2 + (row >> 4);
+                int clip = tile / FUSED_TOK_TILES;
+                int tok = (tile - clip * FUSED_TOK_TILES) * 16 + (row & 15);
+                const float* src = (tensor ? p.g : p.x1) + ((size_t)clip * p.S + tok) * FD + c4 * 4;
+                pre[i] = (tile < ntile && tok < p.S) ? *reinterpret_cast<const float4*>(src) : make_float4(0, 0, 0, 0);
+            }
         }
         int ta = kb * 2, tb = min(kb * 2 + 1, ntile - 1);     // a missing second tile meets zero x1 / g rows
         size_t oa = ((size_t)ta * nht + htile) * (HTILE_ELEMS * ESZ), ob = ((size_t)tb * nht + htile) * (HTILE_ELEMS * ESZ);
@@ -306,6 +324,14 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         }
     };
     auto lstore = [&](int buf_idx) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
+                *reinterpret_cast<uint4*>(ldsh + (i >> 1) * TILEH + row * LDB + c8 * 8) = prs[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int f = tid + i * 256;
@@ -313,14 +339,6 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             if constexpr (BF16) {
                 uint2 pk = make_uint2(pack_bf16(pre[i].x, pre[i].y), pack_bf16(pre[i].z, pre[i].w));
                 *reinterpret_cast<uint2*>(ldsh + (buf_idx * 2 + tensor) * TILEH + row * LDB + c4 * 4) = pk;
-            } else if constexpr (SPLIT) {       // split once per K-block, shared by the four waves
-                uint32_t h0, m0, l0, h1, m1, l1;
-                split_pair(pre[i].x, pre[i].y, h0, m0, l0);
-                split_pair(pre[i].z, pre[i].w, h1, m1, l1);
-                unsigned short* d = ldsh + tensor * 3 * TILEH + row * LDB + c4 * 4;
-                *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(d + TILEH) = make_uint2(m0, m1);
-                *reinterpret_cast<uint2*>(d + 2 * TILEH) = make_uint2(l0, l1);
             } else {
                 *reinterpret_cast<float4*>(lds + (buf_idx * 2 + tensor) * TILE + row * LDX + c4 * 4) = pre[i];
             }
@@ -546,6 +564,7 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
     if (p.hs) {
+        EGX_CHECK(CM != CM_SPLIT || p.xg_planes, "ffn_dw: the split-mode stored-operand kernel reads pre-split x1 / g planes");
         const int occ = CM == CM_SPLIT ? 2 : ffn_dw_occ(true, CM == CM_BF16);
         if (CM == CM_SPLIT) lds = (size_t)2 * 3 * 32 * 144 * sizeof(unsigned short);
         // + per-wave staging of the H / dH tiles (4 waves x 2 tensors x parts x 1 KB)
@@ -958,9 +977,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res2, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);
-                store32(w.g2_out + (tok0 + row) * FD + c0, dx);
             });
         __syncthreads();
+        if (!(CM == CM_SPLIT && p.xg_planes)) store_block(w.g2_out + tok0 * FD, B2, S);
         BSTAMP(1);
         // P3: column sums (norm2_w, norm2_b, lin2_b partials); res1 -> B4 and LayerNorm1 forward in place (x1)
         if (tid < 128) {
@@ -971,9 +990,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
         load_block(B5, sv_res1);        // stays in B5 until LayerNorm1 backward (P5): one global read of res1 per layer
         __syncthreads();
-        ln_rows(B5, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-            store32(w.x1_out + (tok0 + row) * FD + c0, y);      // x1 is only an operand of the weight-gradient kernel
-        });
+        // x1 is only an operand of the weight-gradient kernel; in split mode the forward has saved it, as bf16 parts
+        if (!(CM == CM_SPLIT && p.xg_planes)) {
+            ln_rows(B5, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+                store32(w.x1_out + (tok0 + row) * FD + c0, y);
+            });
+        }
         // CM_SPLIT: g2 (B2) is split once into bf16 operand planes for the P4 loop (over B3 / B4: dY.xhat is consumed, B4 is free)
         unsigned short* GP = reinterpret_cast<unsigned short*>(B3 < B4 ? B3 : B4);
         constexpr int GPS = SP * LDXH;
@@ -982,11 +1004,25 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             const int row = tid >> 2, c0 = (tid & 3) * 32;
             if (row < SP) {     // padded rows of B2 are zero
                 float g[32];
+                uint32_t h[16], m[16], lo[16];
                 load32(B2 + row * LDX + c0, g);
-                store_split32(GP, GPS, row, c0, g);
+                split32(g, h, m, lo);
+                store_parts32(GP + row * LDXH + c0, (size_t)GPS, h, m, lo);
             }
         }
         __syncthreads();
+        if constexpr (CM == CM_SPLIT) {
+            // g2 leaves for the weight-gradient kernel as the same three parts ((3, N, 128) bf16), dense 16-byte pieces in lane order
+            if (p.xg_planes) {
+                const size_t plane = (size_t)p.B * S * FD;
+                unsigned short* dst = reinterpret_cast<unsigned short*>(w.g2_out) + tok0 * FD;
+                for (int i = tid; i < 3 * S * (FD / 8); i += 256) {
+                    int part = i / (S * (FD / 8)), rem = i - part * (S * (FD / 8));
+                    int row = rem >> 4, c8 = rem & 15;
+                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(GP + part * GPS + row * LDXH + c8 * 8);
+                }
+            }
+        }
 
         BSTAMP(2);
         EGX_PHASE();
@@ -1134,9 +1170,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res1, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);      // g1
-                store32(w.g1_out + (tok0 + row) * FD + c0, dx);
             });
         __syncthreads();
+        store_block(w.g1_out + tok0 * FD, B2, S);
         BSTAMP(5);
         PackW<CM, 2, 4> wo_pf;        // W_o^T fragments of P7: in flight under the column sums
         pack_issue(wo_pf, w.out_proj_wtp, wave * 2, 4, 0);
@@ -1191,7 +1227,6 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
                 }
                 store32(Gs + row * LDX + c0, y);
-                store32(w.x_in_out + (tok0 + row) * FD + c0, y);
             });
         } else {
             const FusedBwdLayer& wp = p.layer[l - 1];
@@ -1199,10 +1234,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             __syncthreads();
             ln_rows(Gs, S, wp.norm2_w, wp.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 store32(Gs + row * LDX + c0, y);
-                store32(w.x_in_out + (tok0 + row) * FD + c0, y);
             });
         }
         __syncthreads();
+        store_block(w.x_in_out + tok0 * FD, Gs, S);
         BSTAMP(7);
         EGX_PHASE();
         // P9: QKV recompute: Q -> B4, K -> B5, V -> Gs (written after the barrier: Gs is this GEMM's B operand)

@@ -170,17 +170,24 @@ __device__ __forceinline__ void pin_all(T (&x)[N][M]) {
 // into three bf16 planes [part][rows][LDXH]; a fragment is then six ds_read_b64 and no VALU work. Row stride 272 B: the
 // 16 rows x 2 lane groups of a half-wave cover all 64 banks exactly once.
 constexpr int LDXH = FD + 8;
-__device__ __forceinline__ void store_split32(unsigned short* planes, int plane_stride, int row, int c0, const float (&v)[32]) {
-    uint32_t h[16], m[16], l[16];
+__device__ __forceinline__ void split32(const float (&v)[32], uint32_t (&h)[16], uint32_t (&m)[16], uint32_t (&l)[16]) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
-    unsigned short* d = planes + row * LDXH + c0;
+}
+// 32 consecutive elements of one row, already split: d = &plane0[row][c0]
+__device__ __forceinline__ void store_parts32(unsigned short* d, size_t plane_stride, const uint32_t (&h)[16], const uint32_t (&m)[16],
+                                              const uint32_t (&l)[16]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         *reinterpret_cast<uint4*>(d + 8 * g) = make_uint4(h[4 * g], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]);
         *reinterpret_cast<uint4*>(d + plane_stride + 8 * g) = make_uint4(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]);
         *reinterpret_cast<uint4*>(d + 2 * plane_stride + 8 * g) = make_uint4(l[4 * g], l[4 * g + 1], l[4 * g + 2], l[4 * g + 3]);
     }
+}
+__device__ __forceinline__ void store_split32(unsigned short* planes, int plane_stride, int row, int c0, const float (&v)[32]) {
+    uint32_t h[16], m[16], l[16];
+    split32(v, h, m, l);
+    store_parts32(planes + row * LDXH + c0, (size_t)plane_stride, h, m, l);
 }
 __device__ __forceinline__ Frag<CM_SPLIT> load_split_frag(const unsigned short* planes, int plane_stride, int row, int k0, int q) {
     Frag<CM_SPLIT> f;
@@ -344,6 +351,16 @@ __device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __
 __device__ __forceinline__ void store32(float* dst, const float (&v)[32]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+
+// rows [0, S) of a token-major fp32 LDS block -> dense global rows, 16 bytes per lane in lane order. (store32 from the
+// LayerNorm lanes sends every 128-byte line to the L2 as eight partial writes, and the next vmcnt wait of the wave
+// sits behind them: 12 such stores per lane cost the forward kernel 10 us, the same bytes in lane order 2.5 us.)
+__device__ __forceinline__ void store_block(float* dst, const float* lds_src, int S) {
+    for (int i = threadIdx.x; i < S * (FD / 4); i += 256) {
+        int row = i >> 5, c4 = i & 31;
+        *reinterpret_cast<float4*>(dst + (size_t)i * 4) = *reinterpret_cast<const float4*>(lds_src + row * LDX + c4 * 4);
+    }
 }
 
 __device__ __forceinline__ void load32(const float* src, float (&v)[32]) {
