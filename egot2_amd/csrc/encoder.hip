@@ -175,13 +175,13 @@ static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
 static size_t fused_hid_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return align_up(fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
 }
-// split mode: the FFN input x1 of every layer as three bf16 planes (L, 3, N, d), behind the hidden tiles
+// split mode: the FFN input x1 of every layer as three bf16 planes (L, 3, B * 48, d), behind the hidden tiles
 static bool split_planes(const egx_config* cfg) { return cfg->compute == EGX_F32_SPLIT && store_hidden(); }
 static size_t fused_x1p_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_hid_offset(cfg, segs, pl) + fused_hid_total(cfg, pl);
 }
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.N * pl.d * 6, 256) : 0);
+    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * pl.d * 6, 256) : 0);
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
@@ -197,7 +197,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     memset(&s, 0, sizeof(s));
     size_t cur = 0;
     size_t nd = pl.N * pl.d * 4;
-    size_t nd3 = nd / 2 * 3;        // g2 leaves as three bf16 parts in split mode (6 B per element)
+    size_t nd3 = (size_t)pl.B * FUSED_TOK_PAD * pl.d * 6;        // g2 leaves as three bf16 planes on the 48-row clip grid in split mode
     for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
         s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd3); s.attn_o[l] = take(cur, nd);
         s.g1[l] = take(cur, nd); s.x_in[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
@@ -669,7 +669,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
                         fp.B = B;
                         fp.xg_planes = bp.xg_planes;
-                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * N * d * 6);
+                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * B * FUSED_TOK_PAD * d * 6);
                     }
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr, cfg->deterministic != 0)) return 1;
                     rp_pending = false;

@@ -53,7 +53,7 @@ struct FusedFwdParams {
     void* hid_out;          // optional (L, B, 3, d_ff/16) tiles of the FFN hidden activation (after ReLU and dropout) in
                             // the layout store_hid_tile writes (fp32: ffn_dw's token-along-K operand order; bf16 / split:
                             // accumulator order, transposed by the weight-gradient kernel's LDS reads); fp32 or bf16 elements
-    unsigned short* x1p_out;    // optional, CM_SPLIT: (L, 3, B*S, 128) the FFN input x1 as the three bf16 parts the FFN loop multiplies
+    unsigned short* x1p_out;    // optional, CM_SPLIT: (L, 3, B*48, 128) the FFN input x1 (clip-padded token grid) as the three bf16 parts the FFN loop multiplies
                                 // (the backward then skips its LayerNorm1 recompute; ffn_dw reads these planes)
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
@@ -84,11 +84,12 @@ struct FfnDwParams {
     const uint64_t* seed_ptr; int layer;                       // device-resident seed (see FusedFwdParams)
     // stored-operand variant: H and dH tiles written by the clip-parallel kernels (no recompute, no weights needed)
     const void* hs; const void* dhs; int B;
-    int xg_planes;        // x1 / g hold three bf16 planes [part][N][128] (the CM_SPLIT operands, split by the backward kernel)
+    int xg_planes;        // x1 / g hold three bf16 planes [part][B*48][128] on the clip-padded token grid (the CM_SPLIT operands, split by the backward kernel)
     float* slab_w1; float* slab_w2t; float* slab_b1;           // set by ffn_dw()
     int splits, kb_per_split;
 };
 constexpr int FUSED_TOK_TILES = 3;   // 16-token tiles per clip in the fused kernels (S <= 48)
+constexpr int FUSED_TOK_PAD = FUSED_TOK_TILES * 16;   // rows per clip of the clip-padded token grid (rows >= S are zero)
 static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer of hidden tiles
     return (size_t)B * FUSED_TOK_TILES * (d_ff / 16) * 256 * (bf16 ? 2 : 4);
 }
@@ -111,7 +112,7 @@ struct FusedBwdLayer {
     uint32_t attn_thresh, res_thresh, ffn_thresh;
     float drop_inv;
     // per-token tensors handed to the weight-gradient kernels, all (B*S, .) token-major fp32 (g2_out: three bf16 planes
-    // [part][B*S][128] when FusedBwdParams::xg_planes is set)
+    // [part][B*48][128] when FusedBwdParams::xg_planes is set)
     float* x1_out; float* g2_out; float* attn_o_out; float* g1_out; float* x_in_out; float* dqkv_out;
 };
 

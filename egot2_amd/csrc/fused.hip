@@ -460,10 +460,11 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             // x1 leaves for the weight-gradient kernel in the same three parts ((L, 3, N, 128) bf16): dense 16-byte pieces in
             // lane order out of the LDS planes (stores from the LayerNorm lanes, 64 B per lane and part, cost the kernel 10 us)
             if (p.x1p_out) {
-                const size_t plane = (size_t)p.B * S * FD;
-                unsigned short* dst = p.x1p_out + (size_t)l * 3 * plane + (size_t)clip * S * FD;
-                for (int i = tid; i < 3 * S * (FD / 8); i += 256) {
-                    int part = i / (S * (FD / 8)), rem = i - part * (S * (FD / 8));
+                static_assert(SP == FUSED_TOK_PAD, "the operand planes live on the 48-row clip grid");
+                const size_t plane = (size_t)p.B * SP * FD;
+                unsigned short* dst = p.x1p_out + (size_t)l * 3 * plane + (size_t)clip * SP * FD;
+                for (int i = tid; i < 3 * SP * (FD / 8); i += 256) {
+                    int part = i / (SP * (FD / 8)), rem = i - part * (SP * (FD / 8));
                     int row = rem >> 4, c8 = rem & 15;
                     *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(XP + part * XPS + row * LDXH + c8 * 8);
                 }

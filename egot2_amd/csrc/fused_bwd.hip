@@ -285,17 +285,15 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     uint4 prs[SPLIT ? 12 : 1];
     auto gload = [&](int kb) {
         if constexpr (SPLIT) {
-            const size_t plane = (size_t)p.N * FD;
+            const size_t plane = (size_t)p.B * FUSED_TOK_PAD * FD;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const int tp = i >> 1, tensor = tp / 3, part = tp - tensor * 3;
                 const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
                 int tile = kb * 2 + (row >> 4);
-                int clip = tile / FUSED_TOK_TILES;
-                int tok = (tile - clip * FUSED_TOK_TILES) * 16 + (row & 15);
                 const unsigned short* src = reinterpret_cast<const unsigned short*>(tensor ? p.g : p.x1) + part * plane +
-                                            ((size_t)clip * p.S + tok) * FD + c8 * 8;
-                prs[i] = (tile < ntile && tok < p.S) ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+                                            ((size_t)tile * 16 + (row & 15)) * FD + c8 * 8;
+                prs[i] = tile < ntile ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -375,6 +373,11 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     };
 
     // CM_SPLIT: register prefetch of the next K-block over its single LDS buffer (the loads fly under this block's MFMAs).
+    // Measured on this kernel (79 us): dropping 7/8 of the MFMAs, or all fragment reads but one, or the H / dH split, or half of
+    // the H / dH loads, each moves it by < 10 %; two hidden tiles per wave at one workgroup per CU: 90 us; eight waves sharing
+    // a three-stage LDS-DMA ring with the tiles two K-blocks ahead: 95 us. SQ counters: MFMA busy 35 us + VALU busy 27 us
+    // per SIMD, waves wait 38 % of their time — what helps is two INDEPENDENT workgroups per CU drifting out of phase (one
+    // in its split / staging phase while the other runs MFMAs); an 8-wave workgroup runs all its phases in lockstep.
     // (A 2 x 4 hidden x feature tiling per wave, which halves the LDS fragment reads, was slower: 87 -> 100 us — the kernel
     // follows its total VALU + MFMA work, and that tiling splits twice as many H / dH tiles per wave.)
     constexpr bool PF1 = SPLIT;
@@ -1014,10 +1017,11 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         if constexpr (CM == CM_SPLIT) {
             // g2 leaves for the weight-gradient kernel as the same three parts ((3, N, 128) bf16), dense 16-byte pieces in lane order
             if (p.xg_planes) {
-                const size_t plane = (size_t)p.B * S * FD;
-                unsigned short* dst = reinterpret_cast<unsigned short*>(w.g2_out) + tok0 * FD;
-                for (int i = tid; i < 3 * S * (FD / 8); i += 256) {
-                    int part = i / (S * (FD / 8)), rem = i - part * (S * (FD / 8));
+                static_assert(SP == FUSED_TOK_PAD, "the operand planes live on the 48-row clip grid");
+                const size_t plane = (size_t)p.B * SP * FD;
+                unsigned short* dst = reinterpret_cast<unsigned short*>(w.g2_out) + (size_t)clip * SP * FD;
+                for (int i = tid; i < 3 * SP * (FD / 8); i += 256) {
+                    int part = i / (SP * (FD / 8)), rem = i - part * (SP * (FD / 8));
                     int row = rem >> 4, c8 = rem & 15;
                     *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(GP + part * GPS + row * LDXH + c8 * 8);
                 }
