@@ -254,7 +254,14 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     constexpr int ESZ = BF16 ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int htile = blockIdx.x * 4 + wave, split = blockIdx.y;
+    // Workgroups are dispatched round-robin over the 8 XCDs; the 32 hidden groups of one token split read the same x1 / g
+    // rows, so each XCD takes a contiguous range of (split, hidden group) pairs and its L2 fetches those rows once.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nwg = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        if ((nwg & 7) == 0) { const int t = (id & 7) * (nwg >> 3) + (id >> 3); by = t / gridDim.x; bx = t - by * gridDim.x; }
+    }
+    const int htile = bx * 4 + wave, split = by;
     const int nht = p.d_ff / 16;
     const int ntile = p.B * FUSED_TOK_TILES;
     const int nkb_total = (ntile + 1) / 2;

@@ -32,4 +32,15 @@ for layout, M, N, K in shapes:
         run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
+    # the same product through torch.matmul (hipBLASLt / rocBLAS bf16, fp32 accumulate): a yardstick, not a code path
+    def lib_run():
+        return (A @ B.t()) if layout == 0 else (A.t() @ B)
+    for _ in range(3):
+        lib_run()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        lib_run()
+    e1.record(); torch.cuda.synchronize()
+    us_lib = e0.elapsed_time(e1) / reps * 1e3
+    print(f"   torch.matmul {us_lib:8.1f} us  {2.0 * M * N * K / us_lib / 1e6:7.1f} TFLOP/s", end="  | ")
     print(f"{'NT' if layout == 0 else 'TN'} M={M:6d} N={N:5d} K={K:6d}  {us:8.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s (incl. memset/reduce launches)")
