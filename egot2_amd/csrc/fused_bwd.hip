@@ -539,9 +539,10 @@ __device__ __forceinline__ void reduce_partials_block(const ReducePartialsParams
 }
 __global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) { reduce_slabs_block(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void reduce_tail_kernel(SlabReduce3 a, ReducePartialsParams rp, unsigned slab_blocks, int chunks) {
-    if (blockIdx.x < slab_blocks) { reduce_slabs_block(a, blockIdx.x); return; }
-    unsigned pb = blockIdx.x - slab_blocks;
-    reduce_partials_block(rp, (int)(pb / chunks), (int)(pb % chunks), chunks);
+    // the partial-row blocks go first: they are chains of dependent loads and atomics that then run under the slab streams
+    const unsigned part_blocks = gridDim.x - slab_blocks;
+    if (blockIdx.x >= part_blocks) { reduce_slabs_block(a, blockIdx.x - part_blocks); return; }
+    reduce_partials_block(rp, (int)(blockIdx.x / chunks), (int)(blockIdx.x % chunks), chunks);
 }
 static int partial_chunks(int B) { return B >= 64 ? 16 : (B >= 8 ? 4 : 1); }
 
