@@ -175,13 +175,16 @@ static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
 static size_t fused_hid_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return align_up(fused_act_bytes(pl) + fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
 }
-// split mode: the FFN input x1 of every layer as three bf16 planes (L, 3, B * 48, d), behind the hidden tiles
-static bool split_planes(const egx_config* cfg) { return cfg->compute == EGX_F32_SPLIT && store_hidden(); }
+// split / bf16 mode: the FFN input x1 of every layer as bf16 planes (L, 3 or 1, B * 48, d), behind the hidden tiles
+static bool split_planes(const egx_config* cfg) {
+    return (cfg->compute == EGX_F32_SPLIT || (cfg->compute == EGX_BF16 && ffn_dw_bf16_planes())) && store_hidden();
+}
+static size_t plane_elem_bytes(const egx_config* cfg) { return cfg->compute == EGX_BF16 ? 2 : 6; }   // one bf16 plane, or the three parts
 static size_t fused_x1p_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_hid_offset(cfg, segs, pl) + fused_hid_total(cfg, pl);
 }
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * pl.d * 6, 256) : 0);
+    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * pl.d * plane_elem_bytes(cfg), 256) : 0);
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
@@ -669,7 +672,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
                         fp.B = B;
                         fp.xg_planes = bp.xg_planes;
-                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * B * FUSED_TOK_PAD * d * 6);
+                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * B * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
                     }
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr, cfg->deterministic != 0)) return 1;
                     rp_pending = false;

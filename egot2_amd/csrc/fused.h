@@ -94,6 +94,7 @@ static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer
     return (size_t)B * FUSED_TOK_TILES * (d_ff / 16) * 256 * (bf16 ? 2 : 4);
 }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
+bool ffn_dw_bf16_planes();   // bf16 mode hands x1 / g2 over as bf16 planes (the LDS-ring weight-gradient kernel)
 struct ReducePartialsParams;
 // `rp` (optional): per-clip partial sums to reduce in the same launch as the slab reduction
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,

@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         }
         __syncthreads();
+        if constexpr (CM == CM_BF16) {      // bf16 mode: one bf16 plane (L, B*48, 128), same hand-over
+            if (p.x1p_out) store_block_bf16(p.x1p_out + ((size_t)l * p.B + clip) * FUSED_TOK_PAD * FD, X1, S);
+        }
         if constexpr (CM == CM_SPLIT) {
             // x1 leaves for the weight-gradient kernel in the same three parts ((L, 3, N, 128) bf16): dense 16-byte pieces in
             // lane order out of the LDS planes (stores from the LayerNorm lanes, 64 B per lane and part, cost the kernel 10 us)

@@ -490,6 +490,145 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     }
 }
 
+// bf16 stored-operand kernel with everything staged by LDS-DMA. ffn_dw_stored_kernel<CM_BF16> spends a K-block's time on
+// 16 MFMAs per wave and a chain of load -> convert -> ds_write -> barrier -> ds_read around them. Here the x1 / g rows
+// (bf16 planes on the 48-row clip grid, written by the clip-parallel kernels) and the wave's four H / dH tiles enter a ring
+// of three LDS stages by global_load_lds_dwordx4 — no registers, no conversion, no ds_write — two K-blocks ahead; a counted
+// s_waitcnt leaves the newer K-block in flight across the one barrier per K-block. Stage = x1 image + g image ([32 tokens]
+// [128] bf16, 32-byte column chunks XOR-swizzled with the row so that the transposed fragment reads spread over all banks)
+// + 4 waves x 4 tiles of 512 B (accumulator layout, read back token-along-K by ds_read_b64_tr_b16 as they lie). 256 threads,
+// two independent workgroups per CU.
+#define EGX_RING_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+__global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p) {
+    constexpr int CM = CM_BF16;
+    // (two stages at three workgroups per CU, with 16 or 24 token splits, run at the same 35 us)
+    constexpr int IMG = 32 * 256, TILES = 4 * 4 * 512, SB = 2 * IMG + TILES, D = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    typedef short s4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s4v lds_s4v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {   // XCD-contiguous (split, hidden group) ranges, as in ffn_dw_stored_kernel
+        const int nwg = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        if ((nwg & 7) == 0) { const int t = (id & 7) * (nwg >> 3) + (id >> 3); by = t / gridDim.x; bx = t - by * gridDim.x; }
+    }
+    const int htile = bx * 4 + wave, split = by;
+    const int nht = p.d_ff / 16;
+    const int ntile = p.B * FUSED_TOK_TILES;
+    const int nkb_total = (ntile + 1) / 2;
+    const int kb_beg = split * p.kb_per_split;
+    const int kb_end = min(nkb_total, kb_beg + p.kb_per_split);
+
+    f32x4 accW1[8], accW2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { accW1[j] = f32x4{0, 0, 0, 0}; accW2[j] = f32x4{0, 0, 0, 0}; }
+    float accB4[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // staging, six instructions per wave and K-block: j < 4 moves rows 4 * (idx & 7) .. + 3 of image idx >> 3 (idx = 4 w + j);
+    // j = 4 / 5 moves this wave's two H / two dH tiles (lanes 0..31: first token tile, lanes 32..63: second)
+    const unsigned char* srcS[4];
+    int rowS[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = wave * 4 + j, img = idx >> 3;
+        const int row = (idx & 7) * 4 + (lane >> 4), slot = lane & 15;
+        rowS[j] = row;
+        srcS[j] = reinterpret_cast<const unsigned char*>(img ? p.g : p.x1) + (((slot >> 1) ^ (row & 7)) * 32 + (slot & 1) * 16);
+    }
+    const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(p.hs) + (size_t)htile * 512 + (lane & 31) * 16;
+    const unsigned char* dsrc = reinterpret_cast<const unsigned char*>(p.dhs) + (size_t)htile * 512 + (lane & 31) * 16;
+    auto stage = [&](int kb, int buf) {
+        unsigned char* dst = ring + buf * SB + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int tile = min(kb * 2 + (rowS[j] >> 4), ntile - 1);     // a missing second tile: finite rows, its H / dH operand half is zeroed
+            __builtin_amdgcn_global_load_lds((glb_void*)(srcS[j] + ((size_t)tile * 16 + (rowS[j] & 15)) * (FD * 2)), (lds_void*)(dst + j * 1024), 16, 0, 0);
+        }
+        const int tt = min(kb * 2 + (lane >> 5), ntile - 1);
+        unsigned char* td = ring + buf * SB + 2 * IMG + wave * 2048;
+        __builtin_amdgcn_global_load_lds((glb_void*)(hsrc + (size_t)tt * nht * 512), (lds_void*)td, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(dsrc + (size_t)tt * nht * 512), (lds_void*)(td + 1024), 16, 0, 0);
+    };
+    // x1 / g fragment: lane (r, q) supplies row 4q + (r >> 2) (+ 16) and the 8 bytes 4 (r & 3) of its 32-byte chunk
+    const int frow = 4 * q + (r >> 2);
+    const int foff = frow * 256 + 8 * (r & 3), fswz = frow & 7;
+    auto tok_frag = [&](int buf, int img, int jt) -> Frag<CM> {
+        const unsigned char* b = ring + buf * SB + img * IMG + foff + ((jt ^ fswz) * 32);
+        s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b));
+        s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + 16 * 256));
+        Frag<CM> f;
+        f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return f;
+    };
+    // H / dH tile pair as they lie (accumulator layout: [hidden / 4][token][hidden % 4]): lane (r, q) supplies the 4 hidden
+    // units 4 (r & 3) .. + 3 of token 4q + (r >> 2); the second tile sits 512 B behind the first
+    const int toff = ((r & 3) * 16 + 4 * q + (r >> 2)) * 8;
+
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s)
+        if (kb_beg + s < kb_end) stage(kb_beg + s, s);
+    for (int kb0 = kb_beg; kb0 < kb_end; kb0 += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int kb = kb0 + s;
+            if (kb >= kb_end) break;
+            // this K-block's six loads have landed; the next K-block's six may stay in flight across the barrier
+            if (kb + 1 < kb_end) EGX_RING_WAIT(6); else EGX_RING_WAIT(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kb + D - 1 < kb_end) stage(kb + D - 1, (s + D - 1) % D);
+            const bool has_b = kb * 2 + 1 < ntile;
+            const unsigned char* tb = ring + s * SB + 2 * IMG + wave * 2048;
+            Frag<CM> aH, aD;
+            {
+                s4v hlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tb + toff));
+                s4v hhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tb + 512 + toff));
+                s4v dlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tb + 1024 + toff));
+                s4v dhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tb + 1536 + toff));
+                if (!has_b) { hhi = s4v{0, 0, 0, 0}; dhi = s4v{0, 0, 0, 0}; }
+                aH.v = __builtin_shufflevector(hlo, hhi, 0, 1, 2, 3, 4, 5, 6, 7);
+                aD.v = __builtin_shufflevector(dlo, dhi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            {   // db1: this lane's token of hidden units 4q .. 4q + 3 (tile entry [lane]), summed over the 16 token lanes at the end
+                uint2 da = *reinterpret_cast<const uint2*>(tb + 1024 + lane * 8);
+                uint2 db = *reinterpret_cast<const uint2*>(tb + 1536 + lane * 8);
+                if (!has_b) db = make_uint2(0, 0);
+                accB4[0] += __uint_as_float(da.x << 16) + __uint_as_float(db.x << 16);
+                accB4[1] += __uint_as_float(da.x & 0xffff0000u) + __uint_as_float(db.x & 0xffff0000u);
+                accB4[2] += __uint_as_float(da.y << 16) + __uint_as_float(db.y << 16);
+                accB4[3] += __uint_as_float(da.y & 0xffff0000u) + __uint_as_float(db.y & 0xffff0000u);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 8; ++jt) {
+                Frag<CM> bx1 = tok_frag(s, 0, jt);
+                Frag<CM> bg = tok_frag(s, 1, jt);
+                mma<CM>(accW1[jt], aD, bx1);
+                mma<CM>(accW2[jt], aH, bg);
+            }
+        }
+    }
+
+    float* sw1 = p.slab_w1 + (size_t)split * p.d_ff * FD;
+    float* sw2 = p.slab_w2t + (size_t)split * p.d_ff * FD;
+    const int hrow = htile * 16 + 4 * q;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[jt][e];
+        *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
+            make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float bs = accB4[e];
+        bs += __shfl_xor(bs, 1, 64); bs += __shfl_xor(bs, 2, 64); bs += __shfl_xor(bs, 4, 64); bs += __shfl_xor(bs, 8, 64);
+        accB4[e] = bs;
+    }
+    if (r == 0) *reinterpret_cast<float4*>(p.slab_b1 + (size_t)split * p.d_ff + htile * 16 + 4 * q) = make_float4(accB4[0], accB4[1], accB4[2], accB4[3]);
+}
+
 // Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised. The same launch can
 // carry the reduction of the per-clip partial rows (blocks >= slab_blocks; see reduce_partials_kernel).
 struct SlabReduce3 { const float* slab[3]; float* out[3]; size_t n[3]; int nslab; };
@@ -554,6 +693,14 @@ static int ffn_dw_occ(bool stored, bool bf16) {
     if (!stored) return 2;
     return env ? env : (bf16 ? 2 : 3);
 }
+// EGX_FFN_DW_RING=0: bf16 runs keep fp32 x1 / g2 hand-overs and ffn_dw_stored_kernel<CM_BF16> (tuning aid; read by the
+// encoder when it lays out the buffers, see ffn_dw_bf16_planes())
+static bool ffn_dw_ring() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_FFN_DW_RING"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+bool ffn_dw_bf16_planes() { return ffn_dw_ring(); }
 static int ffn_dw_splits(int nkb, int occ) { return min(nkb, occ == 3 ? 24 : 16); }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
     int nkb = (N + 31) / 32;
@@ -574,7 +721,16 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     }
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
-    if (p.hs) {
+    if (p.hs && CM == CM_BF16 && p.xg_planes && ffn_dw_ring()) {
+        const int ring_bytes = 3 * (2 * 32 * 256 + 4 * 4 * 512);
+        static bool attr3_set = false;
+        if (!attr3_set) {
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes));
+            attr3_set = true;
+        }
+        hipLaunchKernelGGL(ffn_dw_bf16_ring_kernel, grid, dim3(256), ring_bytes, st, p);
+    } else if (p.hs) {
+        EGX_CHECK(!p.xg_planes || CM == CM_SPLIT, "ffn_dw: bf16 operand planes are read by the LDS-ring kernel only (unset EGX_FFN_DW_RING)");
         EGX_CHECK(CM != CM_SPLIT || p.xg_planes, "ffn_dw: the split-mode stored-operand kernel reads pre-split x1 / g planes");
         const int occ = CM == CM_SPLIT ? 2 : ffn_dw_occ(true, CM == CM_BF16);
         if (CM == CM_SPLIT) lds = (size_t)2 * 3 * 32 * 144 * sizeof(unsigned short);
@@ -990,7 +1146,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(B2 + row * LDX + c0, dx);
             });
         __syncthreads();
-        if (!(CM == CM_SPLIT && p.xg_planes)) store_block(w.g2_out + tok0 * FD, B2, S);
+        if (CM == CM_BF16 && p.xg_planes) store_block_bf16(reinterpret_cast<unsigned short*>(w.g2_out) + (size_t)clip * FUSED_TOK_PAD * FD, B2, S);
+        else if (!(CM == CM_SPLIT && p.xg_planes)) store_block(w.g2_out + tok0 * FD, B2, S);
         BSTAMP(1);
         // P3: column sums (norm2_w, norm2_b, lin2_b partials); res1 -> B4 and LayerNorm1 forward in place (x1)
         if (tid < 128) {
@@ -1001,8 +1158,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
         load_block(B5, sv_res1);        // stays in B5 until LayerNorm1 backward (P5): one global read of res1 per layer
         __syncthreads();
-        // x1 is only an operand of the weight-gradient kernel; in split mode the forward has saved it, as bf16 parts
-        if (!(CM == CM_SPLIT && p.xg_planes)) {
+        // x1 is only an operand of the weight-gradient kernel; in split / bf16 mode the forward has saved it, as bf16 planes
+        if (!(CM != CM_F32 && p.xg_planes)) {
             ln_rows(B5, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 store32(w.x1_out + (tok0 + row) * FD + c0, y);
             });

@@ -363,6 +363,21 @@ __device__ __forceinline__ void store_block(float* dst, const float* lds_src, in
     }
 }
 
+// rows [0, 48) of a token-major fp32 LDS block -> one dense bf16 plane [48][128] in HBM (rows >= S as zeros): the x1 / g2
+// operand images of the bf16 weight-gradient kernel, 16 bytes per lane in lane order
+__device__ __forceinline__ void store_block_bf16(unsigned short* dst, const float* lds_src, int S) {
+    for (int i = threadIdx.x; i < 48 * (FD / 8); i += 256) {
+        int row = i >> 4, c8 = i & 15;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < S) {
+            float4 a = *reinterpret_cast<const float4*>(lds_src + row * LDX + c8 * 8);
+            float4 b = *reinterpret_cast<const float4*>(lds_src + row * LDX + c8 * 8 + 4);
+            v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+        }
+        *reinterpret_cast<uint4*>(dst + (size_t)i * 8) = v;
+    }
+}
+
 __device__ __forceinline__ void load32(const float* src, float (&v)[32]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
