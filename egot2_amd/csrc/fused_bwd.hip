@@ -701,7 +701,12 @@ static bool ffn_dw_ring() {
     return v == 1;
 }
 bool ffn_dw_bf16_planes() { return ffn_dw_ring(); }
-static int ffn_dw_splits(int nkb, int occ) { return min(nkb, occ == 3 ? 24 : 16); }
+static int ffn_dw_splits(int nkb, int occ) {
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("EGX_FFN_DW_SPLITS"); env = e ? atoi(e) : 0; }     // tuning aid
+    if (env > 0) return min(nkb, min(env, 24));
+    return min(nkb, occ == 3 ? 24 : 16);
+}
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
     int nkb = (N + 31) / 32;
     int splits = min(nkb, 24);           // sized for the largest split count any variant uses
