@@ -193,6 +193,7 @@ struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], x_in[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes;
+    size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
     int P;
 };
 static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segment* segs, const Plan& pl, int head_n_out = 0) {
@@ -215,6 +216,8 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     slab = size_max(slab, (size_t)(512 + SMALL_DW_MAX * 16) * 64 * 128 * sizeof(float));   // deterministic small_dw: one tile per workgroup
     s.slab_bytes = slab;
     s.slabs = take(cur, slab);
+    s.ffn_slab[0] = s.slabs;
+    for (int l = 1; l < pl.L && l < FUSED_MAX_LAYERS; ++l) s.ffn_slab[l] = take(cur, ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr));
     s.dhid = take(cur, fused_hid_total(cfg, pl));
     s.bytes = cur;
     return s;
@@ -655,6 +658,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             // the partial-row reduction rides in the slab-reduction launch of the first FFN weight gradient
             bool rp_pending = stage != 2;
             void* slab = (char*)scratch + SC.slabs;
+            SlabReduce red;
+            red.narr = 0; red.nslab = 0;
             for (int l = 0; l < pl.L && stage != 2; ++l) {
                 const egx_layer& w = layers[l];
                 const egx_layer_grads& gw = layer_grads[l];
@@ -674,9 +679,13 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                         fp.xg_planes = bp.xg_planes;
                         if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * B * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
                     }
-                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, slab, st, rp_pending ? &rp : nullptr, cfg->deterministic != 0)) return 1;
-                    rp_pending = false;
+                    // every layer's slabs (and the partial rows) are summed by ONE launch behind the last layer's kernel
+                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, (char*)scratch + SC.ffn_slab[l], st, nullptr, cfg->deterministic != 0, &red)) return 1;
                 }
+            }
+            if (red.narr) {
+                if (ffn_dw_reduce(red, rp_pending ? &rp : nullptr, cfg->deterministic != 0, st)) return 1;
+                rp_pending = false;
             }
             if (rp_pending && reduce_partials(rp, st, cfg->deterministic != 0)) return 1;
             // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches

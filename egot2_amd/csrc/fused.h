@@ -96,9 +96,15 @@ static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
 bool ffn_dw_bf16_planes();   // bf16 mode hands x1 / g2 over as bf16 planes (the LDS-ring weight-gradient kernel)
 struct ReducePartialsParams;
-// `rp` (optional): per-clip partial sums to reduce in the same launch as the slab reduction
+// out[k][i] += sum_z slab[k][z * n[k] + i] for up to SLAB_REDUCE_MAX arrays (three per layer: dW1, dW2^T, db1) in ONE launch
+constexpr int SLAB_REDUCE_MAX = 3 * FUSED_MAX_LAYERS;
+struct SlabReduce { const float* slab[SLAB_REDUCE_MAX]; float* out[SLAB_REDUCE_MAX]; size_t n[SLAB_REDUCE_MAX]; int nslab, narr; };
+// `rp` (optional): per-clip partial sums to reduce in the same launch as the slab reduction.
+// `defer` (optional): the slab reduction is not launched; its arrays are appended to *defer and ffn_dw_reduce() sums the
+// slabs of every layer (each layer then needs its own `slabs`) and `rp` in one launch.
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
-           const ReducePartialsParams* rp = nullptr, bool deterministic = false);
+           const ReducePartialsParams* rp = nullptr, bool deterministic = false, SlabReduce* defer = nullptr);
+int ffn_dw_reduce(const SlabReduce& a, const ReducePartialsParams* rp, bool deterministic, hipStream_t st);
 
 struct FusedBwdLayer {
     const void* in_proj_wp;    // packed W_in   (R = 384, K = 128): QKV recompute

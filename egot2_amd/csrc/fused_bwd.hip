@@ -631,11 +631,9 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
 
 // Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised. The same launch can
 // carry the reduction of the per-clip partial rows (blocks >= slab_blocks; see reduce_partials_kernel).
-struct SlabReduce3 { const float* slab[3]; float* out[3]; size_t n[3]; int nslab; };
-__device__ __forceinline__ void reduce_slabs_block(const SlabReduce3& a, unsigned block) {
+__device__ __forceinline__ void reduce_slabs_block(const SlabReduce& a, unsigned block) {
     size_t i = ((size_t)block * 256 + threadIdx.x) * 4;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < a.narr; ++k) {
         if (i < a.n[k]) {
             float4 s = *reinterpret_cast<const float4*>(a.out[k] + i);
             int z = 0;
@@ -676,8 +674,8 @@ __device__ __forceinline__ void reduce_partials_block(const ReducePartialsParams
         if (dst) atomicAdd(dst, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     }
 }
-__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce3 a) { reduce_slabs_block(a, blockIdx.x); }
-__global__ __launch_bounds__(256) void reduce_tail_kernel(SlabReduce3 a, ReducePartialsParams rp, unsigned slab_blocks, int chunks) {
+__global__ __launch_bounds__(256) void reduce_slabs_add_kernel(SlabReduce a) { reduce_slabs_block(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void reduce_tail_kernel(SlabReduce a, ReducePartialsParams rp, unsigned slab_blocks, int chunks) {
     // the partial-row blocks go first: they are chains of dependent loads and atomics that then run under the slab streams
     const unsigned part_blocks = gridDim.x - slab_blocks;
     if (blockIdx.x >= part_blocks) { reduce_slabs_block(a, blockIdx.x - part_blocks); return; }
@@ -761,7 +759,7 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
 
 // dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H with H, dH recomputed. `slabs` holds ffn_dw_scratch_bytes().
 int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void* slabs, hipStream_t st,
-           const ReducePartialsParams* rp, bool deterministic) {
+           const ReducePartialsParams* rp, bool deterministic, SlabReduce* defer) {
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
     EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
     int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
@@ -775,22 +773,32 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     p.slab_b1 = p.slab_w2t + (size_t)splits * p.d_ff * FD;
     int rc = compute == CM_BF16 ? launch_ffn_dw<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_ffn_dw<CM_SPLIT>(p, st) : launch_ffn_dw<CM_F32>(p, st);
     if (rc) return rc;
-    SlabReduce3 a;
-    a.slab[0] = p.slab_w1; a.out[0] = dW1; a.n[0] = (size_t)p.d_ff * FD;
-    a.slab[1] = p.slab_w2t; a.out[1] = dW2; a.n[1] = (size_t)p.d_ff * FD;
-    a.slab[2] = p.slab_b1; a.out[2] = db1; a.n[2] = (size_t)p.d_ff;
+    SlabReduce local;
+    local.narr = 0; local.nslab = splits;
+    SlabReduce& a = defer ? *defer : local;
+    EGX_CHECK(a.narr + 3 <= SLAB_REDUCE_MAX && (a.narr == 0 || a.nslab == splits), "ffn_dw: deferred slab reductions must share the split count");
     a.nslab = splits;
+    const float* sl[3] = {p.slab_w1, p.slab_w2t, p.slab_b1};
+    float* out[3] = {dW1, dW2, db1};
+    const size_t nn[3] = {(size_t)p.d_ff * FD, (size_t)p.d_ff * FD, (size_t)p.d_ff};
     for (int k = 0; k < 3; ++k) {
-        EGX_CHECK(!a.out[k] || (((uintptr_t)a.out[k]) & 15) == 0, "ffn_dw: gradient buffers must be 16-byte aligned");
-        if (!a.out[k]) a.n[k] = 0;
+        EGX_CHECK(!out[k] || (((uintptr_t)out[k]) & 15) == 0, "ffn_dw: gradient buffers must be 16-byte aligned");
+        if (!out[k]) continue;
+        a.slab[a.narr] = sl[k]; a.out[a.narr] = out[k]; a.n[a.narr] = nn[k]; ++a.narr;
     }
-    size_t total = a.n[0] + a.n[1] + a.n[2];
+    if (defer) return 0;
+    return ffn_dw_reduce(a, rp, deterministic, st);
+}
+
+int ffn_dw_reduce(const SlabReduce& a, const ReducePartialsParams* rp, bool deterministic, hipStream_t st) {
+    size_t total = 0;
+    for (int k = 0; k < a.narr; ++k) total += a.n[k];
     unsigned slab_blocks = (unsigned)((total / 4 + 255) / 256);
     if (rp) {
         // deterministic: ONE workgroup per 64 partial columns walks all clips (a single adder per gradient element)
         int chunks = deterministic ? 1 : partial_chunks(rp->B);
         hipLaunchKernelGGL(reduce_tail_kernel, dim3(slab_blocks + (unsigned)(cdiv(rp->P, 64) * chunks)), dim3(256), 0, st, a, *rp, slab_blocks, chunks);
-    } else {
+    } else if (slab_blocks) {
         hipLaunchKernelGGL(reduce_slabs_add_kernel, dim3(slab_blocks), dim3(256), 0, st, a);
     }
     EGX_LAUNCH_CHECK();
