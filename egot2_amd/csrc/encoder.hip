@@ -223,6 +223,12 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     return s;
 }
 
+// EGX_REDUCE_RIDES=0: the slab / partial-row reductions keep their own launch (tuning aid)
+static bool reduce_rides() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_REDUCE_RIDES"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
 static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan& pl, bool* err) {
     *err = false;
     bool ok = fused_ok(cfg, segs, pl);
@@ -683,17 +689,30 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, (char*)scratch + SC.ffn_slab[l], st, nullptr, cfg->deterministic != 0, &red)) return 1;
                 }
             }
-            if (red.narr) {
+            // One-stage backward outside the deterministic mode: the reductions ride in the grouped small-gradient launch below
+            // (its workgroups each sum 1 / grid of the slabs and partial rows first). Otherwise (two-stage backward: the late
+            // region must be complete when the exchange starts; deterministic: fixed single-adder order) they get their own launch.
+            bool any_small = false;
+            for (int l = 0; l < pl.L; ++l) any_small = any_small || layer_grads[l].out_proj_w || layer_grads[l].in_proj_w;
+            for (int i = 0; i < pl.nseg && seg_grads; ++i) any_small = any_small || seg_grads[i].proj_w;
+            SmallDwTail tail;
+            const bool ride = stage == 0 && !cfg->deterministic && any_small && (red.narr || rp_pending) && reduce_rides();
+            if (ride) {
+                small_dw_tail_init(tail, red, rp_pending ? &rp : nullptr);
+                rp_pending = false;
+            } else if (red.narr) {
                 if (ffn_dw_reduce(red, rp_pending ? &rp : nullptr, cfg->deterministic != 0, st)) return 1;
                 rp_pending = false;
             }
             if (rp_pending && reduce_partials(rp, st, cfg->deterministic != 0)) return 1;
+            bool tail_pending = ride;
             // every remaining weight gradient (dW_o, dW_in per layer, dW_proj per segment) in grouped launches
             if (stage != 1) {
                 SmallDwParams sp;
                 memset(&sp, 0, sizeof(sp));
                 auto flush = [&]() -> int {
-                    int rc = sp.n ? small_dw(sp, comp, st, cfg->deterministic ? slab : nullptr, SC.slab_bytes) : 0;
+                    int rc = sp.n ? small_dw(sp, comp, st, cfg->deterministic ? slab : nullptr, SC.slab_bytes, tail_pending ? &tail : nullptr) : 0;
+                    if (sp.n) tail_pending = false;
                     memset(&sp, 0, sizeof(sp));
                     return rc;
                 };

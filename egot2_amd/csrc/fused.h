@@ -164,7 +164,10 @@ struct SmallDwParams {
     float* slabs;         // deterministic mode: one dense [64][128] fp32 tile per workgroup, summed in split order afterwards
 };
 // slabs / slab_bytes: optional scratch for the deterministic (atomic-free) variant; null = atomic accumulation
-int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullptr, size_t slab_bytes = 0);
+struct SmallDwTail;
+// `tail` (optional): the FFN slab reduction and the partial-row reduction, done by this launch's workgroups before their own
+// work (each takes 1 / grid of the units) instead of by a launch of their own
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullptr, size_t slab_bytes = 0, const SmallDwTail* tail = nullptr);
 int seed_advance(uint64_t* seed, hipStream_t st);
 
 struct PartialDst { float* dst; int off, len; };
@@ -175,6 +178,8 @@ struct ReducePartialsParams {
     const float* partials;
 };
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool deterministic = false);
+struct SmallDwTail { SlabReduce red; ReducePartialsParams rp; unsigned slab_blocks; int rp_units, chunks; };
+void small_dw_tail_init(SmallDwTail& t, const SlabReduce& red, const ReducePartialsParams* rp);
 
 // Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.
 enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_FFN_FWD = 3, TIMER_FFN_BWD = 4, TIMER_WIDE_GEMM = 5,

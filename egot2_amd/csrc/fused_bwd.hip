@@ -10,6 +10,7 @@
 // Same operand convention as the forward (fused_dev.h). Reference math: autograd of
 // torch.nn.TransformerEncoderLayer as built at HHI/models/ttm/model_taskspecific.py:212-215.
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "common.h"
 #include "kernels.h"
@@ -790,6 +791,16 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     return ffn_dw_reduce(a, rp, deterministic, st);
 }
 
+void small_dw_tail_init(SmallDwTail& t, const SlabReduce& red, const ReducePartialsParams* rp) {
+    memset(&t, 0, sizeof(t));
+    t.red = red;
+    size_t total = 0;
+    for (int k = 0; k < red.narr; ++k) total += red.n[k];
+    t.slab_blocks = (unsigned)((total / 4 + 255) / 256);
+    t.chunks = 1;
+    if (rp) { t.rp = *rp; t.chunks = partial_chunks(rp->B); t.rp_units = cdiv(rp->P, 64) * t.chunks; }
+}
+
 int ffn_dw_reduce(const SlabReduce& a, const ReducePartialsParams* rp, bool deterministic, hipStream_t st) {
     size_t total = 0;
     for (int k = 0; k < a.narr; ++k) total += a.n[k];
@@ -819,10 +830,20 @@ int seed_advance(uint64_t* seed, hipStream_t st) {
 // G[32][64] and X[32][128] in LDS (coalesced, next block prefetched in registers); wave w owns rows 16w..16w+15 and
 // gathers its A fragment (and the 8 B fragments) transposed from the token-major tiles. Partials are atomically
 // added into the zero-initialised gradient buffers (<= `splits` adders per element).
-template <int CM>
-__global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p) {
+template <int CM, bool TAIL>
+__global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwTail tl) {
     constexpr int LDG = 64 + 4, LDXS = 128 + 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LDG + 32 * LDXS)];
+    if constexpr (TAIL) {
+        // The FFN weight-gradient slabs and the per-clip partial rows are summed here, 1 / grid of the units per workgroup, before
+        // the workgroup's own GEMM work: the reduction launch of its own cost 14 us of mostly exposed latency. (As EXTRA
+        // workgroups of this launch the same units were limited to three per CU by its LDS footprint: +60 us.)
+        for (unsigned u = blockIdx.x; u < tl.slab_blocks; u += gridDim.x) reduce_slabs_block(tl.red, u);
+        for (int u = blockIdx.x; u < tl.rp_units; u += gridDim.x) {
+            reduce_partials_block(tl.rp, u / tl.chunks, u % tl.chunks, tl.chunks);
+            __syncthreads();
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     int pi = 0;
@@ -970,7 +991,7 @@ __global__ __launch_bounds__(256) void small_dw_reduce_kernel(SmallDwParams p) {
     }
 }
 
-int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t slab_bytes) {
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t slab_bytes, const SmallDwTail* tail) {
     int items[SMALL_DW_MAX], nkb[SMALL_DW_MAX], total_items = 0;
     for (int i = 0; i < p.n; ++i) {
         EGX_CHECK(p.pr[i].R % 4 == 0 && p.pr[i].C % 4 == 0 && p.pr[i].ldg % 4 == 0 && p.pr[i].ldx % 4 == 0,
@@ -1002,9 +1023,17 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t 
                   (size_t)blocks * 64 * 128 * sizeof(float), slab_bytes);
         p.slabs = (float*)slabs;
     }
-    if (compute == CM_BF16) hipLaunchKernelGGL(small_dw_kernel<CM_BF16>, dim3(blocks), dim3(256), 0, st, p);
-    else if (compute == CM_SPLIT) hipLaunchKernelGGL(small_dw_kernel<CM_SPLIT>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(small_dw_kernel<CM_F32>, dim3(blocks), dim3(256), 0, st, p);
+    if (tail) {
+        EGX_CHECK(!p.slabs, "small_dw: the reduction tail rides only in the atomic (non-deterministic) variant");
+        if (compute == CM_BF16) hipLaunchKernelGGL((small_dw_kernel<CM_BF16, true>), dim3(blocks), dim3(256), 0, st, p, *tail);
+        else if (compute == CM_SPLIT) hipLaunchKernelGGL((small_dw_kernel<CM_SPLIT, true>), dim3(blocks), dim3(256), 0, st, p, *tail);
+        else hipLaunchKernelGGL((small_dw_kernel<CM_F32, true>), dim3(blocks), dim3(256), 0, st, p, *tail);
+    } else {
+        static SmallDwTail none;
+        if (compute == CM_BF16) hipLaunchKernelGGL((small_dw_kernel<CM_BF16, false>), dim3(blocks), dim3(256), 0, st, p, none);
+        else if (compute == CM_SPLIT) hipLaunchKernelGGL((small_dw_kernel<CM_SPLIT, false>), dim3(blocks), dim3(256), 0, st, p, none);
+        else hipLaunchKernelGGL((small_dw_kernel<CM_F32, false>), dim3(blocks), dim3(256), 0, st, p, none);
+    }
     if (p.slabs) hipLaunchKernelGGL(small_dw_reduce_kernel, dim3(total_items * 8), dim3(256), 0, st, p);
     EGX_LAUNCH_CHECK();
     return 0;
