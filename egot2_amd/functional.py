@@ -200,6 +200,9 @@ class EncoderFn(torch.autograd.Function):
         for i, (ss, f) in enumerate(zip(spec.segments, feats)):
             if f.dim() != 3 or f.shape[0] != B or f.shape[1] != ss.T * max(ss.pool, 1) or f.shape[2] != ss.d_in:
                 raise _lib.EgxError(f"feats[{i}] has shape {tuple(f.shape)}, expected ({B}, {ss.T * max(ss.pool, 1)}, {ss.d_in})")
+            if not ss.has_proj and (f.dtype == torch.bfloat16 or ss.pool > 1):
+                raise _lib.EgxError(f"feats[{i}]: bf16 / frame-pooled features need a projection (an identity segment enters "
+                                    "the shared LayerNorm as fp32 rows)")
             segs[i].feat = ptr(f)
             segs[i].T = ss.T
             segs[i].d_in = ss.d_in

@@ -169,7 +169,8 @@ class TaskFusionMFTransformerLTA4Task(_LTATranslator):
         """Feature hand-off without the pooled intermediate: frames_pnr / frames_oscc are the PNR /
         OSCC backbones' per-FRAME `middle=True` features of all clips, (B, n * frames_per_clip, 8192) in fp32 or bf16; the
         temporal mean of encode_clips_pnr (`.mean(dim=1)`) is taken on the way into the projection GEMM's bf16 operand
-        (wide bf16 path). action (B, n, d) and lta (B, n, 2048) as in forward_features (fp32 or bf16)."""
+        (wide bf16 path). lta (B, n, 2048) as in forward_features (fp32 or bf16); action (B, n, d) must be fp32: it has no
+        projection, so it enters the shared LayerNorm as it is (a packed identity segment is refused by the library)."""
         return self._translate([frames_pnr, frames_oscc, feat_action, feat_lta],
                                [self.proj_pnr, self.proj_oscc, None, self.proj_lta], pools=[frames_per_clip, frames_per_clip, 1, 1])
 

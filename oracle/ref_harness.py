@@ -200,33 +200,35 @@ def hoi_cfg(d=256, heads=8, layers=2, n_clips=4, num_classes=(5, 7), z=3, dropou
               CHECKPOINT_FILE_PATH_AR=None, CHECKPOINT_FILE_PATH_LTA=None)
 
 
+class _SecondT(nn.Module):
+    """ForecastingEncoderDecoder stand-in for the LTA 4-task model: `lta_model(x_lta, None, middle=True)` returns the
+    SECOND pathway tensor (B, n, 2048) as (n, B, 2048) (indexing only) — the reference transposes it back."""
+
+    def forward(self, x, *a, **k):
+        return x[1].transpose(0, 1)
+
+
 def ref_lta4(cfg) -> nn.Module:
     """Real reference TaskFusionMFTransformerLTA4Task (HOI/models/lta/lta_models_lta_transfer.py:257): constructors of
-    the four frozen backbones and their checkpoint loaders are patched out; __init__ / forward arithmetic is the
-    reference's. Feed features through forward_features-like call `ref_lta4_forward`."""
+    the four frozen backbones and their checkpoint loaders are patched out; __init__ AND forward(x_lta, x_pnr)
+    (:354-363, incl. encode_clips / encode_clips_pnr with its `.mean(dim=1)` over frames) are the reference's.
+    Call it as `model([action (B, n, d), lta (B, n, 2048)], frames (B, n, F, 8192))`: the PNR stand-in hands back the
+    clip's frames, the OSCC stand-in the same frames reversed along the channel axis (the reference feeds both
+    backbones the same x_pnr), the SlowFast stand-in the first pathway's clip, the LTA stand-in the second pathway."""
     use_tree("HOI")
     _install_hoi_stubs()
     import models.lta.lta_models_lta_transfer as m
     from types import SimpleNamespace as NS
     m.load_pnr_config = lambda path: NS(MISC=NS(CHECKPOINT_FILE_PATH=None), MODEL=NS(NO_TEMP_POOL=False))
     m.KeyframeLocalizationResNet = lambda cfg: _FeatPass()
-    m.StateChangeClsResNet = lambda cfg: _FeatPass()
+    m.StateChangeClsResNet = lambda cfg: _Flip()
     m.SlowFast = lambda cfg, with_head=True: _FeatPass()
-    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _FeatPass()
+    m.ForecastingEncoderDecoder = lambda cfg, build_decoder=True: _SecondT()
     m.load_ckpt = lambda *a, **k: None
     m.load_lta_backbone = lambda *a, **k: None
     m.freeze_params = lambda *a, **k: None
     m.freeze_backbone_params = lambda *a, **k: None
     return m.TaskFusionMFTransformerLTA4Task(cfg)
-
-
-def ref_lta4_forward(model, feat_pnr, feat_oscc, feat_action, feat_lta):
-    """The reference forward() after its backbone calls (lta_models_lta_transfer.py:355-363), on features:
-    pnr/oscc (B, n, 8192), action (B, n, d), lta (B, n, 2048)."""
-    f = torch.cat((model.proj_pnr(feat_pnr), model.proj_oscc(feat_oscc), feat_action, model.proj_lta(feat_lta)), dim=1)
-    f = model.ln(f) + model.pe
-    out = model.transformer(f).mean(dim=1)
-    return model.decode(out)
 
 
 # ---- HOI EgoT2-s: PNR/OSCC translator and the two action-recognition translators (SURVEY.md §8f row F3) -------------

@@ -29,7 +29,8 @@ HHI_CASES = [
     dict(name="hhig_B2_T15_L3_d256", kind="hhig", n_tasks=3, B=2, T=15, L=3, d=256, h=4, wseed=51, fseed=52),
 ]
 HOI_CASES = [
-    dict(name="lta4_B3_n4_L2_d256", kind="lta4", B=3, n=4, L=2, d=256, h=8, classes=[5, 7], z=3, wseed=61, fseed=62),
+    # REAL forward(x_lta, x_pnr): F per-frame PNR features per clip, averaged by the reference's encode_clips_pnr
+    dict(name="lta4_B3_n4_L2_d256", kind="lta4", B=3, n=4, F=3, L=2, d=256, h=8, classes=[5, 7], z=3, wseed=61, fseed=62),
     # HOI EgoT2-s (row F3): real recipes ts_pnr.yaml (d=128, 8 heads -> head dim 16, d_ff = 2d) and ts_ar.yaml
     dict(name="pnr3_B2_L2_d128", kind="pnr3", B=2, L=2, d=128, h=8, task="state_change_detection", wseed=71, fseed=72),
     dict(name="pnr3kf_B2_L1_d256", kind="pnr3", B=2, L=1, d=256, h=8, task="keyframe_localization", wseed=73, fseed=74),
@@ -119,7 +120,7 @@ def run_hhi():
 def hoi_feat_shapes(c):
     B = c["B"]
     if c["kind"] == "lta4":
-        return [(B, c["n"], 8192), (B, c["n"], 8192), (B, c["n"], c["d"]), (B, c["n"], 2048)]
+        return [(B, c["n"], c["F"], 8192), (B, c["n"], c["d"]), (B, c["n"], 2048)]      # PNR frames, action, lta
     if c["kind"] == "pnr3":
         return [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)]           # pnr, oscc, slow, fast
     if c["kind"] == "ar3":
@@ -190,7 +191,7 @@ def run_hoi():
                 enc = named[f"out_{task}"]
                 named[f"dec_{task}"] = m.decode(g_targets(c, task, enc.shape[1], len(m.vocab), sy), enc)
         elif c["kind"] == "lta4":
-            outs = rh.ref_lta4_forward(m, *feats)
+            outs = m([feats[1], feats[2]], feats[0])      # REAL forward(x_lta, x_pnr)
             named = {"out_verb": outs[0], "out_noun": outs[1]}
         elif c["kind"] == "pnr3":       # the REAL forward(x1, x2) over pass-through backbones
             named = {"out": m([feats[0], feats[1]], [rh.pathway5d(feats[2]), rh.pathway5d(feats[3])])}

@@ -69,8 +69,13 @@ def test_cpu_tensors_raise_not_fallback(egx_lib):
         model.forward_features(*seeded_feats(1, [(2, 15, 256)] * 3))
 
 
-def test_registry_and_constructor_protocol():
+def test_registry_and_constructor_protocol(monkeypatch):
     """HHI/models/ttm/build.py:17-20 semantics and the reference's backbone/freeze quirk."""
+    # order-independent: other test modules put the reference HHI tree on sys.path (then `models.lam.model` resolves to
+    # the real LAMBackbone and the checkpoint open fails instead); a None entry makes the import fail as it does on a
+    # box without the reference tree.
+    for name in ("models", "models.lam", "models.lam.model", "models.ttm", "models.ttm.model"):
+        monkeypatch.setitem(sys.modules, name, None)
     from argparse import Namespace
     from egot2_amd import hhi_asd, hhi_ttm
     from tests.util import hhi_args

@@ -270,6 +270,65 @@ def test_feature_handoff_bf16_and_frame_pooling(egx_lib, cuda):
         m.forward_features(p16[0], p16[1], act, l16)
 
 
+@pytest.mark.parametrize("frame_dtype", ["f32", "bf16"])
+def test_frame_feature_handoff_against_oracle_and_reference_fixture(egx_lib, cuda, frame_dtype):
+    """Row F4 against the ORACLE and the REFERENCE: per-frame PNR / OSCC features go in through forward_frame_features (the
+    temporal mean of encode_clips_pnr fused into the projection operand cast, HOI/models/lta/lta_models_lta_transfer.py:
+    335-345) and must match (a) the fp64 oracle run on `frames.mean(2)` — outputs 1e-2, every parameter gradient 6e-2 (the
+    bf16 tolerances) — and (b) the lta4 fixture, which the reference's REAL forward(x_lta, x_pnr) produced from the same
+    frames."""
+    from tests.test_oracle_golden import build_ours, check_against_fixture, load_fixture, lta4_frames
+    c, z = load_fixture("lta4_B3_n4_L2_d256")
+    B, n, F = c["B"], c["n"], c["F"]
+    model = build_ours(c)
+    sd = seeded_state_dict(model, c["wseed"])
+    model.load_state_dict(sd)
+    model = model.to(cuda).set_compute("bf16").train()
+    frames, action, lta = lta4_frames(c)
+    fr_pnr = frames.reshape(B, n * F, 8192).to(cuda)
+    fr_oscc = frames.flip(-1).reshape(B, n * F, 8192).contiguous().to(cuda)
+    if frame_dtype == "bf16":
+        fr_pnr, fr_oscc = fr_pnr.bfloat16(), fr_oscc.bfloat16()
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    o = model.forward_frame_features(fr_pnr, fr_oscc, action.to(cuda), lta.to(cuda), frames_per_clip=F)
+    loss = lin(o[0]) + lin(o[1])
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    # (b) the reference's own forward on the same frames
+    check_against_fixture(z, {"out_verb": o[0], "out_noun": o[1]}, loss, grads, 1e-2, 6e-2)
+    # (a) fp64 oracle on the pooled features (what encode_clips_pnr hands to the projections)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    f64 = frames.double()
+    if frame_dtype == "bf16":
+        f64 = frames.bfloat16().double()       # the oracle sees the values the producer actually handed over
+    r = tr.lta4_forward(sd64, c["h"], f64.mean(2), f64.flip(-1).mean(2), action.double(), lta.double(), c["classes"])
+    (lin(r[0]) + lin(r[1])).backward()
+    for a, b in zip(o, r):
+        assert (a.detach().cpu().double() - b.detach()).abs().max().item() < 1e-2 * max(1.0, b.abs().max().item())
+    errs = {k: (g.detach().cpu().double() - sd64[k].grad).norm().item() / (sd64[k].grad.norm().item() + 1e-12)
+            for k, g in grads.items() if sd64[k].grad is not None}
+    assert len(errs) > 20
+    bad = {k: v for k, v in errs.items() if not v < 6e-2}
+    assert not bad, bad
+
+
+def test_packed_identity_segment_is_refused(egx_lib, cuda):
+    """A segment WITHOUT a projection feeds the shared LayerNorm directly in fp32: bf16 or frame-pooled features for it
+    have no cast pass to ride on, and every implementation (wide included) must refuse them instead of reading bf16 bytes
+    as fp32 (the action stream of the LTA translators is such a segment)."""
+    from egot2_amd import _lib, hoi_lta
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(4, 256, 8, 2))
+    m.load_state_dict(seeded_state_dict(m, 5))
+    pnr, oscc, act, lta = [f.to(cuda) for f in seeded_feats(6, [(3, 4, 8192), (3, 4, 8192), (3, 4, 256), (3, 4, 2048)])]
+    for impl in ("auto", "wide"):
+        m = m.to(cuda).set_compute("bf16", impl).train()
+        with pytest.raises(_lib.EgxError, match="need a projection"):
+            m.forward_features(pnr, oscc, act.bfloat16(), lta)
+        with pytest.raises((_lib.EgxError, AssertionError)):
+            m._translate([pnr, oscc, act.repeat(1, 2, 1), lta], [m.proj_pnr, m.proj_oscc, None, m.proj_lta], pools=[1, 1, 2, 1])
+
+
 @pytest.mark.parametrize("compute,tol_out,tol_grad", [("f32", 1e-3, 1e-2), ("bf16", 1e-2, 6e-2)])
 def test_hoi_egot2g_encoder_real_dimensions(egx_lib, cuda, compute, tol_out, tol_grad):
     """BASELINE.json configs[4], HOI EgoT2-g at its real width: d = 512, 8 heads of 64, 3 layers

@@ -84,11 +84,18 @@ def g_targets(c, task, batch, vocab_size, sy=2):
     return torch.from_numpy(rng.integers(0, vocab_size, (batch, sy))).long()
 
 
+def lta4_frames(c):
+    """The raw inputs of the lta4 fixture: PNR frames (B, n, F, 8192), action (B, n, d), lta (B, n, 2048)."""
+    return seeded_feats(c["fseed"], [(c["B"], c["n"], c["F"], 8192), (c["B"], c["n"], c["d"]), (c["B"], c["n"], 2048)])
+
+
 def fixture_feats(c):
     B = c["B"]
     if c["kind"] == "lta4":
-        n, d = c["n"], c["d"]
-        return seeded_feats(c["fseed"], [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
+        # feature-level view of the reference's forward(x_lta, x_pnr): per-clip mean of the frames (encode_clips_pnr); the
+        # OSCC stream of the fixture is the channel-reversed PNR stream (oracle/ref_harness.py _Flip)
+        frames, action, lta = lta4_frames(c)
+        return [frames.mean(2), frames.flip(-1).mean(2), action, lta]
     if c["kind"] == "pnr3":
         return seeded_feats(c["fseed"], [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)])
     if c["kind"] == "ar3":
