@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: clips/s, forward+backward, 3-task TTM translator (B=256 per GPU, T=15, d=128, h=4, L=1,
 d_ff=2048) on synthetic backbone features — BASELINE.json configs[1]. `--config c1|c3|c4|c5hhi|c5hoi` times the other
-BASELINE configurations the same way (each with its own roofline block); the default line stays configs[1], fp32.
+BASELINE configurations the same way (each with its own roofline block). The default line is configs[1] in "f32s"
+arithmetic (fp32 storage / accumulation / results, every product formed from an exact three-way bf16 split of its fp32
+operands: the top-level "arithmetic" field says so) with the exact-fp32-MFMA step timed beside it as `native_f32`.
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -51,7 +53,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--trials", type=int, default=0, help="timed repetitions of --steps (0 = auto: >= 5 and >= 0.3 s of timed region)")
+    ap.add_argument("--trials", type=int, default=0, help="timed repetitions of --steps (0 = auto: >= 5 and >= --min-seconds of timed region)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="auto trials: total timed GPU work to aim for")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch clips per GPU; strong: --batch clips in total, sharded over the ranks (SURVEY.md 8e)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi"],
                     help="BASELINE.json configuration (default c2 = configs[1], the metric)")
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
@@ -159,8 +164,9 @@ def main(argv=None):
     if args.gpus > 1 and env_world is None:
         return self_launch(args, argv)                  # before ANY torch / HIP call in this process
     if env_world is not None and int(env_world) != args.gpus:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: launch with a matching world size", file=sys.stderr)
-        return 2
+        # launched under torchrun: the environment's world size is the truth (a harness may not repeat --gpus)
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={env_world}: using the environment's world size", file=sys.stderr)
+        args.gpus = int(env_world)
     if args.launch_selftest:
         return launch_selftest(args)
     return run(args)
@@ -196,7 +202,15 @@ def run(args) -> int:
     # fp32 accumulation ("f32s": fp32-grade results, tests/test_gpu_translator.py::test_split_bf16_mode_is_fp32_grade);
     # `--dtype f32` is the exact v_mfma_f32_16x16x4_f32 path, reported beside it as `native_f32`
     run_dtype = args.dtype or ("f32s" if args.config in ("c1", "c2") else None)
-    wl = synth.make_workload(args.config, dev, batch=args.batch, frames=args.frames, layers=args.layers or None,
+    # weak scaling: --batch clips on every GPU. strong scaling ("global B = 256 -> 32 clips / GPU at n = 8"): the
+    # --batch clips are sharded over the ranks, the per-GPU work shrinks with N
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit(f"--scaling strong: --batch {args.batch} is not divisible by {world} ranks")
+        local_batch = args.batch // world
+    else:
+        local_batch = args.batch
+    wl = synth.make_workload(args.config, dev, batch=local_batch, frames=args.frames, layers=args.layers or None,
                              dtype=run_dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
                              feat_dtype=args.feat_dtype, feat_frames=args.feat_frames)
     model, params, B = wl["model"], wl["params"], wl["B"]
@@ -265,8 +279,8 @@ def run(args) -> int:
             step_fn()
         sync()
         est = (time.perf_counter() - t0) / 3 * steps
-        n = max(5, int(0.3 / max(est, 1e-6)) + 1)
-        n = min(n, 200)
+        n = max(5, int(args.min_seconds / max(est, 1e-6)) + 1)
+        n = min(n, 2000)
         if multi:       # every rank must run the same number of trials
             t = torch.tensor([n], device=dev, dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,8 +435,8 @@ def run(args) -> int:
     out = {
         "metric": metric,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": DTYPE_LABEL.get(dtype, dtype), "data": "synthetic",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": DTYPE_LABEL.get(dtype, dtype), "arithmetic": dtype, "data": "synthetic",
         "trials": trials, "ms_per_step_p10": percentile(ms, 0.1), "ms_per_step_p90": percentile(ms, 0.9),
         "ms_per_step_min": min(ms), "timed_seconds": sum(dts),
         "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
@@ -476,22 +490,61 @@ def run(args) -> int:
     return 0
 
 
-def pmc_traffic(dtype, B, T, L, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.sh: FETCH_SIZE and
-    WRITE_SIZE in separate runs, KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes). PMC
-    collection needs the profiler, so the number is read from profiles/ (a builder-side measurement) and only when it
-    was taken on this workload."""
+def csrc_sha():
+    """sha256 over the kernel sources (egot2_amd/csrc/*.hip, *.h and include/egot2x.h): committed counter files carry it, and
+    the bench line drops their numbers when the kernels have changed since they were taken."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(here, "egot2_amd", "csrc", "*.hip")) + glob.glob(os.path.join(here, "egot2_amd", "csrc", "*.h")))
+    for f in files + [os.path.join(here, "include", "egot2x.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(config, dtype, B, T, L, encoder_only=False):
+    """Per-kernel hardware counters of this workload from the newest matching profiles/r*_pmc_*.json (tools/pmc_collect.py:
+    rocprofv3 --pmc passes, FETCH_SIZE / WRITE_SIZE separately, KiB units, FETCH_SIZE doubled for gfx950 as
+    MI355X_MICROARCH.md prescribes). PMC collection needs the profiler, so the numbers are a builder-side measurement read
+    from profiles/ — used only when the file was taken on THIS workload and on THESE kernel sources (csrc_sha); otherwise
+    (None, reason)."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_{dtype}.json")), reverse=True):
+    sha = csrc_sha()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_*.json")), reverse=True):
         try:
             d = json.load(open(f))
             w = d.get("workload", {})
-            if (w.get("batch"), w.get("frames"), w.get("layers")) == (B, T, L) and kernel in d["kernels"]:
-                return d["kernels"][kernel]["traffic_bytes"], os.path.relpath(f, here)
+            if (w.get("config"), w.get("batch"), w.get("frames"), w.get("layers") or 0, bool(w.get("encoder_only"))) != (config, B, T, L or 0, bool(encoder_only)):
+                continue
+            if (w.get("dtype") or dtype) != dtype or "kernels" not in d:
+                continue
+            if d.get("csrc_sha") != sha:
+                stale = stale or f"{os.path.relpath(f, here)} was taken on other kernel sources (csrc_sha {d.get('csrc_sha')} != {sha}): dropped"
+                continue
+            return d, os.path.relpath(f, here)
         except (OSError, ValueError, KeyError):
             continue
-    return None, None
+    return None, stale
+
+
+def counter_fields(cnt, kernel, avg_launch_us):
+    """traffic / hbm_gbps / mfma_busy of one kernel from a committed counter file (None where not collected)."""
+    k = (cnt or {}).get("kernels", {}).get(kernel) or {}
+    traffic = k.get("traffic_bytes")
+    out = {"traffic": traffic,
+           "hbm_gbps": (traffic / (avg_launch_us * 1e-6) / 1e9) if traffic and avg_launch_us else None}
+    if k.get("SQ_BUSY_CYCLES"):
+        # SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+        out["mfma_busy"] = (k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0) / (k["SQ_BUSY_CYCLES"] / 32.0)
+        out["valu_per_mfma"] = k.get("SQ_INSTS_VALU", 0.0) / max(k.get("SQ_INSTS_MFMA", 0.0), 1.0)
+        out["lds_bank_conflict_cycles"] = k.get("SQ_LDS_BANK_CONFLICT")
+    else:
+        out["mfma_busy"] = None
+    return out
 
 
 TIMED_KERNELS = ("fused_fwd_kernel", "fused_bwd_kernel", "ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel",
@@ -543,20 +596,26 @@ def measure_roofline(torch, lib, step, wl, dtype):
         flops["fused_bwd_kernel"] -= ffn
     lib.egx_timing_enable(0)
     peak = PEAK_TFLOPS[dtype]
+    cnt, cnt_src = committed_counters(wl["name"], dtype, wl.get("batch_arg", B), wl.get("frames"), wl.get("layers_arg"), wl.get("encoder_only", False))
     if "fused_bwd_kernel" in res:
         t = res["fused_bwd_kernel"]
         ach = flops["fused_bwd_kernel"] / t / 1e12
-        traffic, traffic_src = pmc_traffic(dtype, B, wl["S"] // max(len(wl["feats"]), 1), L, "egx::fused_bwd_kernel")
         extra = {}
         if dtype == "f32s":
             extra = {"peak_note": "bf16 dense MFMA peak (2500 TFLOP/s) / 6 instructions per algorithmic K-block; the exact fp32 MFMA peak "
                                   "is 157.3 TFLOP/s", "frac_of_native_f32_mfma_peak": ach / PEAK_TFLOPS["f32"]}
+        cf = counter_fields(cnt, "egx::fused_bwd_kernel", t * 1e6)
+        step_traffic = None
+        if cnt:
+            step_traffic = sum(v.get("traffic_bytes", 0.0) * v.get("launches", 0) for k, v in cnt["kernels"].items()
+                               if k.startswith("egx::")) / max(cnt.get("steps_profiled", 1), 1)
         return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": peak,
-                "unit": "TFLOP/s", "frac": ach / peak, **extra, "traffic": traffic, "traffic_unit": "bytes/launch",
-                "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": ach / peak, **extra, **cf, "traffic_unit": "bytes/launch",
+                "counters_source": cnt_src, "hbm_bytes_per_step": step_traffic,
                 "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
                 "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
-                                      "frac": flops[k] / v / 1e12 / peak} for k, v in res.items() if k != "fused_bwd_kernel"}}
+                                      "frac": flops[k] / v / 1e12 / peak, **counter_fields(cnt, "egx::" + k, v * 1e6)}
+                                  for k, v in res.items() if k != "fused_bwd_kernel"}}
     if "wide_gemm_kernel" in res:
         # many launches of different shapes per step: achieved = all GEMM FLOPs of one step / all GEMM time of one step
         t_step = tot_ms["wide_gemm_kernel"] * 1e-3 / reps
@@ -567,8 +626,19 @@ def measure_roofline(torch, lib, step, wl, dtype):
                 ts = tot_ms[k] * 1e-3 / reps
                 others[k] = {"us_per_step": ts * 1e6, "launches_per_step": counts[k] / reps,
                              "achieved_tflops": flops[k] / ts / 1e12, "frac": flops[k] / ts / 1e12 / peak}
+        traffic = mfma_busy = None
+        if cnt:     # the GEMM launches of one step together (NT + TN kernels), per step
+            gk = [v for k, v in cnt["kernels"].items() if k.startswith("egx::wide_gemm")]
+            steps_p = max(cnt.get("steps_profiled", 1), 1)
+            if gk and all("traffic_bytes" in v for v in gk):
+                traffic = sum(v["traffic_bytes"] * v["launches"] for v in gk) / steps_p
+            if gk and all(v.get("SQ_BUSY_CYCLES") for v in gk):
+                mfma_busy = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * v["launches"] for v in gk) / 1024.0 / (
+                    sum(v["SQ_BUSY_CYCLES"] * v["launches"] for v in gk) / 32.0)
         return {"bound": "mfma", "kernel": "egx::wide_gemm_kernel", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None, "flops_per_step": flops["wide_gemm_kernel"],
+                "frac": ach / peak, "traffic": traffic, "traffic_unit": "bytes/step (all GEMM launches of one step)",
+                "hbm_gbps": (traffic / t_step / 1e9) if traffic else None, "mfma_busy": mfma_busy, "counters_source": cnt_src,
+                "flops_per_step": flops["wide_gemm_kernel"],
                 "us_per_step": t_step * 1e6, "launches_per_step": counts["wide_gemm_kernel"] / reps,
                 "avg_launch_us": res["wide_gemm_kernel"] * 1e6, "other_kernels": others}
     return {"bound": "mfma", "kernel": None, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None}

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libegot2x.so")
+# EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
+LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
 EGX_ABI_VERSION = 9
 EGX_MAX_SEGMENTS = 8

@@ -34,9 +34,25 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit for gfx950 and link libegot2x.so. Returns the library path."""
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """Compile every HIP translation unit for gfx950 and link libegot2x.so. Returns the library path.
+    `variant` (development aid): build egot2_amd/_variants/lib_<variant>.so with `extra_flags` added, next to the product
+    library (objects in csrc/_obj/<variant>/); load it with EGX_LIB=<path>."""
+    global FLAGS
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    OBJ_DIR = os.path.join(CSRC, "_obj", variant) if variant else os.path.join(CSRC, "_obj")
+    LIB_PATH = os.path.join(PKG_DIR, "_variants", f"lib_{variant}.so") if variant else os.path.join(PKG_DIR, "libegot2x.so")
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    base_flags = FLAGS
+    if extra_flags:
+        FLAGS = list(extra_flags) + FLAGS
+    try:
+        return _build(srcs, OBJ_DIR, LIB_PATH, force, verbose)
+    finally:
+        FLAGS = base_flags
+
+
+def _build(srcs, OBJ_DIR, LIB_PATH, force, verbose) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     hipcc = _hipcc()
@@ -79,4 +95,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m egot2_amd.build [--force] [--variant NAME -DFLAG ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    extra = [a for a in argv if a.startswith("-D") or a.startswith("-m") or a.startswith("-f")]
+    print(build(force="--force" in argv, verbose=True, variant=variant, extra_flags=extra))

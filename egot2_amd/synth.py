@@ -166,4 +166,5 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
         raise ValueError(f"unknown workload {name!r} (c1, c2, c3, c4, c5hhi, c5hoi)")
     params = [q for q in model.parameters() if q.requires_grad] + list(getattr(model, "extra_params", []))
     return {"name": name, "model": model, "feats": feats, "loss_fn": loss_fn, "params": params, "flops": fl,
-            "describe": desc, "B": B, "S": S, "d": d, "segs": segs, "L": L, "compute": model.egx_compute}
+            "describe": desc, "B": B, "S": S, "d": d, "segs": segs, "L": L, "compute": model.egx_compute,
+            "batch_arg": batch, "frames": frames, "layers_arg": layers or 0, "encoder_only": bool(encoder_only)}

@@ -61,12 +61,27 @@ class StockTTMTranslator(nn.Module):
         return self.linear_head(out)
 
 
-def time_cpu_baseline(B=256, T=15, n_tasks=3, dim=128, n_heads=4, num_layers=1, dropout=0.5, budget_s=15.0,
-                      max_steps=20, threads=None):
-    """fwd + weighted-CE + bwd of the stock module on the host cores; bounded by `budget_s` seconds of work."""
+def _time_steps(step, max_steps, budget_s, warmup):
     import time
-    if threads:
-        torch.set_num_threads(threads)
+    for _ in range(warmup):
+        step()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < max_steps and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], len(ts), time.perf_counter() - t_all
+
+
+def time_cpu_baseline(B=256, T=15, n_tasks=3, dim=128, n_heads=4, num_layers=1, dropout=0.5, budget_s=40.0,
+                      max_steps=20, threads=None, one_thread_steps=3):
+    """fwd + weighted-CE + bwd of the stock module on the host cores (BASELINE.md §3 protocol: all cores, 3 warm-up + 20
+    timed steps, median; bounded by `budget_s` seconds), plus a 1-thread figure from a bounded sample of
+    `one_thread_steps` steps (a full 20-step protocol at one thread takes minutes and would not fit the default bench run)."""
+    all_threads = threads or torch.get_num_threads()
+    torch.set_num_threads(all_threads)
     torch.manual_seed(0)
     m = StockTTMTranslator(n_tasks, dim, n_heads, dropout, num_layers).train()
     g = torch.Generator().manual_seed(1234)
@@ -78,13 +93,16 @@ def time_cpu_baseline(B=256, T=15, n_tasks=3, dim=128, n_heads=4, num_layers=1, 
         m.zero_grad(set_to_none=True)
         crit(m(*feats), y).backward()
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < max_steps and (time.perf_counter() - t0) < budget_s:
-        step()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": B * n / dt, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd steps of the stock torch.nn translator, B={B}, T={T}, K={n_tasks}, d={dim}, "
-                      f"L={num_layers}, dropout={dropout} (+0.1 PE), fp32, {dt:.1f}s"}
+    med, n, dt = _time_steps(step, max_steps, budget_s, warmup=3)
+    desc = (f"stock torch.nn translator, B={B}, T={T}, K={n_tasks}, d={dim}, L={num_layers}, dropout={dropout} (+0.1 PE), fp32")
+    out = {"value": B / med, "unit": "clips/s", "cores": all_threads, "kind": "port",
+           "sample": f"median of {n} fwd+bwd steps after 3 warm-up steps, {desc}, {dt:.1f}s"}
+    if one_thread_steps > 0:
+        torch.set_num_threads(1)
+        try:
+            med1, n1, dt1 = _time_steps(step, one_thread_steps, budget_s, warmup=1)
+        finally:
+            torch.set_num_threads(all_threads)
+        out["one_thread"] = {"value": B / med1, "unit": "clips/s", "cores": 1,
+                             "sample": f"median of {n1} steps after 1 warm-up step (bounded sample), {dt1:.1f}s"}
+    return out

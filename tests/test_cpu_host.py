@@ -220,13 +220,18 @@ def test_bench_self_launches_ranks_gloo():
     assert out["max_rank_seconds"] >= 0.02          # rank 1 sleeps 20 ms: the max over ranks, not rank 0's 10 ms
 
 
-def test_bench_rejects_mismatched_world_size():
-    """--gpus N under a launcher that set a different WORLD_SIZE is an error, not a silently relabelled run."""
+def test_bench_trusts_the_launchers_world_size():
+    """Under a launcher (WORLD_SIZE set) the environment decides the world size: a harness that runs
+    `torchrun --nproc-per-node=N bench.py` without repeating --gpus N must still get its JSON line, labelled with the
+    ranks that actually ran; the mismatch is reported on stderr."""
+    import json
     import subprocess
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-selftest"],
                        capture_output=True, text=True, env=env, timeout=120)
-    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+    assert r.returncode == 0 and "WORLD_SIZE" in r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "dp1"
 
 
 def _ddp_weighted_worker(rank, world, port, q):
