@@ -59,30 +59,41 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 }
 
 // Counter-based dropout RNG: a 64-bit (seed, site) key and a (row, column) element index -> 16 uniform bits.
-// Forward and backward regenerate identical masks; nothing is stored. One 32-bit hash serves the two columns of a
-// pair (2c, 2c+1), so a lane that owns adjacent columns pays one integer-multiply round per two elements (the
-// quarter-rate v_mul_lo_u32 of a full hash per element used to cost more than the FFN epilogue around it).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
+// Forward and backward regenerate identical masks; nothing is stored. ONE hash serves the four columns of a quad
+// (4c .. 4c+3): a multiply-fold round (32 x 32 -> 64, high ^ low: one v_mad_u64_u32) and one multiply-xorshift round give
+// 64 bits = 4 x 16, i.e. half a quarter-rate integer multiply per element (round 2: one 32-bit hash per column pair, one
+// multiply per element — the multiplies were a quarter of the FFN epilogue of the clip kernels). Statistics of the four
+// lanes (uniformity, pairwise / adjacent-row / adjacent-column correlation, joint keep patterns): tools/rng_quality.py.
+__device__ __forceinline__ uint2 rand_quad(uint64_t key, uint32_t row, uint32_t colquad) {
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    uint32_t x = (row * 0x9E3779B1U + k1) ^ (colquad * 0x85EBCA77U + k0);
+    x ^= x >> 16;
+    const uint64_t p = (uint64_t)x * 0x7feb352dU;
+    uint32_t y = (uint32_t)p ^ (uint32_t)(p >> 32);
+    y ^= y >> 15;
+    uint32_t z = y * 0x846ca68bU;
+    z ^= z >> 16;
+    return make_uint2(z, y);        // columns 4c, 4c+1 <- low / high half of z; 4c+2, 4c+3 <- low / high half of y
 }
-__device__ __forceinline__ uint32_t rand_pair(uint64_t key, uint32_t row, uint32_t colpair) {
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-    return mix32((row * 0x9E3779B1U + k1) ^ (colpair * 0x85EBCA77U + k0));
-}
+// keep tests on the 16-bit halves of a hash word without extracting them: the high half by a full-word compare against
+// thresh << 16, the low half by a 16-bit compare. Only for callers whose keep-scale is applied elsewhere and is 0 at p >= 1
+// (thresh = 65536 wraps to "keep everything" here; the scale 1 / (1 - p) := 0 folded into the weights still zeroes the output).
+__device__ __forceinline__ bool keep_hi(uint32_t w, uint32_t thresh) { return w >= (thresh << 16); }
+__device__ __forceinline__ bool keep_lo(uint32_t w, uint32_t thresh) { return (uint16_t)w >= (uint16_t)thresh; }
 // keep-scale for inverted dropout: returns 0 or 1/(1-p). `thresh` is on the 16-bit scale (drop_threshold).
 __device__ __forceinline__ float drop_scale(uint64_t key, uint32_t row, uint32_t col, uint32_t thresh, float inv_keep) {
-    uint32_t h = rand_pair(key, row, col >> 1);
-    uint32_t v = (col & 1u) ? (h >> 16) : (h & 0xffffu);
+    const uint2 h = rand_quad(key, row, col >> 2);
+    const uint32_t w = (col & 2u) ? h.y : h.x;
+    const uint32_t v = (col & 1u) ? (w >> 16) : (w & 0xffffu);
     return v >= thresh ? inv_keep : 0.f;
 }
-// four adjacent columns col0..col0+3 (col0 a multiple of 4) of one row: two hashes
+// four adjacent columns col0..col0+3 (col0 a multiple of 4) of one row: one hash
 __device__ __forceinline__ void drop_scale4(uint64_t key, uint32_t row, uint32_t col0, uint32_t thresh, float inv_keep, float (&out)[4]) {
-    uint32_t h0 = rand_pair(key, row, col0 >> 1), h1 = rand_pair(key, row, (col0 >> 1) + 1);
-    out[0] = (h0 & 0xffffu) >= thresh ? inv_keep : 0.f;
-    out[1] = (h0 >> 16) >= thresh ? inv_keep : 0.f;
-    out[2] = (h1 & 0xffffu) >= thresh ? inv_keep : 0.f;
-    out[3] = (h1 >> 16) >= thresh ? inv_keep : 0.f;
+    const uint2 h = rand_quad(key, row, col0 >> 2);
+    out[0] = (h.x & 0xffffu) >= thresh ? inv_keep : 0.f;
+    out[1] = (h.x >> 16) >= thresh ? inv_keep : 0.f;
+    out[2] = (h.y & 0xffffu) >= thresh ? inv_keep : 0.f;
+    out[3] = (h.y >> 16) >= thresh ? inv_keep : 0.f;
 }
 static inline uint32_t drop_threshold(float p) {
     double t = (double)p * 65536.0;

@@ -161,13 +161,8 @@ static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segmen
     return L;
 }
 // The FFN hidden activation H (forward) and its gradient dH (backward) are handed to the weight-gradient kernel as
-// operand tiles instead of being recomputed there (EGX_FFN_RECOMPUTE=1 restores the recompute variant, which needs no
-// (B, 48, d_ff) tensors in HBM).
-static bool store_hidden() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("EGX_FFN_RECOMPUTE"); v = (e && e[0] == '1') ? 0 : 1; }
-    return v == 1;
-}
+// operand tiles instead of being recomputed there (ffn_dw_kernel, the recompute variant, is kept as the egx_ffn_dw unit hook).
+static bool store_hidden() { return true; }     // (the recompute variant of the clip kernels was dropped in round 3: their FFN loops store unconditionally)
 static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
     return store_hidden() ? align_up((size_t)pl.L * fused_hid_bytes(pl.B, pl.dff, cfg->compute == EGX_BF16), 256) : 0;
 }
@@ -432,11 +427,15 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         pk.mode = comp;
         pk.seed_advance = (cfg->advance_seed && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
         FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
-        auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose) -> const void* {
+        auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose, float scale = 1.f) -> const void* {
             PackDesc& dsc = pk.d[pk.n++];
-            dsc.src = src; dsc.dst = dst; dsc.R = R; dsc.K = K; dsc.ld = ld; dsc.transpose = transpose;
+            dsc.src = src; dsc.dst = dst; dsc.R = R; dsc.K = K; dsc.ld = ld; dsc.transpose = transpose; dsc.scale = scale;
             return dst;
         };
+        // the keep-scale of the FFN hidden dropout rides on the packed W1 (forward: relu(s (W1 x + b1)) = s relu(W1 x + b1)) and
+        // W2^T (backward: dH = alive ? s W2^T g : 0): the FFN epilogues of the clip kernels have no multiply
+        const Drop dffn = make_drop(training, cfg->p_drop, seed, 0, SITE_FFN);
+        const float ffn_scale = dffn.thresh ? dffn.inv_keep : 1.f;
         for (int i = 0; i < pl.nseg; ++i) {
             FusedSeg& fs = fp.seg[i];
             fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, PL.proj[i], d, segs[i].d_in, segs[i].d_in, 0); fs.proj_b = segs[i].proj_b;
@@ -448,13 +447,13 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             const egx_layer& w = layers[l];
             fl.in_proj_wp = add_pack(w.in_proj_w, PL.layer[l].in_w, 3 * d, d, d, 0); fl.in_proj_b = w.in_proj_b;
             fl.out_proj_wp = add_pack(w.out_proj_w, PL.layer[l].out_w, d, d, d, 0); fl.out_proj_b = w.out_proj_b;
-            fl.lin1_wp = add_pack(w.lin1_w, PL.layer[l].lin1_w, pl.dff, d, d, 0); fl.lin1_b = w.lin1_b;
+            fl.lin1_wp = add_pack(w.lin1_w, PL.layer[l].lin1_w, pl.dff, d, d, 0, ffn_scale); fl.lin1_b = w.lin1_b;
             fl.lin2_wp = add_pack(w.lin2_w, PL.layer[l].lin2_w, d, pl.dff, pl.dff, 0); fl.lin2_b = w.lin2_b;
             {   // transposed copies for the backward kernels
                 add_pack(w.in_proj_w, PL.layer[l].in_wt, d, 3 * d, d, 1);
                 add_pack(w.out_proj_w, PL.layer[l].out_wt, d, d, d, 1);
                 add_pack(w.lin1_w, PL.layer[l].lin1_wt, d, pl.dff, d, 1);
-                add_pack(w.lin2_w, PL.layer[l].lin2_wt, pl.dff, d, pl.dff, 1);
+                add_pack(w.lin2_w, PL.layer[l].lin2_wt, pl.dff, d, pl.dff, 1, ffn_scale);
             }
             fl.norm1_w = w.norm1_w; fl.norm1_b = w.norm1_b; fl.norm2_w = w.norm2_w; fl.norm2_b = w.norm2_b;
             Drop da = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);

@@ -63,6 +63,7 @@ struct FusedFwdParams {
 struct PackDesc {
     const float* src; void* dst;
     int R, K, ld, transpose, first_block;
+    float scale;        // the packed copy holds scale * W (0 = 1): the FFN dropout keep-scale 1 / (1 - p) rides on W1 and W2^T
 };
 constexpr int PACK_MAX = 40;
 struct PackParams {

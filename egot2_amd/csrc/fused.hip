@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "fused.h"
 #include "fused_dev.h"
+#include <type_traits>
 #include <vector>
 
 namespace egx {
@@ -34,12 +35,13 @@ __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
     int t = local / nkb, kb = local % nkb;
     int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
     float v[8];
+    const float sc = d.scale == 0.f ? 1.f : d.scale;
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int row = t * 16 + r, k = kb * 32 + half * 16 + 4 * q + j;
-            v[half * 4 + j] = d.transpose ? d.src[(size_t)k * d.ld + row] : d.src[(size_t)row * d.ld + k];
+            v[half * 4 + j] = sc * (d.transpose ? d.src[(size_t)k * d.ld + row] : d.src[(size_t)row * d.ld + k]);
         }
     if (pp.mode == CM_BF16) {
         uint4 o = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
@@ -495,38 +497,45 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) y[i][t] = f32x4{0, 0, 0, 0};
             const int nhb = p.d_ff / 32;
-            WRaw<CM> w1r[2][FD / 32];   // W1 rows of the current hidden block (prefetched one phase ahead)
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // hidden-block indices stay scalar: SGPR-based weight addresses
+            // ROLLING REFILL: the registers of a weight fragment are reloaded with the same fragment of the NEXT hidden block right
+            // behind the MFMAs that consumed it. Every fragment then has a whole block (3k-10k cycles) to arrive, the loads are
+            // spread over the MFMA phases instead of queueing as one batch in front of the CU's one vector-memory pipe (18-50
+            // wave loads issued back to back stall the wave 0.8-1.9k cycles per block: 64 B/clk shared by four waves), and no
+            // second register set is needed. Every memory operation of the loop is UNCONDITIONAL (the last block refills itself,
+            // H tiles and alive bits always leave): with a load or store under a branch hipcc's s_waitcnt insertion assumes the
+            // fewest outstanding operations of any path and a fragment wait also drains everything issued after the fragment.
+            WRaw<CM> w1r[2][FD / 32];   // W1 rows of the current hidden block
             WRaw<CM> w2r[8];            // W2 columns of the current hidden block
             float4 b1r[2];
-            auto issue_w1 = [&](int hb) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb)
-                        w1r[i][kb] = load_w<CM>(w.lin1_wp, hb * 2 + i, FD / 32, kb, lane);
-                    b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb * 32 + i * 16 + 4 * q);
-                }
-            };
-            auto issue_w2 = [&](int hb) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hb, lane);
-            };
-            // CM_SPLIT: the wait for the W2 fragments moves behind the epilogue (its MFMA phases are too short to cover the fetch:
-            // 142 -> 137 us). Spreading the 50 loads of a hidden block in quarters between the MFMA groups and epilogue stages
-            // was slower (154 us): a batch of loads issues faster than the same loads one by one.
-            constexpr bool LATE_W2 = CM == CM_SPLIT;
+            const int nit = nhb / 4;
             // Every CU walks the same weights: rotate the starting hidden block per clip so that the CUs of an XCD
             // spread their L2 requests over all channels instead of hammering the same few lines in lockstep.
-            const int nit = nhb / 4;
             const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
-            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
-            issue_w1(hb_of(0));
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
+            // the dropout keep-scale 1 / (1 - p) is folded into the packed W1 (encoder.hip) and, here, into b1:
+            // relu(s (W1 x + b1)) = s relu(W1 x + b1) for s > 0, so the epilogue has no multiply
+            const float bscale = w.ffn_thresh ? w.drop_inv : 1.f;
+            const size_t bits_base = ((size_t)l * p.B + clip) * nhb * 64 + lane;
+            constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
+            const int nht = p.d_ff / 16;
+            char* const hid_base = (char*)p.hid_out + ((size_t)l * p.B + clip) * NT * nht * (size_t)(HTILE_ELEMS * ESZ);
+            {
+                const int hb0 = hb_of(0);
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) w1r[i][kb] = load_w<CM>(w.lin1_wp, hb0 * 2 + i, FD / 32, kb, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hb0 * 32 + i * 16 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hb0, lane);
+            }
             LSTAMP_INIT();
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
-                issue_w2(hb);                       // in flight while GEMM1 runs
+                const int hbn = hb_of(it + 1 < nit ? it + 1 : it);     // the last block refills itself (never used)
                 __builtin_amdgcn_sched_barrier(0);
-                pin_all(w1r);
                 LSTAMP(0);
                 f32x4 hacc[2][NT];
 #pragma unroll
@@ -544,73 +553,100 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+                        pin(w1r[i][kb]);
                         Frag<CM> a = w_frag<CM>(w1r[i][kb]);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) mma<CM>(hacc[i][t], a, xb[XRES ? kb : 0][t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        w1r[i][kb] = load_w<CM>(w.lin1_wp, hbn * 2 + i, FD / 32, kb, lane);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                float bv[2][4] = {{b1r[0].x, b1r[0].y, b1r[0].z, b1r[0].w}, {b1r[1].x, b1r[1].y, b1r[1].z, b1r[1].w}};
+                float bv[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bv[i][0] = b1r[i].x * bscale; bv[i][1] = b1r[i].y * bscale; bv[i][2] = b1r[i].z * bscale; bv[i][3] = b1r[i].w * bscale;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hbn * 32 + i * 16 + 4 * q);
                 __builtin_amdgcn_sched_barrier(0);
                 LSTAMP(1);
-                if (it + 1 < nit) issue_w1(hb_of(it + 1));  // in flight while GEMM2 runs
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!LATE_W2) pin_all(w2r);
                 LSTAMP(2);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) hacc[i][t][e] = fmaxf(hacc[i][t][e] + bv[i][e], 0.f);
-                if (w.ffn_thresh) {     // one wave-uniform branch per hidden block
+                if (w.ffn_thresh) {     // one wave-uniform branch per hidden block (no memory operation inside)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        int h0 = hb * 32 + i * 16 + 4 * q;
+                        const uint32_t cq = (uint32_t)(hb * 32 + i * 16 + 4 * q) >> 2;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            float ds[4];
-                            drop_scale4(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), (uint32_t)h0, w.ffn_thresh, w.drop_inv, ds);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) hacc[i][t][e] *= ds[e];
+#ifdef EGX_DIAG_NOHASH
+                            const uint2 h = make_uint2(cq * 0x9E3779B1u + t, cq * 0x85EBCA77U + r);
+#else
+                            const uint2 h = rand_quad(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), cq);
+#endif
+                            // dropped units become negative: the ReLU below zeroes them and their sign bit marks them dead
+                            hacc[i][t][0] = keep_lo(h.x, w.ffn_thresh) ? hacc[i][t][0] + bv[i][0] : -1.f;
+                            hacc[i][t][1] = keep_hi(h.x, w.ffn_thresh) ? hacc[i][t][1] + bv[i][1] : -1.f;
+                            hacc[i][t][2] = keep_lo(h.y, w.ffn_thresh) ? hacc[i][t][2] + bv[i][2] : -1.f;
+                            hacc[i][t][3] = keep_hi(h.y, w.ffn_thresh) ? hacc[i][t][3] + bv[i][3] : -1.f;
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hacc[i][t][e] += bv[i][e];
                 }
-                // "Alive" bits for the backward: ReLU active AND kept by the dropout, i.e. H != 0. The backward then
-                // needs neither the H GEMM nor the dropout RNG: dH = alive ? dY W2 / (1 - p) : 0. 256 B per wave, coalesced.
-                uint32_t bits = 0;
+                // "Alive" bits for the backward: ReLU active AND kept by the dropout = sign bit clear (a pre-activation of exactly
+                // +0 counts as alive: measure zero). The backward then needs neither the H GEMM nor the dropout RNG:
+                // dH = alive ? dY W2 / (1 - p) : 0. One v_alignbit per unit shifts its sign into the word; 256 B per wave, coalesced.
+                uint32_t dead = 0;
+#pragma unroll
+                for (int k = 2 * NT * 4 - 1; k >= 0; --k) {
+                    const int i = k / (NT * 4), t = (k / 4) % NT, e = k & 3;
+                    dead = __builtin_amdgcn_alignbit(dead, __float_as_uint(hacc[i][t][e]), 31);
+                }
+                p.relu_bits[bits_base + (size_t)hb * 64] = ~dead & ((1u << (2 * NT * 4)) - 1u);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) bits |= (hacc[i][t][e] > 0.f ? 1u : 0u) << ((i * NT + t) * 4 + e);
-                p.relu_bits[(((size_t)l * p.B + clip) * nhb + hb) * 64 + lane] = bits;
+                        for (int e = 0; e < 4; ++e)     // ReLU as ONE integer max on the bit pattern (a float max pays a canonicalising second op)
+                            hacc[i][t][e] = __int_as_float(max(__float_as_int(hacc[i][t][e]), 0));
                 Frag<CM> hbq[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) hbq[t] = chain_frag<CM>(hacc[0][t], hacc[1][t]);
-                if (p.hid_out) {        // H tiles for the weight-gradient kernel (which then skips its recompute)
-                    constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
-                    const int nht = p.d_ff / 16;
-                    char* hb_base = (char*)p.hid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
+#ifndef EGX_DIAG_NOSTORE
+                {       // H tiles for the weight-gradient kernel
+                    char* hb_base = hid_base + (size_t)hb * 2 * (HTILE_ELEMS * ESZ);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (CM == CM_BF16) {      // the packed operand words ARE the two accumulator-layout tiles
+                            const u32x4 u = __builtin_bit_cast(u32x4, hbq[t].v);
+                            store_hid_tile_bf16(hb_base + (size_t)t * nht * (HTILE_ELEMS * ESZ), u, lane, S - t * 16);
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
+                            for (int i = 0; i < 2; ++i)
+                                store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), hacc[i][t], lane, S - t * 16);
+                        }
+                    }
                 }
-                if constexpr (LATE_W2) {     // the split-mode epilogue is long enough to cover the W2 fetch: wait here
-                    __builtin_amdgcn_sched_barrier(0);
-                    pin_all(w2r);
-                }
-                LSTAMP(3);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+                LSTAMP(3);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    pin(w2r[i]);
                     Frag<CM> a = w_frag<CM>(w2r[i]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mma<CM>(y[i][t], a, hbq[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hbn, lane);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 LSTAMP(4);
             }
             LSTAMP_FLUSH();

@@ -1241,6 +1241,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         {
             constexpr bool XRES = CM == CM_BF16;
             constexpr int XR = XRES ? FD / 32 : 1;
+            // same schedule as the forward FFN loop (fused.hip): rolling refill of every weight fragment right behind the MFMAs
+            // that consumed it, every memory operation unconditional so that the per-fragment waits are exact
             Frag<CM> gb[XR][NT];
             if constexpr (XRES) {
 #pragma unroll
@@ -1255,27 +1257,29 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 for (int t = 0; t < NT; ++t) dxa[i][t] = f32x4{0, 0, 0, 0};
             const int nhb = p.d_ff / 32;
             const int nit = nhb / 4;
+            const int wave_s = __builtin_amdgcn_readfirstlane(wave);
             const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
-            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave + 4 * j; };
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
             WRaw<CM> w2r[2][FD / 32], w3r[8];
             uint32_t relu_word;
-            const uint32_t* relu_bits = p.relu_bits + ((size_t)l * p.B + clip) * (size_t)(p.d_ff / 32) * 64;
-            auto issue_a = [&](int hb) {
+            const uint32_t* relu_bits = p.relu_bits + ((size_t)l * p.B + clip) * (size_t)(p.d_ff / 32) * 64 + lane;
+            constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
+            const int nht = p.d_ff / 16;
+            char* const dhid_base = (char*)p.dhid_out + ((size_t)l * p.B + clip) * NT * nht * (size_t)(HTILE_ELEMS * ESZ);
+            {
+                const int hb0 = hb_of(0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int kb = 0; kb < FD / 32; ++kb)
 #pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb) w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb * 2 + i, FD / 32, kb, lane);
-                relu_word = relu_bits[(size_t)hb * 64 + lane];
-            };
-            auto issue_b = [&](int hb) {
+                    for (int i = 0; i < 2; ++i) w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb0 * 2 + i, FD / 32, kb, lane);
+                relu_word = relu_bits[(size_t)hb0 * 64];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hb, lane);
-            };
-            issue_a(hb_of(0));
+                for (int i = 0; i < 8; ++i) w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hb0, lane);
+            }
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
-                pin_all(w2r);
-                const uint32_t bits = relu_word;
+                const int hbn = hb_of(it + 1 < nit ? it + 1 : it);     // the last block refills itself (never used)
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 dacc[2][NT];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -1292,48 +1296,58 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     }
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+                        pin(w2r[i][kb]);
                         Frag<CM> a2 = w_frag<CM>(w2r[i][kb]);
 #pragma unroll
                         for (int t = 0; t < NT; ++t) mma<CM>(dacc[i][t], a2, gb[XRES ? kb : 0][t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        w2r[i][kb] = load_w<CM>(w.lin2_wtp, hbn * 2 + i, FD / 32, kb, lane);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                // W1 / W2^T fragments are dead now: fetch W1^T (its latency overlaps the mask/dropout VALU work below);
-                // holding all three weight sets at once overflowed the 256 arch VGPRs and spilled to scratch.
+                const uint32_t bits = relu_word;
                 __builtin_amdgcn_sched_barrier(0);
-                issue_b(hb);
-                // CM_SPLIT: the dX GEMM below is too short (2.3k cycles) to cover the next block's W2^T fetch; start it here
-                if constexpr (CM == CM_SPLIT) { if (it + 1 < nit) issue_a(hb_of(it + 1)); }
+                relu_word = relu_bits[(size_t)hbn * 64];
                 __builtin_amdgcn_sched_barrier(0);
-                // alive bits = ReLU active AND kept by the forward's dropout: no RNG here
-                const float dscale = w.ffn_thresh ? w.drop_inv : 1.f;
+                // alive bits = ReLU active AND kept by the forward's dropout: no RNG here, and no multiply either — the keep-scale
+                // 1 / (1 - p) is folded into the packed W2^T (encoder.hip). One sign-extended bit field + one AND per unit.
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dacc[i][t][e] = ((bits >> ((i * NT + t) * 4 + e)) & 1u) ? dacc[i][t][e] * dscale : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = (i * NT + t) * 4 + e;
+                            const int32_t m = ((int32_t)(bits << (31 - k))) >> 31;
+                            dacc[i][t][e] = __uint_as_float(__float_as_uint(dacc[i][t][e]) & (uint32_t)m);
+                        }
                 Frag<CM> dq_[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dq_[t] = chain_frag<CM>(dacc[0][t], dacc[1][t]);
-                if (p.dhid_out) {       // dH tiles for the weight-gradient kernel
-                    constexpr int ESZ = CM == CM_BF16 ? 2 : 4;
-                    const int nht = p.d_ff / 16;
-                    char* hb_base = (char*)p.dhid_out + (((size_t)l * p.B + clip) * NT * nht + hb * 2) * (size_t)(HTILE_ELEMS * ESZ);
+                {       // dH tiles for the weight-gradient kernel
+                    char* hb_base = dhid_base + (size_t)hb * 2 * (HTILE_ELEMS * ESZ);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (CM == CM_BF16) {
+                            const u32x4 u = __builtin_bit_cast(u32x4, dq_[t].v);
+                            store_hid_tile_bf16(hb_base + (size_t)t * nht * (HTILE_ELEMS * ESZ), u, lane, S - t * 16);
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), dacc[i][t], lane, S - t * 16);
+                            for (int i = 0; i < 2; ++i)
+                                store_hid_tile<CM>(hb_base + ((size_t)t * nht + i) * (HTILE_ELEMS * ESZ), dacc[i][t], lane, S - t * 16);
+                        }
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                pin_all(w3r);
-                if constexpr (CM != CM_SPLIT) { if (it + 1 < nit) issue_a(hb_of(it + 1)); }  // next block's W2^T streams in under the dX GEMM
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
+                    pin(w3r[i]);
                     Frag<CM> a = w_frag<CM>(w3r[i]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) mma<CM>(dxa[i][t], a, dq_[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hbn, lane);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         BSTAMP(3);

@@ -281,6 +281,18 @@ __device__ __forceinline__ void store_hid_tile(void* tile, const f32x4& c, int l
         reinterpret_cast<float4*>(tile)[dst] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
+// bf16: the two accumulator-layout tiles (hidden tiles 2 hb, 2 hb + 1; 512 B each, adjacent) of one token tile, taken from
+// the packed operand words of the chained GEMM (u = {tile0 lo, tile0 hi, tile1 lo, tile1 hi}): no second conversion
+__device__ __forceinline__ void store_hid_tile_bf16(void* tile0, u32x4 u, int lane, int n_valid) {
+    if (__builtin_amdgcn_readfirstlane(n_valid) < 16) {      // wave-uniform: only a clip's last (partial) token tile pays for it
+        asm volatile("" ::: "memory");
+        const bool ok = (lane & 15) < n_valid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = ok ? u[j] : 0u;
+    }
+    reinterpret_cast<uint2*>(tile0)[lane] = make_uint2(u[0], u[1]);
+    reinterpret_cast<uint2*>(tile0)[64 + lane] = make_uint2(u[2], u[3]);
+}
 // A/B operand of one K-block of 32 tokens = two consecutive 16-token tiles of one hidden tile
 template <int CM>
 __device__ __forceinline__ Frag<CM> load_hid_frag(const void* tile_a, const void* tile_b, int lane) {

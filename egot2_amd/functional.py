@@ -242,6 +242,9 @@ class EncoderFn(torch.autograd.Function):
         # first-tokens-only output: in-kernel on the fused path; elsewhere the full block is sliced here (and the gradient
         # scattered back in backward)
         py_slice = 0
+        if spec.out_tokens and nhead:
+            raise _lib.EgxError("out_tokens (first-tokens-only output) cannot be combined with the fused pooled head: the head pools "
+                                "every token of the clip")
         if spec.out_tokens:
             import dataclasses
             full = dataclasses.replace(spec, out_tokens=0)
@@ -661,17 +664,22 @@ def weighted_cross_entropy(logits, target, weight=None):
 
 
 _LCE_SCRATCH = {}
+_LCE_RETIRED = []       # outgrown buffers stay alive: a hipGraph captured earlier still holds their addresses
 
 
 def _lce_scratch(device, nbytes: int) -> torch.Tensor:
-    """Scratch of the fused classifier head: arrival counters (zero between launches) + partial sums. One per device, grown
-    on demand; a new buffer is zero-filled once (the kernels leave the counters zero again)."""
+    """Scratch of the fused classifier head: arrival counters (zero between launches) + partial sums. One per device (NOT per
+    stream: a hipGraph is captured on a stream of its own and must find the buffer its eager warm-up created — so two streams
+    must not run lossAV concurrently on one device), grown on demand; a new buffer is zero-filled once (the kernels leave the
+    counters zero again). An outgrown buffer is never freed: a graph captured at the smaller size keeps replaying into it."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     t = _LCE_SCRATCH.get(key)
     if t is None or t.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
             # a buffer created inside a capture would live in that graph's private pool
             raise RuntimeError("linear_cross_entropy: run one eager step at this problem size before capturing it in a graph")
+        if t is not None:
+            _LCE_RETIRED.append(t)
         t = _LCE_SCRATCH[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
     return t
 

@@ -53,7 +53,9 @@ def test_dropout_masks_are_identical_in_forward_and_backward(egx_lib, cuda, impl
             lm = _loss(m, feats, target, 1234).item()
             pr[idx] = old
         fd = (lp - lm) / (2 * eps)
-        assert abs(fd - g) < 2e-2 * max(abs(g), abs(fd)) + 2e-4, f"{name}{idx}: finite difference {fd} vs gradient {g}"
+        # 5 %: a step of 2e-2 crosses a few of the 6 * 45 * 2048 ReLU kinks (measured 4.5 % on norm1.weight with the round-3
+        # masks); masks that differed between forward and backward give errors of order 100 %
+        assert abs(fd - g) < 5e-2 * max(abs(g), abs(fd)) + 2e-4, f"{name}{idx}: finite difference {fd} vs gradient {g}"
 
 
 def test_keep_rate_and_expectation(egx_lib, cuda):
