@@ -67,10 +67,95 @@ __device__ __forceinline__ int xcd_tile(int id, int total) {
 // Variants: 256 x 128 (wave 64 x 64, 3 stages) and 128 x 128 (2 stages, two workgroups per CU) fetch 11.4 B per kFLOP
 // through L2 -> LDS, which caps them near 700 TFLOP/s (measured: the L2 -> CU path delivers ~6.5 TB/s to 256 CUs running
 // them); 256 x 256 (wave 128 x 64, 2 stages of 64 KB) fetches 7.6 B per kFLOP.
+// Epilogue of the NT kernels: lane (r, g) of accumulator tile (i, j) holds C[mb + j*16 + r][nb + i*16 + 4g .. +3] (mb, nb: first
+// row / column of the wave's WTM x 64 sub-tile; prow0: its first row of the column-sum partial buffer, one per 64 output rows).
+template <int TJ>
+__device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g) {
+    constexpr int JG = TJ / 4;                       // 64-row groups of a wave: one column-sum partial row each
+    float cs_part[JG][4][4];
+#pragma unroll
+    for (int jg = 0; jg < JG; ++jg)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs_part[jg][i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int m = mb + j * 16 + r;
+        const bool mv = m < p.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nb + i * 16 + 4 * g;
+            if (!mv || n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.drop_thresh) {
+                float ds[4];
+                drop_scale4(p.drop_key, (uint32_t)m, (uint32_t)n, p.drop_thresh, p.drop_inv, ds);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= ds[e];
+            }
+            if (p.mask) {
+                uint2 mk = *reinterpret_cast<const uint2*>(p.mask + (size_t)m * p.ldm + n);
+                v[0] = (mk.x & 0xffffu) ? v[0] * p.mask_scale : 0.f;
+                v[1] = (mk.x >> 16) ? v[1] * p.mask_scale : 0.f;
+                v[2] = (mk.y & 0xffffu) ? v[2] * p.mask_scale : 0.f;
+                v[3] = (mk.y >> 16) ? v[3] * p.mask_scale : 0.f;
+            }
+            if (p.residual) {
+                float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
+                v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
+            }
+            if (p.Cf) *reinterpret_cast<float4*>(p.Cf + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.Cb) {
+                uint2 o = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = o;
+                if (p.colsum) {     // sums of the values as stored (bf16-rounded), so that db == colsum(stored dY) exactly
+                    cs_part[j / 4][i][0] += bf2f((bf16_t)(o.x & 0xffffu)); cs_part[j / 4][i][1] += bf2f((bf16_t)(o.x >> 16));
+                    cs_part[j / 4][i][2] += bf2f((bf16_t)(o.y & 0xffffu)); cs_part[j / 4][i][3] += bf2f((bf16_t)(o.y >> 16));
+                }
+            } else if (p.colsum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs_part[j / 4][i][e] += v[e];
+            }
+        }
+    }
+    if (p.colsum) {      // one partial row per 64 output rows: [ceil(M / 64)][N]
+#pragma unroll
+        for (int jg = 0; jg < JG; ++jg) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = cs_part[jg][i][e];
+                    sv += __shfl_xor(sv, 1, 64); sv += __shfl_xor(sv, 2, 64); sv += __shfl_xor(sv, 4, 64); sv += __shfl_xor(sv, 8, 64);
+                    cs_part[jg][i][e] = sv;
+                }
+            if (r == 0) {
+                const int prow = prow0 + jg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = nb + i * 16 + 4 * g;
+                    if (n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)prow * p.N + n) =
+                        make_float4(cs_part[jg][i][0], cs_part[jg][i][1], cs_part[jg][i][2], cs_part[jg][i][3]);
+                }
+            }
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 0) EGX_WAIT_VM(0);
     else if constexpr (N == 6) EGX_WAIT_VM(6);
     else if constexpr (N == 8) EGX_WAIT_VM(8);
+    else if constexpr (N == 10) EGX_WAIT_VM(10);
     else if constexpr (N == 12) EGX_WAIT_VM(12);
     else if constexpr (N == 16) EGX_WAIT_VM(16);
     else static_assert(N == 0, "add the s_waitcnt immediate");
@@ -154,85 +239,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_nt_k
         }
     }
 
-    // epilogue: lane (r, g) of tile (i, j) holds C[m0 + wm*WTM + j*16 + r][n0 + wn*64 + i*16 + 4g .. +3]
-    constexpr int JG = WTM / 64;                     // 64-row groups of a wave: one column-sum partial row each
-    float cs_part[JG][4][4];
-#pragma unroll
-    for (int jg = 0; jg < JG; ++jg)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) cs_part[jg][i][e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int m = m0 + wm * WTM + j * 16 + r;
-        const bool mv = m < p.M;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + 4 * g;
-            if (!mv || n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (p.drop_thresh) {
-                float ds[4];
-                drop_scale4(p.drop_key, (uint32_t)m, (uint32_t)n, p.drop_thresh, p.drop_inv, ds);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= ds[e];
-            }
-            if (p.mask) {
-                uint2 mk = *reinterpret_cast<const uint2*>(p.mask + (size_t)m * p.ldm + n);
-                v[0] = (mk.x & 0xffffu) ? v[0] * p.mask_scale : 0.f;
-                v[1] = (mk.x >> 16) ? v[1] * p.mask_scale : 0.f;
-                v[2] = (mk.y & 0xffffu) ? v[2] * p.mask_scale : 0.f;
-                v[3] = (mk.y >> 16) ? v[3] * p.mask_scale : 0.f;
-            }
-            if (p.residual) {
-                float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
-                v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
-            }
-            if (p.Cf) *reinterpret_cast<float4*>(p.Cf + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.Cb) {
-                uint2 o = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-                *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = o;
-                if (p.colsum) {     // sums of the values as stored (bf16-rounded), so that db == colsum(stored dY) exactly
-                    cs_part[j / 4][i][0] += bf2f((bf16_t)(o.x & 0xffffu)); cs_part[j / 4][i][1] += bf2f((bf16_t)(o.x >> 16));
-                    cs_part[j / 4][i][2] += bf2f((bf16_t)(o.y & 0xffffu)); cs_part[j / 4][i][3] += bf2f((bf16_t)(o.y >> 16));
-                }
-            } else if (p.colsum) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cs_part[j / 4][i][e] += v[e];
-            }
-        }
-    }
-    if (p.colsum) {      // one partial row per 64 output rows: [ceil(M / 64)][N]
-#pragma unroll
-        for (int jg = 0; jg < JG; ++jg) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float s = cs_part[jg][i][e];
-                    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-                    cs_part[jg][i][e] = s;
-                }
-            if (r == 0) {
-                const int prow = m0 / 64 + wm * JG + jg;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = n0 + wn * 64 + i * 16 + 4 * g;
-                    if (n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)prow * p.N + n) =
-                        make_float4(cs_part[jg][i][0], cs_part[jg][i][1], cs_part[jg][i][2], cs_part[jg][i][3]);
-                }
-            }
-        }
-    }
+    nt_epilogue<TJ>(p, acc, m0 + wm * WTM, n0 + wn * 64, m0 / 64 + wm * (WTM / 64), r, g);
 }
 
 template <int BM, int BN, int WTM, int D>
@@ -252,20 +259,161 @@ static int launch_nt(const WideGemmParams& p, hipStream_t st) {
     return 0;
 }
 
+// ---- NT, 256 x 256 tile, two staggered wave groups ("ping-pong") --------------------------------------------------------
+// 8 waves; wave (wr = wave >> 2, wn = wave & 3) owns the 128 x 64 sub-tile (rows 128 wr, columns 64 wn). A 64-deep K tile is
+// four phases of 16 MFMAs, one per quadrant of the sub-tile (X half of 64 rows x W half of 32 columns x K = 64):
+//   P1 reads X half 0 + W half 0 (12 ds_read_b128), P2 reads W half 1 (4), P3 reads X half 1 (8), P4 reads nothing.
+// Every phase is  { fragment reads; two LDS-DMA staging instructions; counted vmcnt; lgkmcnt(0) }  barrier  { 16 MFMAs }
+// barrier, and the waves 4-7 run ONE BARRIER behind the waves 0-3: while one wave of a SIMD issues MFMAs its partner reads
+// fragments and stages, so the LDS reads, the DMA issue and the waits sit under the partner's matrix work instead of in
+// front of the wave's own (one barrier per K step with all eight waves in lockstep left the matrix pipe idle during every
+// read burst: 0.27-0.36 of peak). Two 64 KB stages; a region of a stage is restaged as soon as its last reader phase is over:
+//   in tile T:  P1 stages X quarters 1, 3 of tile T+1 (other stage; last read in P3 of T-1),  P2 X quarters 0, 2 of T+2 (this
+//   stage; last read in P1),  P3 / P4 the W rows of T+2 that are read in P1 / P2. Each wave stages 8 rows of every region, so
+//   its own vmcnt covers a slice of everything; loads complete in order, two per phase: vmcnt(10) after a phase's issue says
+//   "everything issued five or more phases ago has landed", which is at least one phase earlier than any region is read
+//   (6-7 phases after its issue), and a barrier separates that wait from the reads.
+// WAR: a region's restaging is issued at least one barrier after the lgkmcnt(0) that retired its last reads in BOTH groups.
+__global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams p, int ntM, int ntN) {
+    constexpr int BM = 256, BN = 256, SB = (BM + BN) * TBK * 2, WOFF = BM * TBK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wn = wave & 3;
+    const int t = xcd_tile(blockIdx.x, ntM * ntN);
+    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * BN;
+    const int nk = p.K / TBK;
+
+    // staging: one instruction = 8 rows x 128 B; lane -> row (lane >> 3), 16-byte chunk (lane & 7) ^ row of the SOURCE
+    const int srow = lane >> 3, lch = (lane & 7) ^ srow;
+    const bf16_t* srcX[4];      // X quarter q: rows 64 q + 8 wave .. + 8
+    const bf16_t* srcW[4];      // W pieces 2 wave, 2 wave + 1 of the P1 rows (j = 0, 1) and of the P2 rows (j = 2, 3)
+    int dstX[4], dstW[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 64 * q + 8 * wave;
+        int gm = m0 + row + srow; gm = gm < p.M ? gm : p.M - 1;
+        srcX[q] = p.A + (size_t)gm * p.lda + lch * 8;
+        dstX[q] = row * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = wave * 2 + (j & 1);                                   // 16 pieces of 8 rows per half
+        const int row = (idx >> 2) * 64 + (j >> 1) * 32 + (idx & 3) * 8;      // wave wn reads rows 64 wn + [0, 32) in P1, + [32, 64) in P2
+        int gn = n0 + row + srow; gn = gn < p.N ? gn : p.N - 1;
+        srcW[j] = p.B + (size_t)gn * p.ldb + lch * 8;
+        dstW[j] = WOFF + row * 128;
+    }
+    auto koff = [&](int kt) { return (kt < nk ? kt : nk - 1) * TBK; };      // tiles past the end re-fetch the last one (never read)
+    auto stage_x = [&](int kt, int qa, int qb) {
+        unsigned char* st = smem + (kt & 1) * SB;
+        const int k0 = koff(kt);
+        glds16(srcX[qa] + k0, st + dstX[qa]);
+        glds16(srcX[qb] + k0, st + dstX[qb]);
+    };
+    auto stage_w = [&](int kt, int h) {
+        unsigned char* st = smem + (kt & 1) * SB;
+        const int k0 = koff(kt);
+        glds16(srcW[2 * h] + k0, st + dstW[2 * h]);
+        glds16(srcW[2 * h + 1] + k0, st + dstW[2 * h + 1]);
+    };
+
+    const int r = lane & 15, g = lane >> 4;
+    const int offX = (wr * 128 + r) * 128, offW = WOFF + (wn * 64 + r) * 128;
+    const int c0 = ((0 * 4 + g) ^ (r & 7)) * 16, c1 = ((1 * 4 + g) ^ (r & 7)) * 16;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // prologue, in the order the steady state would have issued them: tile 0 complete, tile 1 up to its P2-P4 regions
+    stage_x(0, 0, 2); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1, 3);
+    stage_x(1, 0, 2); stage_w(1, 0); stage_w(1, 1);
+    EGX_WAIT_VM(10);
+    ring_barrier();
+    if (wr == 1) ring_barrier();        // the stagger: waves 4-7 run one barrier behind
+
+    bf16x8 fx[4][2], fw[4][2];          // X half (4 row tiles x 2 K sub-steps), W tiles 0..3 (both halves stay live for P4)
+#define EGX_PP_PHASE_TAIL()                                  \
+    EGX_WAIT_VM(10);                                         \
+    ring_barrier();                                          \
+    __builtin_amdgcn_s_setprio(1);
+#define EGX_PP_MFMA(XH, I0)                                                                                              \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+                acc[I0 + i][XH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[I0 + i][s], fx[j][s], acc[I0 + i][XH * 4 + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    ring_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* st = smem + (kt & 1) * SB;
+        // P1: X half 0, W half 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fx[j][0] = lds_read128(st + offX + j * 2048 + c0); fx[j][1] = lds_read128(st + offX + j * 2048 + c1); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { fw[i][0] = lds_read128(st + offW + i * 2048 + c0); fw[i][1] = lds_read128(st + offW + i * 2048 + c1); }
+        stage_x(kt + 1, 1, 3);
+        EGX_PP_PHASE_TAIL();
+        EGX_PP_MFMA(0, 0);
+        // P2: W half 1
+#pragma unroll
+        for (int i = 2; i < 4; ++i) { fw[i][0] = lds_read128(st + offW + i * 2048 + c0); fw[i][1] = lds_read128(st + offW + i * 2048 + c1); }
+        stage_x(kt + 2, 0, 2);
+        EGX_PP_PHASE_TAIL();
+        EGX_PP_MFMA(0, 2);
+        // P3: X half 1 (the registers of half 0 are dead)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { fx[j][0] = lds_read128(st + offX + (4 + j) * 2048 + c0); fx[j][1] = lds_read128(st + offX + (4 + j) * 2048 + c1); }
+        stage_w(kt + 2, 0);
+        EGX_PP_PHASE_TAIL();
+        EGX_PP_MFMA(1, 2);
+        // P4: no reads
+        stage_w(kt + 2, 1);
+        EGX_PP_PHASE_TAIL();
+        EGX_PP_MFMA(1, 0);
+    }
+#undef EGX_PP_PHASE_TAIL
+#undef EGX_PP_MFMA
+    if (wr == 0) ring_barrier();        // balance the stagger
+    EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup
+    nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
+}
+
+static int launch_nt_pp(const WideGemmParams& p, hipStream_t st) {
+    constexpr int LDS = 2 * (256 + 256) * TBK * 2;
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    const int ntM = cdiv(p.M, 256), ntN = cdiv(p.N, 256);
+    timing_begin(TIMER_WIDE_GEMM, st);
+    hipLaunchKernelGGL(wide_gemm_nt_pp_kernel, dim3(ntM * ntN), dim3(512), LDS, st, p, ntM, ntN);
+    timing_end(TIMER_WIDE_GEMM, st);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
 // tile choice. 256 x 256 (EGX_WIDE_TILE=512 forces it, =256 / =128 force the others): N a multiple of 256 and at least 3.5
 // rounds of tiles over the 256 CUs (its 1.5x lower operand traffic is worth nothing in a half-empty last round)
 static int nt_variant(int M, int N) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("EGX_WIDE_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 1024) return 3;        // the ping-pong 256 x 256 kernel
     if (force == 512) return 2;
     if (force == 256) return 1;
     if (force == 128) return 0;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    if (N % 256 == 0 && t256 >= 896) return 2;
+    // the ping-pong kernel once its tiles fill the chip at least once (same-box A/B against the one-barrier 256 x 256 / 256 x 128
+    // variants at M = 32768: N = 2048, K = 768: 872 vs 832 TFLOP/s; N = 768, K = 2048 / 2304: 917 / 950 vs 849 / 892; equal
+    // on the K = 768, N = 768 / 2304 shapes); below that the 128-row tiles spread the work over more CUs
+    if (t256 >= 256 && (N % 256 == 0 || N >= 1024)) return 3;
     return (long)cdiv(M, 256) * cdiv(N, TBN) >= 512 ? 1 : 0;
 }
 // rows of the `colsum` partial buffer written by wide_gemm_nt for an (M, N) output: one per 64 output rows of every tile
-int wide_gemm_nt_colsum_rows(int M, int N) { return nt_variant(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }
+int wide_gemm_nt_colsum_rows(int M, int N) { return nt_variant(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }     // one per 64 rows of every tile
 
 int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     EGX_CHECK(p.A && p.B && (p.Cf || p.Cb), "wide_gemm_nt: null operand");
@@ -273,6 +421,7 @@ int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
     const int v = nt_variant(p.M, p.N);
+    if (v == 3) return launch_nt_pp(p, st);
     if (v == 2) return launch_nt<256, 256, 128, 2>(p, st);
     // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves) below
     if (v == 1) return launch_nt<256, 128, 64, 3>(p, st);

@@ -1,0 +1,30 @@
+"""Correctness of egx_wide_gemm (NT) against torch.matmul on random bf16 operands, several shapes incl. ragged M / N, repeated to
+catch staging races; the tile variant follows EGX_WIDE_TILE (1024 = the ping-pong 256 x 256 kernel). usage: python tools/gemm_check.py [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from egot2_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+torch.manual_seed(0)
+bad = 0
+for M, N, K in [(256, 256, 64), (256, 256, 128), (512, 256, 192), (300, 260, 256), (1024, 768, 768), (4096, 2304, 768), (32768, 768, 2048),
+                (1000, 1000, 1024), (8192, 768, 8192), (777, 516, 320)]:
+    A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16()
+    bias = torch.randn(N, device=dev)
+    ref = (A.float() @ B.float().t()) + bias
+    sc = torch.empty(lib.egx_wide_gemm_scratch(0, M, N, K), dtype=torch.uint8, device=dev)
+    worst = 0.0
+    for rep in range(reps):
+        Cf = torch.full((M, N), float("nan"), device=dev)
+        rc = lib.egx_wide_gemm(0, A.data_ptr(), B.data_ptr(), Cf.data_ptr(), None, M, N, K, bias.data_ptr(), 0, None, sc.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.egx_last_error()
+        torch.cuda.synchronize()
+        err = (Cf - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, err if err == err else 1e9)
+    ok = worst < 2e-3
+    bad += not ok
+    print(f"M={M:6d} N={N:5d} K={K:5d}  max rel err {worst:.2e}  {'ok' if ok else 'FAIL'}")
+sys.exit(1 if bad else 0)
