@@ -430,6 +430,17 @@ def run(args) -> int:
         for p in params:        # 20 averaged copies later the gradients are still finite; nothing reads them again
             p.grad = None
 
+    # launches per step: kernels the library enqueues for one eager fwd + bwd (a hipGraph replay issues the same nodes)
+    launches_per_step = None
+    if hasattr(lib, "egx_launch_count"):
+        lib.egx_launch_count(1)
+        fwd_bwd()
+        F_egx.run_deferred()
+        torch.cuda.synchronize()
+        launches_per_step = int(lib.egx_launch_count(1))
+        for p in params:
+            p.grad = None
+
     metric = ("clips/sec fwd+bwd, 3-task TTM translator (B=256,T=15,d=128)" if wl["name"] == "c2"
               else f"clips/sec fwd+bwd, {wl['name']}")
     out = {
@@ -444,6 +455,7 @@ def run(args) -> int:
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
                    "launch": "one hipGraph replay per step" if use_graph else "eager",
                    "deterministic": bool(args.deterministic)},
+        "library_launches_per_step": launches_per_step,
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
         "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
     }

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 9
+EGX_ABI_VERSION = 10
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
@@ -56,10 +56,29 @@ class Config(C.Structure):
                 ("deterministic", C.c_int), ("out_tokens", C.c_int)]
 
 
+class DecConfig(C.Structure):
+    _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int), ("vocab", C.c_int),
+                ("sy", C.c_int), ("S", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("p_drop", C.c_float),
+                ("p_pos", C.c_float)]
+
+
+_DEC_LAYER_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "norm1_w", "norm1_b", "ca_in_w", "ca_in_b", "ca_out_w",
+                     "ca_out_b", "norm2_w", "norm2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm3_w", "norm3_b"]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, _fp) for n in _DEC_LAYER_FIELDS]
+
+
+class DecLayerGrads(C.Structure):
+    _fields_ = [(n, _fp) for n in _DEC_LAYER_FIELDS]
+
+
 # symbol -> (restype, argtypes); every symbol include/egot2x.h declares
 SIGNATURES = {
     "egx_abi_version": (C.c_int, []),
     "egx_last_error": (C.c_char_p, []),
+    "egx_launch_count": (C.c_longlong, [C.c_int]),
     "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "egx_encoder_uses_fused": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
@@ -87,6 +106,11 @@ SIGNATURES = {
     "egx_embed_pos_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_float, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     C.c_uint64, _fp]),
     "egx_embed_pos_bwd": (C.c_int, [_fp, _fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_decoder_workspace": (C.c_int, [C.POINTER(DecConfig), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "egx_decoder_fwd": (C.c_int, [C.POINTER(DecConfig), _fp, _fp, _fp, _fp, C.c_int, C.POINTER(DecLayer), _fp, _fp, C.c_int, _fp, _fp,
+                                  _fp, C.c_int, C.c_uint64, _fp]),
+    "egx_decoder_bwd": (C.c_int, [C.POINTER(DecConfig), _fp, C.POINTER(DecLayer), _fp, C.c_int, _fp, _fp, _fp, _fp, _fp,
+                                  C.POINTER(DecLayerGrads), _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_uint64, _fp]),
     "egx_relu_mask": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
     "egx_dropout": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
     "egx_weighted_ce": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
@@ -142,12 +166,15 @@ def load() -> C.CDLL:
     # libegot2x.so binds to the SAME runtime instance; loading ours first splits the process across two runtimes.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    variant = bool(os.environ.get("EGX_LIB"))       # a variant build (A/B aid) may predate the newest entry points
     for name, (res, args) in SIGNATURES.items():
+        if variant and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
     ver = lib.egx_abi_version()
-    if ver != EGX_ABI_VERSION:
+    if ver != EGX_ABI_VERSION and not variant:
         raise EgxError(f"libegot2x ABI version {ver} != binding version {EGX_ABI_VERSION}; rebuild the library")
     _lib = lib
     return lib

@@ -11,6 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 void set_error(const char* fmt, ...);
+void count_launch();        // kernel launches issued by the library since egx_launch_count_reset (egx_launch_count)
 
 #define EGX_CHECK(cond, ...)                         \
     do {                                             \
@@ -32,6 +33,7 @@ void set_error(const char* fmt, ...);
 
 #define EGX_LAUNCH_CHECK()                                                               \
     do {                                                                                 \
+        ::egx::count_launch();                                                           \
         hipError_t _e = hipGetLastError();                                               \
         if (_e != hipSuccess) {                                                          \
             ::egx::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e),  \

@@ -16,6 +16,8 @@ namespace egx {
 
 static thread_local char g_err[1024] = "";
 
+static long long g_launches = 0;
+void count_launch() { ++g_launches; }
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -305,6 +307,7 @@ using namespace egx;
 extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
+long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
 int egx_debug_stamps(unsigned long long* out, int n) { return n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n); }
 int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }

@@ -25,6 +25,24 @@ class DecoderMixin:
         sy = y.shape[1]
         if y.shape[0] != B:
             raise ValueError(f"target batch {y.shape[0]} != memory batch {B}")
+        comp_model = getattr(self, "egx_compute", "f32")
+        d_ff = decoder.layers[0].linear1.out_features
+        post_ln = not any(getattr(layer, "norm_first", False) for layer in decoder.layers)
+        if post_ln and F_egx.decoder_supported(comp_model, d, n_heads, d_ff, sy, S, len(decoder.layers)) and not getattr(self, "egx_composed_decoder", False):
+            # ONE library call per direction (egx_decoder_fwd / egx_decoder_bwd): bf16 MFMA GEMMs over all B * sy target rows
+            train = bool(self.training)
+            meta = dict(n_layers=len(decoder.layers), n_heads=n_heads, d_ff=d_ff, ln_eps=decoder.layers[0].norm1.eps,
+                        p_drop=p_drop if train else 0.0, p_pos=pos_embed.dropout.p if train else 0.0, training=train,
+                        seed=self._egx_seed() if train else 0)
+            params = []
+            for layer in decoder.layers:
+                sa, ca = layer.self_attn, layer.multihead_attn
+                params += [sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.norm1.weight, layer.norm1.bias,
+                           ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight, ca.out_proj.bias, layer.norm2.weight, layer.norm2.bias,
+                           layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm3.weight, layer.norm3.bias]
+            mem2d = encoded_x.permute(1, 0, 2).contiguous().view(B * S, d)
+            out = F_egx.DecoderFn.apply(meta, y, mem2d, embedding.weight, pos_embed.pe[:sy, 0, :], *params, fc.weight, fc.bias)
+            return out.view(B, sy, -1).permute(1, 0, 2)
         comp = "f32"        # (B * sy)-row GEMMs: negligible work, they always run the exact fp32 MFMA path
         comp_mem = getattr(self, "egx_compute", "f32")     # the K / V projection of the (B * S)-row memory follows the encoder's compute type
         train = bool(self.training)

@@ -656,6 +656,91 @@ class WeightedCEFn(torch.autograd.Function):
         return dl * grad_out, None, None
 
 
+class DecoderFn(torch.autograd.Function):
+    """The EgoT2-g sequence decoder + vocabulary head as ONE library call per direction (egx_decoder_fwd / egx_decoder_bwd, compute =
+    bf16): logits (B * sy, |V|) from target tokens (B, sy) and the encoder memory (B * S, d). Inputs after `meta`: memory, embedding
+    weight, positional rows (sy, d), 18 tensors per layer in _lib._DEC_LAYER_FIELDS order, fc weight, fc bias. All parameter gradients
+    are views of one flat buffer (zero-filled by the library's backward)."""
+
+    @staticmethod
+    def forward(ctx, meta, tokens, memory, emb, pe, *rest):
+        lib = _lib.load()
+        n_layers = meta["n_layers"]
+        layer_t = [_dev_f32(t, "decoder layer parameter") for t in rest[:18 * n_layers]]
+        fc_w, fc_b = _dev_f32(rest[18 * n_layers], "fc.weight"), _dev_f32(rest[18 * n_layers + 1], "fc.bias")
+        memory, emb, pe = _dev_f32(memory, "memory"), _dev_f32(emb, "embedding.weight"), _dev_f32(pe, "positional rows")
+        if tokens.dtype != torch.int64 or not tokens.is_cuda:
+            raise _lib.EgxError("decoder tokens must be an int64 tensor on the GPU")
+        tokens = tokens.contiguous()
+        B, sy = tokens.shape
+        d = emb.shape[1]
+        S = memory.shape[0] // B
+        cfg = _lib.DecConfig(d, meta["n_heads"], meta["d_ff"], n_layers, emb.shape[0], sy, S, meta["ln_eps"], EGX_BF16,
+                             meta["p_drop"], meta["p_pos"])
+        sv, sc = C.c_size_t(0), C.c_size_t(0)
+        check(lib.egx_decoder_workspace(C.byref(cfg), B, C.byref(sv), C.byref(sc)))
+        need_grad = any(ctx.needs_input_grad)
+        saved = torch.empty(max(sv.value, 256), dtype=torch.uint8, device=memory.device) if need_grad else _workspace("dec_saved", memory.device, sv.value)
+        scratch = _workspace("dec_scratch", memory.device, sc.value)
+        layers = (_lib.DecLayer * n_layers)()
+        for l in range(n_layers):
+            for k, name in enumerate(_lib._DEC_LAYER_FIELDS):
+                setattr(layers[l], name, ptr(layer_t[18 * l + k]))
+        logits = torch.empty((B * sy, emb.shape[0]), dtype=torch.float32, device=memory.device)
+        seed = C.c_uint64(meta["seed"] & (2**64 - 1))
+        check(lib.egx_decoder_fwd(C.byref(cfg), ptr(tokens), ptr(memory), ptr(emb), ptr(pe), pe.stride(0), layers, ptr(fc_w), ptr(fc_b), B,
+                                  ptr(logits), ptr(saved), ptr(scratch), int(meta["training"]), seed, _stream()))
+        ctx.meta, ctx.cfg_args, ctx.B, ctx.saved_buf, ctx.scratch_bytes = meta, (d, sy, S), B, saved, sc.value
+        ctx.save_for_backward(tokens, memory, emb, pe, *layer_t, fc_w, fc_b)
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        lib = _lib.load()
+        meta = ctx.meta
+        n_layers = meta["n_layers"]
+        sv = list(ctx.saved_tensors)
+        tokens, memory, emb, pe = sv[:4]
+        layer_t = sv[4:4 + 18 * n_layers]
+        fc_w, fc_b = sv[4 + 18 * n_layers], sv[5 + 18 * n_layers]
+        d, sy, S = ctx.cfg_args
+        B = ctx.B
+        need = ctx.needs_input_grad      # (meta, tokens, memory, emb, pe, *layer_t, fc_w, fc_b)
+        device = d_logits.device
+        pk = _GradPacker()
+        i_emb = pk.add(emb, need[3])
+        i_layer = [pk.add(t, need[5 + i]) for i, t in enumerate(layer_t)]
+        i_fcw = pk.add(fc_w, need[5 + 18 * n_layers])
+        i_fcb = pk.add(fc_b, need[6 + 18 * n_layers])
+        grads = pk.materialise(device, zero=False)
+
+        def g(i):
+            return grads[i] if i >= 0 else None
+
+        d_memory = torch.empty_like(memory) if need[2] else None
+        cfg = _lib.DecConfig(d, meta["n_heads"], meta["d_ff"], n_layers, emb.shape[0], sy, S, meta["ln_eps"], EGX_BF16,
+                             meta["p_drop"], meta["p_pos"])
+        layers = (_lib.DecLayer * n_layers)()
+        lgr = (_lib.DecLayerGrads * n_layers)()
+        for l in range(n_layers):
+            for k, name in enumerate(_lib._DEC_LAYER_FIELDS):
+                setattr(layers[l], name, ptr(layer_t[18 * l + k]))
+                setattr(lgr[l], name, ptr(g(i_layer[18 * l + k])))
+        scratch = _workspace("dec_scratch", device, ctx.scratch_bytes)
+        dl = d_logits.float().contiguous()
+        seed = C.c_uint64(meta["seed"] & (2**64 - 1))
+        check(lib.egx_decoder_bwd(C.byref(cfg), ptr(tokens), layers, ptr(fc_w), B, ptr(dl), ptr(ctx.saved_buf), ptr(scratch), ptr(d_memory),
+                                  ptr(g(i_emb)), lgr, ptr(g(i_fcw)), ptr(g(i_fcb)), ptr(pk.flat), pk.flat.numel() * 4, int(meta["training"]),
+                                  seed, _stream()))
+        return (None, None, d_memory, g(i_emb), None) + tuple(g(i) for i in i_layer) + (g(i_fcw), g(i_fcb))
+
+
+def decoder_supported(compute: str, d: int, n_heads: int, d_ff: int, sy: int, S: int, n_layers: int) -> bool:
+    """Shapes egx_decoder_fwd / egx_decoder_bwd serve (include/egot2x.h); everything else stays on the composed decoder."""
+    return (compute == "bf16" and 256 <= d <= 1024 and d % 128 == 0 and n_heads > 0 and d % n_heads == 0 and d // n_heads in (32, 64)
+            and d_ff >= 128 and d_ff % 128 == 0 and 1 <= sy <= 8 and 1 <= S <= 64 and 1 <= n_layers <= 16)
+
+
 def weighted_cross_entropy(logits, target, weight=None):
     """F.cross_entropy(logits, target, weight=weight) with mean reduction (HHI/tasks/ttm/video_task_2loader.py:21-22,34).
     Labels outside [0, C) - including F.cross_entropy's default ignore_index = -100 - contribute neither loss, weight nor

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 9
+#define EGX_ABI_VERSION 10
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -157,6 +157,9 @@ typedef struct egx_config {
 } egx_config;
 
 int egx_abi_version(void);
+/* Kernel launches (and memsets) the library has enqueued on this thread's behalf since the last reset: the bench reports
+ * launches per step with it. reset != 0 zeroes the counter after reading. Not thread-safe (a diagnostic). */
+long long egx_launch_count(int reset);
 const char* egx_last_error(void);
 
 /* Workspace sizes in bytes for a batch of B clips of S tokens (S = sum of segment T). */
@@ -336,6 +339,44 @@ int egx_embed_pos_fwd(const int64_t* tokens, const float* emb, const float* pe, 
                       int B, int sy, int d, int V, float p_drop, uint64_t seed, void* stream);
 int egx_embed_pos_bwd(const int64_t* tokens, const float* dy, float* d_emb, float scale, int B, int sy, int d, int V,
                       float p_drop, uint64_t seed, void* stream);
+/* ---- the whole decoder as ONE call per direction (round 3) ----------------------------------------------------------
+ * Same reference lines as above (task_prompt_model.py:260-269, video_model_builder.py:150-159; CustomDecoderLayer
+ * task_prompt_model.py:163-172). compute = EGX_BF16 only: the B * sy target rows and the B * S memory rows run through the
+ * bf16 MFMA GEMMs of the wide path with fused epilogues, the LayerNorms through its row kernels, the two attentions through
+ * a register-resident kernel (one wave per (clip, head)). d_model a multiple of 128 in [256, 1024], head dim 32 or 64,
+ * sy <= 8 target tokens, S <= 64 memory tokens per clip; other configurations return an error (the caller composes the
+ * decoder from the entry points above instead). Parameters are torch-layout fp32 ([out, in] row-major); `ca_in_w` /
+ * `ca_in_b` are the packed in-projection of the cross-attention (rows [0, d): query, rows [d, 3d): key / value). */
+typedef struct egx_dec_config {
+    int d_model, n_heads, d_ff, n_layers;
+    int vocab;          /* |V|: rows of the embedding, outputs of fc */
+    int sy, S;          /* target tokens per clip, memory tokens per clip */
+    float ln_eps;
+    int compute;        /* EGX_BF16 */
+    float p_drop;       /* dropout of the decoder layers (attention probabilities, the three residual branches, FFN hidden) */
+    float p_pos;        /* dropout of the positional encoding */
+} egx_dec_config;
+typedef struct egx_dec_layer {
+    const float* sa_in_w; const float* sa_in_b; const float* sa_out_w; const float* sa_out_b; const float* norm1_w; const float* norm1_b;
+    const float* ca_in_w; const float* ca_in_b; const float* ca_out_w; const float* ca_out_b; const float* norm2_w; const float* norm2_b;
+    const float* lin1_w; const float* lin1_b; const float* lin2_w; const float* lin2_b; const float* norm3_w; const float* norm3_b;
+} egx_dec_layer;
+typedef struct egx_dec_layer_grads {     /* accumulated (+=); any may be NULL */
+    float* sa_in_w; float* sa_in_b; float* sa_out_w; float* sa_out_b; float* norm1_w; float* norm1_b;
+    float* ca_in_w; float* ca_in_b; float* ca_out_w; float* ca_out_b; float* norm2_w; float* norm2_b;
+    float* lin1_w; float* lin1_b; float* lin2_w; float* lin2_b; float* norm3_w; float* norm3_b;
+} egx_dec_layer_grads;
+int egx_decoder_workspace(const egx_dec_config* cfg, int B, size_t* saved_bytes, size_t* scratch_bytes);
+/* tokens (B, sy) int64; memory (B * S, d) fp32, rows b * S + s (the encoder output, batch-first); emb (vocab, d); pe rows at
+ * pe + t * pe_stride; logits (B * sy, vocab) fp32 out. `saved` is read by the backward; `scratch` is free afterwards. */
+int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const float* memory, const float* emb, const float* pe, int pe_stride,
+                    const egx_dec_layer* layers, const float* fc_w, const float* fc_b, int B, float* logits, void* saved, void* scratch,
+                    int training, uint64_t seed, void* stream);
+/* d_memory (B * S, d) is overwritten (=); every parameter gradient is accumulated (+=) — `zero_buf` / `zero_bytes` (optional):
+ * a buffer the first operation of the call zero-fills (the caller's flat gradient buffer holding all += targets). */
+int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_dec_layer* layers, const float* fc_w, int B, const float* d_logits,
+                    const void* saved, void* scratch, float* d_memory, float* d_emb, const egx_dec_layer_grads* grads, float* d_fc_w,
+                    float* d_fc_b, void* zero_buf, size_t zero_bytes, int training, uint64_t seed, void* stream);
 /* dy[i] = y[i] > 0 ? dy[i] : 0 in place: backward of the ReLU fused into egx_linear_fwd(relu = 1). */
 int egx_relu_mask(float* dy, const float* y, size_t n, void* stream);
 /* x[r, c] *= keep(seed, site, r, c) / (1 - p) in place (inverted dropout); calling it on the gradient with the same

@@ -82,4 +82,6 @@ def test_hip_matches_reference_fixture(egx_lib, cuda, name, compute, tol_out, to
     loss.backward()
     torch.cuda.synchronize()
     grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
-    check_against_fixture(z, outs, loss, grads, tol_out, tol_grad)
+    # bf16: the fused decoder (row F1, egx_decoder_*) stacks L more bf16 layers on the bf16 encoder memory, whose own error is
+    # already 0.5-0.7 % of the output scale: its logits are held to 1.5e-2 (measured 0.7-1.2 %)
+    check_against_fixture(z, outs, loss, grads, tol_out, tol_grad, tol_dec=1.5e-2 if compute == "bf16" else None)
