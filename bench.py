@@ -315,7 +315,8 @@ def run(args) -> int:
         return ok
 
     overlap = multi and not args.no_overlap and staged_backward_ok()
-    ar_time = {"s": 0.0, "n": 0}
+    bucketed = multi and not args.no_overlap and not use_graph
+    exch = {"collectives": None}
 
     def place_optimizer(with_opt):
         """FusedAdam re-points the parameters into its flat buffer on its FIRST step; a graph captured before that would
@@ -379,6 +380,16 @@ def run(args) -> int:
                     with_opt.step()
             return step_overlapped
         model.egx_defer_small = False
+        if bucketed:
+            # wide / generic paths (c4, c5*): the backward announces its gradient buffer slice by slice (per encoder layer, last
+            # layer first; the decoder's buffer as a whole) and every slice is all-reduced while the rest of the backward runs
+            def step_bucketed():
+                with ddp.BucketedExchange(params, force=args.force_dist) as ex:
+                    fwd_bwd()
+                exch["collectives"] = ex.collectives
+                if with_opt:
+                    with_opt.step()
+            return step_bucketed
         if with_opt and not multi:
             def body():
                 fwd_bwd()
@@ -451,7 +462,8 @@ def run(args) -> int:
         "trials": trials, "ms_per_step_p10": percentile(ms, 0.1), "ms_per_step_p90": percentile(ms, 0.9),
         "ms_per_step_min": min(ms), "timed_seconds": sum(dts),
         "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
-                               + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else "")) if multi else ""),
+                               + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else
+                                                                 " in per-layer buckets overlapped with the backward" if bucketed else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
                    "launch": "one hipGraph replay per step" if use_graph else "eager",
                    "deterministic": bool(args.deterministic)},
@@ -461,6 +473,9 @@ def run(args) -> int:
     }
     if allreduce_us is not None:
         out["allreduce_us"] = allreduce_us
+        out["overlap"] = "staged" if overlap else ("bucketed" if bucketed else "none")
+        if exch["collectives"] is not None:
+            out["collectives_per_step"] = exch["collectives"]
 
     if not args.optimizer and not args.no_optimizer_line:
         # "+ optimizer step reported separately" (SURVEY.md 8d): the same step with the Adam update inside

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 10
+EGX_ABI_VERSION = 11
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
@@ -53,7 +53,10 @@ class Config(C.Structure):
                 ("n_segments", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("impl", C.c_int),
                 ("p_drop", C.c_float), ("p_pos", C.c_float), ("p_feat", C.c_float), ("seed_ptr", _fp),
                 ("advance_seed", C.c_int), ("zero_buf", _fp), ("zero_bytes", C.c_size_t), ("bwd_stage", C.c_int),
-                ("deterministic", C.c_int), ("out_tokens", C.c_int)]
+                ("deterministic", C.c_int), ("out_tokens", C.c_int), ("bucket_cb", C.c_void_p), ("bucket_user", C.c_void_p)]
+
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 
 class DecConfig(C.Structure):

@@ -291,7 +291,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
     // Cache (d = 512: 764 MB, +1.5 %; C4: 1.1 GB, +0.8 %), so they keep the reduction right behind each GEMM.
     WideReduceBatch rb;
     size_t slab_cur = 0;
-    const bool defer_ok = pl.slab_all_bytes > 0;
+    const bool defer_ok = pl.slab_all_bytes > 0 && !cfg->bucket_cb;     // bucketed exchange: a layer's gradients must be final when its bucket is announced
     auto dw_tn = [&](const bf16_t* dy, int ldy, const bf16_t* x, int ldx, float* dW, int n_out, int k_in, int tokens) -> int {
         if (!dW) return 0;
         WideGemmParams t;
@@ -369,6 +369,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             if (wide_gemm_nt(q, st)) return 1;
         }
         g = g0;
+        if (cfg->bucket_cb) cfg->bucket_cb(cfg->bucket_user, pl.L - 1 - l);     // every gradient of layer l is enqueued
     }
 
     // token preparation backward

@@ -140,3 +140,64 @@ def allreduce_gradients_overlapped(finish_backward, params: Iterable[torch.nn.Pa
     if rest:
         n += allreduce_gradients(rest, group, average, force)
     return n
+
+
+class BucketedExchange:
+    """Gradient exchange overlapped with the backward, bucket by bucket (the wide bf16 path: BASELINE.json configs[3] / [4], the
+    8-GPU EgoT2-g configuration; the reference gets it from DDP's bucketed reducer, HOI/scripts/multitask/run.py:41-50):
+
+        with ddp.BucketedExchange(params) as ex:
+            loss.backward()
+        # every .grad of `params` is now the average over the ranks; ex.collectives were issued
+
+    Inside the block every backward of the library announces a slice of its flat gradient buffer as soon as the kernels that
+    complete it are enqueued (functional.bucket_hook): the wide encoder one slice per layer, last layer first — the buffer is
+    laid out in that order — the sequence decoder its whole buffer (it runs before the encoder's backward). Each announcement
+    starts an asynchronous all-reduce of that slice; RCCL orders it behind the kernels enqueued so far and runs it beside the
+    ones enqueued afterwards. Leaving the block waits for the collectives and exchanges the gradients that were not announced
+    (task heads computed by torch) the way allreduce_gradients does. `force` runs the collectives in a one-rank group."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True, force: bool = False):
+        self.params, self.group, self.average, self.force = list(params), group, average, force
+        self.collectives = 0
+        self._work, self._covered = [], []
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+
+    def _on_bucket(self, flat: torch.Tensor, lo: int, hi: int):
+        if hi <= lo:
+            return
+        buf = flat[lo:hi]
+        fused_avg = self.average and dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
+        self._work.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf, fused_avg))
+        self._covered.append((flat.untyped_storage().data_ptr(), flat.data_ptr() + 4 * lo, flat.data_ptr() + 4 * hi))
+        self.collectives += 1
+
+    def __enter__(self):
+        from . import functional as F_egx
+        if self.active:
+            if F_egx.bucket_hook is not None:
+                raise RuntimeError("BucketedExchange: another exchange is active")
+            F_egx.bucket_hook = self._on_bucket
+        return self
+
+    @torch.no_grad()
+    def __exit__(self, exc_type, exc, tb):
+        from . import functional as F_egx
+        if not self.active:
+            return False
+        F_egx.bucket_hook = None
+        world = dist.get_world_size(self.group)
+        for work, buf, fused_avg in self._work:
+            work.wait()
+            if self.average and not fused_avg:
+                buf.mul_(1.0 / world)
+        if exc_type is None:
+            def covered(g):
+                a = g.data_ptr()
+                return any(lo <= a < hi for _, lo, hi in self._covered)
+            rest = [p for p in self.params if p.grad is not None and not covered(p.grad)]
+            if rest:
+                self.collectives += allreduce_gradients(rest, self.group, self.average, self.force)
+        self._work = []
+        return False

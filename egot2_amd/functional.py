@@ -115,20 +115,27 @@ class _GradPacker:
         self.total = 0
         self.late_floats = 0
 
-    def add(self, t: Optional[torch.Tensor], want: bool, late: bool = False) -> int:
+    def add(self, t: Optional[torch.Tensor], want: bool, late: bool = False, rank: int = 0) -> int:
+        """`rank`: entries are laid out by ascending rank (stable): the bucketed exchange gives the tensors of the encoder layer the
+        backward finishes first the lowest rank, so every layer's gradients are one contiguous slice (self.rank_span)."""
         if t is None or not want:
             self.entries.append(None)
             return -1
-        self.entries.append((t.shape, (t.numel() + 3) // 4 * 4, late))
+        self.entries.append((t.shape, (t.numel() + 3) // 4 * 4, late, rank))
         return len(self.entries) - 1
 
     def materialise(self, device, zero: bool = True) -> List[Optional[torch.Tensor]]:
         """zero=False: the caller hands `self.flat` to the library, whose backward zero-fills it (egx_config.zero_buf)."""
         offs, cur = {}, 0
+        self.rank_span = {}
+        order = sorted((i for i, e in enumerate(self.entries) if e is not None), key=lambda i: self.entries[i][3])
         for want_late in (True, False):
-            for i, e in enumerate(self.entries):
-                if e is not None and e[2] == want_late:
+            for i in order:
+                e = self.entries[i]
+                if e[2] == want_late:
                     offs[i] = cur
+                    lo, hi = self.rank_span.get(e[3], (cur, cur))
+                    self.rank_span[e[3]] = (min(lo, cur), cur + e[1])
                     cur += e[1]
             if want_late:
                 self.late_floats = cur
@@ -151,6 +158,10 @@ class _GradPacker:
 
 
 _deferred = []          # closures that finish a staged backward (EncoderSpec.defer_small)
+# Bucketed gradient exchange (ddp.BucketedExchange): when set, bucket_hook(flat, lo, hi) is called from inside a backward as
+# soon as the kernels that complete flat[lo:hi] are enqueued on the current stream (per encoder layer on the wide path, once
+# per buffer elsewhere); the hook starts the all-reduce of that slice, which then overlaps the rest of the backward.
+bucket_hook = None
 last_grad_layout = {}   # {"flat": flat gradient buffer of the latest encoder backward, "late_floats": size of its late region}
 
 
@@ -312,15 +323,21 @@ class EncoderFn(torch.autograd.Function):
         need = ctx.needs_input_grad  # (spec, task_embed, pos_table, ln_w, ln_b, *rest)
 
         pk = _GradPacker()
-        i_te = pk.add(task_embed, need[1])
-        i_pos = pk.add(pos_table, need[2])
-        i_lnw = pk.add(ln_w, need[3])
-        i_lnb = pk.add(ln_b, need[4])
-        i_feat = [pk.add(f, need[5 + i]) for i, f in enumerate(feats)]
+        _rr = spec.n_layers if bucket_hook is not None else 0
+        i_te = pk.add(task_embed, need[1], rank=_rr)
+        i_pos = pk.add(pos_table, need[2], rank=_rr)
+        i_lnw = pk.add(ln_w, need[3], rank=_rr)
+        i_lnb = pk.add(ln_b, need[4], rank=_rr)
+        i_feat = [pk.add(f, need[5 + i], rank=_rr) for i, f in enumerate(feats)]
         # proj: (w, b) pairs; layer: 12 tensors in _LAYER_FIELDS order, in_proj_w / out_proj_w are indices 0 and 2
-        i_proj = [pk.add(t, need[5 + nseg + i], late=(i % 2 == 0)) for i, t in enumerate(proj)]
-        i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i], late=(i % 12 in (0, 2))) for i, t in enumerate(layer_t)]
-        i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i]) for i, t in enumerate(head_t)]
+        i_proj = [pk.add(t, need[5 + nseg + i], late=(i % 2 == 0) and bucket_hook is None, rank=_rr) for i, t in enumerate(proj)]
+        hook = bucket_hook
+        n_l = spec.n_layers
+        # bucketed exchange: the backward finishes the LAST layer first -> it gets rank 0, ..., layer 0 rank L - 1, the rest L
+        lrank = (lambda i: n_l - 1 - i // 12) if hook is not None else (lambda i: 0)
+        rest_rank = n_l if hook is not None else 0
+        i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i], late=(i % 12 in (0, 2)) and hook is None, rank=lrank(i)) for i, t in enumerate(layer_t)]
+        i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i], rank=rest_rank) for i, t in enumerate(head_t)]
         grads = pk.materialise(device, zero=False)      # zero-filled by the library's backward (saves a fill launch)
 
         def g(i):
@@ -358,6 +375,17 @@ class EncoderFn(torch.autograd.Function):
 
         cfg = spec.config()
         cfg.zero_buf, cfg.zero_bytes = ptr(pk.flat), pk.flat.numel() * 4
+        announced = set()
+        cb_keep = None
+        if hook is not None and ctx.impl == EGX_IMPL_WIDE:
+            flat_for_cb, spans = pk.flat, dict(pk.rank_span)
+
+            def _cb(_user, bucket):       # host callback from wide_encoder_bwd: layer n_l - 1 - bucket is complete on the stream
+                if bucket in spans and bucket not in announced:
+                    announced.add(bucket)
+                    hook(flat_for_cb, spans[bucket][0], spans[bucket][1])
+            cb_keep = _lib.BUCKET_CB(_cb)
+            cfg.bucket_cb = C.cast(cb_keep, C.c_void_p)
         defer = bool(spec.defer_small) and ctx.fused_path
         cfg.bwd_stage = 1 if defer else 0
         scratch = _workspace("scratch", device, ctx.scratch_bytes)
@@ -387,6 +415,14 @@ class EncoderFn(torch.autograd.Function):
                                           ptr(scratch), sgr, p_lnw, p_lnb, lgr, int(spec.training), seed,
                                           _stream()))
         launch(cfg)
+        if hook is not None and not defer:
+            # whatever the per-layer callbacks did not announce (other implementations: everything) is complete now
+            done = sorted(pk.rank_span[b] for b in announced)
+            cur = 0
+            for lo, hi in done + [(pk.total, pk.total)]:
+                if lo > cur:
+                    hook(pk.flat, cur, lo)
+                cur = max(cur, hi)
         last_grad_layout.update(flat=pk.flat, late_floats=pk.late_floats if defer else 0)
         if defer:
             # stage 2 (dW_proj, dW_in, dW_o) on request: same arguments, kept alive by this closure; the shared scratch
@@ -732,6 +768,8 @@ class DecoderFn(torch.autograd.Function):
         check(lib.egx_decoder_bwd(C.byref(cfg), ptr(tokens), layers, ptr(fc_w), B, ptr(dl), ptr(ctx.saved_buf), ptr(scratch), ptr(d_memory),
                                   ptr(g(i_emb)), lgr, ptr(g(i_fcw)), ptr(g(i_fcb)), ptr(pk.flat), pk.flat.numel() * 4, int(meta["training"]),
                                   seed, _stream()))
+        if bucket_hook is not None and pk.total:
+            bucket_hook(pk.flat, 0, pk.total)        # the decoder's gradients are exchanged while the encoder's backward runs
         return (None, None, d_memory, g(i_emb), None) + tuple(g(i) for i in i_layer) + (g(i_fcw), g(i_fcb))
 
 

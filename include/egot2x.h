@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 10
+#define EGX_ABI_VERSION 11
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -154,6 +154,16 @@ typedef struct egx_config {
                                  the ASD translator returns its first segment, HHI/models/asd/model_taskspecific.py:156-158;
                                  without this the caller slices (copy) and autograd zero-fills and scatters the gradient.
                                  Fused per-clip kernels only (egx_encoder_impl() == EGX_IMPL_FUSED); an error elsewhere. */
+    void (*bucket_cb)(void* user, int bucket);   /* BACKWARD, optional (wide bf16 path): called on the host thread right after the
+                                 kernels that complete gradient bucket `bucket` have been enqueued on the stream. Bucket b in
+                                 [0, n_layers) = every parameter gradient of encoder layer n_layers - 1 - b (the order the backward
+                                 finishes them); everything else (projections, shared LayerNorm, embeddings) is complete when the
+                                 call returns. The caller lays its flat gradient buffer out last-layer-first and starts the
+                                 all-reduce of a layer's slice from the callback, so the exchange of layer l overlaps the backward
+                                 of layers l - 1 .. 0 (the reference gets this from DDP's bucketed reducer,
+                                 HOI/scripts/multitask/run.py:41-50). With a callback every split-K slab reduction runs right
+                                 behind its GEMM (no deferred batch). Other implementations ignore it. */
+    void* bucket_user;
 } egx_config;
 
 int egx_abi_version(void);

@@ -202,6 +202,53 @@ def test_two_rank_overlapped_allreduce():
     assert np.allclose(flat[:12], 15.0 * i[:12])
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from egot2_amd import ddp, functional as F_egx
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a "backward" that announces its flat buffer in three slices (two layers, last layer first, then the rest), one
+    # parameter whose gradient lives outside any announced buffer (a task head computed by torch)
+    flat = torch.zeros(48)
+    ps = [torch.nn.Parameter(torch.zeros(16)) for _ in range(3)] + [torch.nn.Parameter(torch.zeros(5))]
+    for i in range(3):
+        ps[i].grad = flat[16 * i:16 * (i + 1)]
+    order = []
+    with ddp.BucketedExchange(ps) as ex:
+        assert F_egx.bucket_hook is not None
+        for i in range(3):                                   # slice i becomes final, is announced, then the next one is "computed"
+            flat[16 * i:16 * (i + 1)] = (i + 1) * (rank + 1) * torch.arange(16, dtype=torch.float32)
+            F_egx.bucket_hook(flat, 16 * i, 16 * (i + 1))
+            order.append(ex.collectives)
+        ps[3].grad = torch.full((5,), float(rank + 1))
+    assert F_egx.bucket_hook is None
+    if rank == 0:
+        q.put((ex.collectives, order, flat.numpy().copy(), ps[3].grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_exchange():
+    """ddp.BucketedExchange on gloo: every announced slice is all-reduced (averaged) as it is announced, the gradient that no
+    backward announced is exchanged when the block is left, and the hook is removed again."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    n, order, flat, loose = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert order == [1, 2, 3] and n == 4            # three slices + one collective for the unannounced gradient
+    i = np.arange(16, dtype=np.float32)
+    for k in range(3):
+        assert np.allclose(flat[16 * k:16 * (k + 1)], 1.5 * (k + 1) * i)
+    assert np.allclose(loose, 1.5)
+
+
 def test_bench_self_launches_ranks_gloo():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start 2 ranks by itself (the round-1 script
     silently ran one). The launcher plumbing is exercised on CPU through --launch-selftest --backend gloo: both ranks
