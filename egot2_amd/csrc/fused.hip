@@ -85,7 +85,7 @@ __device__ unsigned long long g_stamps[32];
 #ifdef EGX_STAMPS
 #define LSTAMP_INIT() unsigned long long lt_prev = __builtin_amdgcn_s_memtime(), lt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define LSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); lt_acc[k] += t_ - lt_prev; lt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define LSTAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) g_stamps[16 + k_] = lt_acc[k_]; } while (0)
+#define LSTAMP_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) if (lt_acc[k_]) g_stamps[16 + k_] = lt_acc[k_]; } while (0)
 #else
 #define LSTAMP_INIT() do { } while (0)
 #define LSTAMP(k) do { } while (0)
@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     float* Vt = Ks + SP * LDX;                  // [FD][LDV] V^T, keys >= S zero
     float* X1 = Vt + FD * LDV;                  // [SP][LDX] res1 / x1
     float* Part = Qs;                           // FFN partials 1..3 alias Q/K/Vt (needs 3*SP*LDX <= 2*SP*LDX + FD*LDV)
+    // segment descriptors in LDS: `p.seg[i]` with a run-time i is a chain of dependent scalar loads from the kernel-argument
+    // segment (advance / source / store touch ~10 fields per step: 2.5-3k cycles per step, 15-18k of the 35-40k cycles of the
+    // token preparation by the stamps); one ds_read burst + v_readfirstlane per step instead
+    FusedSeg* segtab = reinterpret_cast<FusedSeg*>(X1 + SP * LDX);
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -126,73 +130,125 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
     // zero the padded rows once so that padded tokens stay finite everywhere
     for (int i = tid; i < SP * LDX; i += 256) { Xs[i] = 0.f; X1[i] = 0.f; }
+    if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
     __syncthreads();
+    auto seg_of = [&](int i) {      // wave-uniform copy of descriptor i in scalar registers
+        static_assert(sizeof(FusedSeg) % 4 == 0, "descriptor is copied word by word");
+        FusedSeg o;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(segtab + i);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(FusedSeg) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
+        return o;
+    };
+    STAMP(10);
 
     // ---- token preparation: proj GEMM (feature-major) -> LDS token-major -> LN + task embedding + position.
-    // Steps = (segment, 16-row tile, 128-wide K chunk); the loads of step i+1 are issued before the MFMAs of step i.
+    // Steps = (segment, 16-row tile, 128-wide K chunk), two register sets. ROLLING REFILL as in the FFN loop: a fragment's
+    // registers are reloaded with the same fragment of step i + 2 right behind the MFMAs that consumed it, every load is
+    // unconditional (steps past the end re-fetch the last one) so that the per-fragment s_waitcnt counts are exact. Round 2
+    // issued a whole step's 12 fragments under `if (valid(next))`: every wait then drained all loads in flight and the six
+    // steps of a clip each paid a full HBM / L2 round trip (40k cycles for 0.8 GF; the weight stream alone needs ~12k).
     {
         struct Step { int sgi, t0, k0; };
         auto valid = [&](const Step& s) { return s.sgi < p.nseg; };
         auto advance = [&](Step s) {
             s.k0 += 128;
-            if (s.k0 >= p.seg[s.sgi].d_in) { s.k0 = 0; s.t0 += 16; if (s.t0 >= p.seg[s.sgi].T) { s.t0 = 0; ++s.sgi; } }
+            const int d_in = __builtin_amdgcn_readfirstlane(segtab[s.sgi].d_in), T = __builtin_amdgcn_readfirstlane(segtab[s.sgi].T);
+            if (s.k0 >= d_in) { s.k0 = 0; s.t0 += 16; if (s.t0 >= T) { s.t0 = 0; ++s.sgi; } }
             return s;
         };
-        auto issue = [&](const Step& s, Raw (&rb)[4], WRaw<CM> (&ra0)[4], WRaw<CM> (&ra1)[4]) {
-            const FusedSeg& sg = p.seg[s.sgi];
-            int trow = s.t0 + r;
-            bool tv = trow < sg.T;
-            const float* frow = sg.feat + ((size_t)clip * sg.T + (tv ? trow : 0)) * sg.d_in;
-            const int nkb = sg.d_in / 32;
+        auto clamped = [&](const Step& s, const Step& fallback) { return valid(s) ? s : fallback; };
+        struct Src { const float* frow; const void* wp; const float* bias; int nkb, kb0; };
+        auto source = [&](const Step& s) {
+            const FusedSeg sg = seg_of(s.sgi);
+            const int trow = s.t0 + r;
+            Src o;
+            o.frow = sg.feat + ((size_t)clip * sg.T + (trow < sg.T ? trow : 0)) * sg.d_in + s.k0;   // rows >= T read row 0 (discarded at the store)
+            o.wp = sg.proj_wp; o.nkb = sg.d_in / 32; o.kb0 = s.k0 / 32;
+            o.bias = sg.proj_b + wave * 32 + 4 * q;
+            return o;
+        };
+        Raw rb[2][4];
+        WRaw<CM> ra0[2][4], ra1[2][4];
+        float4 pb[2][2];        // projection bias of the step's two feature tiles: fetched WITH the step's fragments (a load issued in
+                                // the store epilogue would be the youngest in flight: its wait drained every prefetched fragment)
+        auto issue_all = [&](auto SET, const Step& s) {
+            constexpr int b = decltype(SET)::value;
+            const Src o = source(s);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int k = s.k0 + 32 * j;       // d_in % 128 == 0; rows >= T read row 0 and are discarded at the store
-                rb[j] = load_raw(frow + k, q);
-                ra0[j] = load_w<CM>(sg.proj_wp, wave * 2 + 0, nkb, k / 32, lane);
-                ra1[j] = load_w<CM>(sg.proj_wp, wave * 2 + 1, nkb, k / 32, lane);
+                rb[b][j] = load_raw(o.frow + 32 * j, q);
+                ra0[b][j] = load_w<CM>(o.wp, wave * 2 + 0, o.nkb, o.kb0 + j, lane);
+                ra1[b][j] = load_w<CM>(o.wp, wave * 2 + 1, o.nkb, o.kb0 + j, lane);
             }
+            pb[b][0] = *reinterpret_cast<const float4*>(o.bias);
+            pb[b][1] = *reinterpret_cast<const float4*>(o.bias + 16);
         };
         f32x4 acc[2];
-        auto compute = [&](const Step& s, Raw (&rb)[4], WRaw<CM> (&ra0)[4], WRaw<CM> (&ra1)[4]) {
-            const FusedSeg& sg = p.seg[s.sgi];
-            pin_all(rb); pin_all(ra0); pin_all(ra1);
+        LSTAMP_INIT();
+        auto step = [&](auto SET, const Step& s, const Step& refill) {
+            constexpr int b = decltype(SET)::value;
+            const FusedSeg sg = seg_of(s.sgi);
+            const Src o = source(refill);
             if (s.k0 == 0) { acc[0] = f32x4{0, 0, 0, 0}; acc[1] = f32x4{0, 0, 0, 0}; }
+            LSTAMP(5);
+#ifdef EGX_STAMPS
+            if (s.sgi == 0 && s.t0 == 0 && s.k0 == 0 && blockIdx.x == 0 && threadIdx.x == 0) g_stamps[11] = lt_acc[5];
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                Frag<CM> b = to_frag<CM>(rb[j]);
-                mma<CM>(acc[0], w_frag<CM>(ra0[j]), b);
-                mma<CM>(acc[1], w_frag<CM>(ra1[j]), b);
+                pin(rb[b][j]); pin(ra0[b][j]); pin(ra1[b][j]);
+                if (j == 0) { LSTAMP(6); }
+                Frag<CM> bf = to_frag<CM>(rb[b][j]);
+                mma<CM>(acc[0], w_frag<CM>(ra0[b][j]), bf);
+                mma<CM>(acc[1], w_frag<CM>(ra1[b][j]), bf);
+                __builtin_amdgcn_sched_barrier(0);
+                rb[b][j] = load_raw(o.frow + 32 * j, q);
+                ra0[b][j] = load_w<CM>(o.wp, wave * 2 + 0, o.nkb, o.kb0 + j, lane);
+                ra1[b][j] = load_w<CM>(o.wp, wave * 2 + 1, o.nkb, o.kb0 + j, lane);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            const float4 bb0 = pb[b][0], bb1 = pb[b][1];
+            __builtin_amdgcn_sched_barrier(0);
+            pb[b][0] = *reinterpret_cast<const float4*>(o.bias);
+            pb[b][1] = *reinterpret_cast<const float4*>(o.bias + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            LSTAMP(7);
             if (s.k0 + 128 >= sg.d_in) {
-                int trow = s.t0 + r;
+                const int trow = s.t0 + r;
                 if (trow < sg.T) {
-#pragma unroll
-                    for (int ft = 0; ft < 2; ++ft) {
-                        int f0 = (wave * 2 + ft) * 16 + 4 * q;
-                        float4 bb = *reinterpret_cast<const float4*>(sg.proj_b + f0);
-                        float4 o = make_float4(acc[ft][0] + bb.x, acc[ft][1] + bb.y, acc[ft][2] + bb.z, acc[ft][3] + bb.w);
-                        *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0) = o;
-                    }
+                    const int f0 = wave * 32 + 4 * q;
+                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0) =
+                        make_float4(acc[0][0] + bb0.x, acc[0][1] + bb0.y, acc[0][2] + bb0.z, acc[0][3] + bb0.w);
+                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0 + 16) =
+                        make_float4(acc[1][0] + bb1.x, acc[1][1] + bb1.y, acc[1][2] + bb1.z, acc[1][3] + bb1.w);
                 }
             }
         };
-        Raw rbA[4], rbB[4];
-        WRaw<CM> ra0A[4], ra1A[4], ra0B[4], ra1B[4];
+        typedef std::integral_constant<int, 0> SA;
+        typedef std::integral_constant<int, 1> SB;
         Step cur{0, 0, 0};
-        issue(cur, rbA, ra0A, ra1A);
-        while (valid(cur)) {
-            Step nx = advance(cur);
-            if (valid(nx)) issue(nx, rbB, ra0B, ra1B);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(cur, rbA, ra0A, ra1A);
-            cur = nx;
-            if (!valid(cur)) break;
-            nx = advance(cur);
-            if (valid(nx)) issue(nx, rbA, ra0A, ra1A);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(cur, rbB, ra0B, ra1B);
-            cur = nx;
+        {
+            const Step n1 = clamped(advance(cur), cur);
+            issue_all(SA{}, cur);
+            issue_all(SB{}, n1);
         }
+        for (;;) {
+            if (!valid(cur)) break;
+            {
+                const Step n1 = advance(cur);
+                step(SA{}, cur, clamped(valid(n1) ? advance(n1) : n1, cur));
+                cur = n1;
+            }
+            if (!valid(cur)) break;
+            {
+                const Step n1 = advance(cur);
+                step(SB{}, cur, clamped(valid(n1) ? advance(n1) : n1, cur));
+                cur = n1;
+            }
+        }
+        LSTAMP_FLUSH();
     }
     __syncthreads();
     STAMP(1);
@@ -201,8 +257,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     __syncthreads();
     ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
         int sgi = 0;
-        while (sgi + 1 < p.nseg && row >= p.seg[sgi + 1].off) ++sgi;
-        const FusedSeg& sg = p.seg[sgi];
+        while (sgi + 1 < p.nseg && row >= segtab[sgi + 1].off) ++sgi;
+        const FusedSeg sg = segtab[sgi];
         int t = row - sg.off;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -770,7 +826,7 @@ int timing_read(int which, double* total_ms, int* count) {
 
 size_t fused_lds_bytes(int NT) {
     int SP = NT * 16;
-    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float);
+    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg);
 }
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {

@@ -380,14 +380,16 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
         egx_segment_grads sgr;
         memset(&sgr, 0, sizeof(sgr));
         if (seg_grads) sgr = seg_grads[i];
-        EGX_CHECK(!sgr.feat, "wide path: gradients into the features are not supported (use impl = generic)");
+        // d(features): an identity segment's feature gradient IS the LayerNorm backward's fp32 input gradient (the trainable
+        // SlowFast head of the LTA translators feeds such a segment); projected features stay frozen on this path
+        EGX_CHECK(!sgr.feat || !sg.proj_w, "wide path: gradients into PROJECTED features are not supported (use impl = generic)");
         const int rows = B * sg.T;
         if (sgr.pos && wide_pos_grad(g, B, S, pl.seg_off[i], sg.T, d, sgr.pos, sg.pos_stride, dp.key, dp.thresh, dp.inv, cspart, st)) return 1;
-        const bool need = (sg.proj_w && (sgr.proj_w || sgr.proj_b)) || d_ln_w || d_ln_b || sgr.add_vec;
+        const bool need = (sg.proj_w && (sgr.proj_w || sgr.proj_b)) || d_ln_w || d_ln_b || sgr.add_vec || sgr.feat;
         if (!need) continue;
         WideLnBwdParams b;
         b.dy = g; b.pre = sg.proj_w ? cat<float>(saved, pl.seg_pre[i]) : sg.feat; b.stats = cat<float>(saved, pl.seg_stats[i]);
-        b.w = ln_w; b.dx16 = sg.proj_w ? dseg16 : nullptr; b.rows = rows; b.d = d; b.T = sg.T; b.S = S; b.off = pl.seg_off[i];
+        b.w = ln_w; b.dx16 = sg.proj_w ? dseg16 : nullptr; b.dx32 = sg.proj_w ? nullptr : sgr.feat; b.rows = rows; b.d = d; b.T = sg.T; b.S = S; b.off = pl.seg_off[i];
         b.drop_key = dp.key; b.drop_thresh = dp.thresh; b.drop_inv = dp.inv;
         if (sg.proj_w) {
             Drop df = mkdrop(training, cfg->p_feat, seed, (uint32_t)i, SITE_FEAT);

@@ -241,9 +241,16 @@ class EncoderFn(torch.autograd.Function):
         needs_grad = any(nig)
         if spec.impl == "auto" and (nig[2] or any(nig[5:5 + nseg])):
             import dataclasses
-            if any(nig[5:5 + nseg]):
-                # gradients into the features: only the shape-generic backward produces them
+            feat_grad = [bool(nig[5 + i]) for i in range(nseg)]
+            probe_cfg = spec.config()
+            wide_ident_only = (lib.egx_encoder_impl(C.byref(probe_cfg), segs, B) == EGX_IMPL_WIDE
+                               and not any(fg and ss.has_proj for fg, ss in zip(feat_grad, spec.segments)))
+            if any(feat_grad) and not wide_ident_only:
+                # gradients into projected features: only the shape-generic backward produces them (the wide path serves
+                # identity segments — the trainable action stream of the LTA translators — from its LayerNorm backward)
                 spec = dataclasses.replace(spec, impl="generic")
+            elif any(feat_grad):
+                pass
             else:
                 # learned positional table (HOI `pe`): the fused per-clip backward emits no gradient for it; the wide
                 # bf16 path and the generic kernels do

@@ -236,3 +236,25 @@ def test_asd_translator_at_bench_size_with_its_head(egx_lib, cuda, compute, tol_
     errs["FC.bias"] = rel_err(head.FC.bias.grad, b.grad)
     bad = {k: v for k, v in errs.items() if not v < tol_grad}
     assert len(errs) > 20 and not bad, bad
+
+
+def test_split_mode_keeps_nonfinite_operands_nonfinite(egx_lib, cuda):
+    """f32s splits every fp32 operand into three bf16 parts (x - bf16(x) ...): an infinite operand gives inf - inf = NaN where the
+    exact fp32 path propagates +-inf (include/egot2x.h, EGX_F32_SPLIT). Either way a non-finite feature must never come out as a
+    finite logit: both modes are checked, and the documented difference (NaN vs inf / NaN) is pinned."""
+    from egot2_amd import hhi_ttm
+    feats = seeded_feats(3, [(4, 15, 256)] * 3)
+    feats[1][2, 5, 17] = float("inf")
+    out = {}
+    for compute in ("f32s", "f32"):
+        m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args())
+        m.load_state_dict(seeded_state_dict(m, 3))
+        m = m.to(cuda).set_compute(compute).eval()
+        with torch.no_grad():
+            out[compute] = m.forward_features(*[f.to(cuda) for f in feats]).cpu()
+    for compute, o in out.items():
+        assert not torch.isfinite(o[2]).any(), f"{compute}: the clip with the infinite feature produced finite logits"
+        clean = [0, 1, 3]
+        assert torch.isfinite(o[clean]).all(), f"{compute}: other clips must be untouched"
+    assert torch.isnan(out["f32s"][2]).all()
+    assert torch.allclose(out["f32s"][[0, 1, 3]], out["f32"][[0, 1, 3]], atol=1e-4)

@@ -197,6 +197,35 @@ def test_wide_path_is_selected_and_generic_agrees(egx_lib, cuda):
         assert (gw - gg).norm().item() <= 8e-2 * gg.norm().item() + 1e-6, k
 
 
+def test_wide_path_feeds_gradients_into_identity_segments(egx_lib, cuda):
+    """The LTA translators' action stream comes from a SlowFast whose head is TRAINABLE (reference
+    lta_models_lta_transfer.py:296-302, 357): it needs d(feature). On the wide path that gradient is the token-prep LayerNorm
+    backward's fp32 input gradient; the encoder must stay on the wide kernels (round 2 silently fell back to the generic
+    ones) and agree with them."""
+    from egot2_amd import hoi_lta, functional as F_egx
+    res = {}
+    for impl in ("auto", "generic"):
+        m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(4, 256, 8, 2))
+        m.load_state_dict(seeded_state_dict(m, 5))
+        m = m.to(cuda).set_compute("bf16", impl).train()
+        feats = [f.to(cuda) for f in seeded_feats(6, [(3, 4, 8192), (3, 4, 8192), (3, 4, 256), (3, 4, 2048)])]
+        feats[2].requires_grad_()
+        egx_lib.egx_launch_count(1)
+        o = m.forward_features(*feats)
+        (o[0].sum() + (o[1] * o[1]).sum()).backward()
+        res[impl] = (feats[2].grad.clone(), m.transformer.layers[0].linear1.weight.grad.clone())
+    # the auto run used the wide kernels: its weight gradient is bit-identical to a run without the feature gradient
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(4, 256, 8, 2))
+    m.load_state_dict(seeded_state_dict(m, 5))
+    m = m.to(cuda).set_compute("bf16", "wide").train()
+    feats = [f.to(cuda) for f in seeded_feats(6, [(3, 4, 8192), (3, 4, 8192), (3, 4, 256), (3, 4, 2048)])]
+    o = m.forward_features(*feats)
+    (o[0].sum() + (o[1] * o[1]).sum()).backward()
+    assert torch.equal(res["auto"][1], m.transformer.layers[0].linear1.weight.grad)
+    ga, gg = res["auto"][0], res["generic"][0]
+    assert (ga - gg).norm().item() <= 8e-2 * gg.norm().item() + 1e-6
+
+
 def test_wide_path_dropout_training_is_reproducible(egx_lib, cuda):
     """Train-mode dropout on the wide path: same seed -> bit-identical outputs and gradients (counter-based masks shared by
     forward and backward, fixed-order reductions everywhere: no atomics on this path); eval mode differs and has no noise."""

@@ -22,3 +22,5 @@ for comp in ("f32", "f32s", "bf16"):
     t = list(buf)[:10]
     print(comp, "total ticks", t[9] - t[0], " ".join(f"{n}={t[i + 1] - t[i]}" for i, n in enumerate(names[:9])))
     print("   ffn loop (wave 0): wait_w1 %d gemm1 %d wait_w2 %d epilogue %d gemm2 %d" % tuple(list(buf)[16:21]))
+    b = list(buf)
+    print("   token prep (wave 0): lds zero + barrier %d | steps: setup %d (of it before the first step: %d) first-fragment wait %d mfma + refill %d" % (b[10] - b[0], b[21], b[11], b[22], b[23]))
