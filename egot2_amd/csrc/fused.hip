@@ -508,9 +508,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         });
         if constexpr (CM == CM_SPLIT) {     // padded rows of the planes: zero operands
-            for (int i = tid; i < 3 * (SP - S) * (LDXH / 8); i += 256) {
-                int pl = i / ((SP - S) * (LDXH / 8)), rem = i - pl * ((SP - S) * (LDXH / 8));
-                *reinterpret_cast<uint4*>(XP + pl * XPS + (S + rem / (LDXH / 8)) * LDXH + (rem % (LDXH / 8)) * 8) = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < 3 * (SP - S) * (LDXH / 4); i += 256) {
+                int pl = i / ((SP - S) * (LDXH / 4)), rem = i - pl * ((SP - S) * (LDXH / 4));
+                *reinterpret_cast<uint2*>(XP + pl * XPS + (S + rem / (LDXH / 4)) * LDXH + (rem % (LDXH / 4)) * 4) = make_uint2(0, 0);
             }
         }
         __syncthreads();
@@ -527,7 +527,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 for (int i = tid; i < 3 * SP * (FD / 8); i += 256) {
                     int part = i / (SP * (FD / 8)), rem = i - part * (SP * (FD / 8));
                     int row = rem >> 4, c8 = rem & 15;
-                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(XP + part * XPS + row * LDXH + c8 * 8);
+                    const unsigned short* src = XP + part * XPS + row * LDXH + c8 * 8;        // rows are 8-byte aligned
+                    const uint2 a = *reinterpret_cast<const uint2*>(src), b = *reinterpret_cast<const uint2*>(src + 4);
+                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = make_uint4(a.x, a.y, b.x, b.y);
                 }
             }
         }

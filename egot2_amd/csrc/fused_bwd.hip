@@ -1230,7 +1230,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 for (int i = tid; i < 3 * SP * (FD / 8); i += 256) {
                     int part = i / (SP * (FD / 8)), rem = i - part * (SP * (FD / 8));
                     int row = rem >> 4, c8 = rem & 15;
-                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = *reinterpret_cast<const uint4*>(GP + part * GPS + row * LDXH + c8 * 8);
+                    const unsigned short* src = GP + part * GPS + row * LDXH + c8 * 8;        // rows are 8-byte aligned
+                    const uint2 a = *reinterpret_cast<const uint2*>(src), b = *reinterpret_cast<const uint2*>(src + 4);
+                    *reinterpret_cast<uint4*>(dst + part * plane + rem * 8) = make_uint4(a.x, a.y, b.x, b.y);
                 }
             }
         }

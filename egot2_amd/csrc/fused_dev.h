@@ -167,21 +167,25 @@ __device__ __forceinline__ void pin_all(T (&x)[N][M]) {
 
 // ---- pre-split operand planes (CM_SPLIT) ------------------------------------------------------------------------------
 // A token-major fp32 LDS block that is the B operand of many MFMAs (the FFN input x1: 64 hidden blocks) is split ONCE
-// into three bf16 planes [part][rows][LDXH]; a fragment is then six ds_read_b64 and no VALU work. Row stride 272 B: the
-// 16 rows x 2 lane groups of a half-wave cover all 64 banks exactly once.
-constexpr int LDXH = FD + 8;
+// into three bf16 planes [part][rows][LDXH]; a fragment is then three ds_read2_b64 (hipcc merges the low / high half of a
+// K-block, 32 B apart) and no VALU work. ds_read2_b64 is banked over 32 banks in groups of 16 CONSECUTIVE lanes = the 16 rows
+// of a fragment at one lane group q: the row stride must be 2 (mod 4) dwords for them to cover all 32 banks. Round 2 used
+// 272 B (68 dwords = 4 mod 32, chosen for plain ds_read_b64's 64-bank rule): rows r and r + 8 collided — the 6.0 M / 7.6 M
+// SQ_LDS_BANK_CONFLICT cycles of the split-mode clip kernels. 264 B = 66 dwords: lane r reads banks 2r, 2r + 1. Rows are
+// then only 8-byte aligned: the planes are written and copied out in 8-byte pieces.
+constexpr int LDXH = FD + 4;
 __device__ __forceinline__ void split32(const float (&v)[32], uint32_t (&h)[16], uint32_t (&m)[16], uint32_t (&l)[16]) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) split_pair(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
 }
-// 32 consecutive elements of one row, already split: d = &plane0[row][c0]
+// 32 consecutive elements of one row, already split: d = &plane0[row][c0] (8-byte aligned)
 __device__ __forceinline__ void store_parts32(unsigned short* d, size_t plane_stride, const uint32_t (&h)[16], const uint32_t (&m)[16],
                                               const uint32_t (&l)[16]) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<uint4*>(d + 8 * g) = make_uint4(h[4 * g], h[4 * g + 1], h[4 * g + 2], h[4 * g + 3]);
-        *reinterpret_cast<uint4*>(d + plane_stride + 8 * g) = make_uint4(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]);
-        *reinterpret_cast<uint4*>(d + 2 * plane_stride + 8 * g) = make_uint4(l[4 * g], l[4 * g + 1], l[4 * g + 2], l[4 * g + 3]);
+    for (int g = 0; g < 8; ++g) {
+        *reinterpret_cast<uint2*>(d + 4 * g) = make_uint2(h[2 * g], h[2 * g + 1]);
+        *reinterpret_cast<uint2*>(d + plane_stride + 4 * g) = make_uint2(m[2 * g], m[2 * g + 1]);
+        *reinterpret_cast<uint2*>(d + 2 * plane_stride + 4 * g) = make_uint2(l[2 * g], l[2 * g + 1]);
     }
 }
 __device__ __forceinline__ void store_split32(unsigned short* planes, int plane_stride, int row, int c0, const float (&v)[32]) {

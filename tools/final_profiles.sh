@@ -1,22 +1,56 @@
-set -x
-mkdir -p gpurun_out/final
-# bench lines (default = f32s headline incl. native_f32 and cpu baseline), other dtypes / configs
-python bench.py > gpurun_out/final/bench_f32s.log 2>&1; tail -1 gpurun_out/final/bench_f32s.log > gpurun_out/final/r02_bench_f32s.json
-python bench.py --dtype f32 --no-cpu-baseline > gpurun_out/final/bench_f32.log 2>&1; tail -1 gpurun_out/final/bench_f32.log > gpurun_out/final/r02_bench_f32.json
-python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/final/bench_bf16.log 2>&1; tail -1 gpurun_out/final/bench_bf16.log > gpurun_out/final/r02_bench_bf16.json
-python bench.py --config c3 --no-cpu-baseline > gpurun_out/final/bench_c3.log 2>&1; tail -1 gpurun_out/final/bench_c3.log > gpurun_out/final/r02_bench_c3.json
-python bench.py --config c4 --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/final/bench_c4.log 2>&1; tail -1 gpurun_out/final/bench_c4.log > gpurun_out/final/r02_bench_c4.json
-python bench.py --config c5hoi --encoder-only --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/final/bench_c5hoi.log 2>&1; tail -1 gpurun_out/final/bench_c5hoi.log > gpurun_out/final/r02_bench_c5hoi_enc.json
-python bench.py --config c5hhi --encoder-only --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/final/bench_c5hhi.log 2>&1; tail -1 gpurun_out/final/bench_c5hhi.log > gpurun_out/final/r02_bench_c5hhi_enc.json
-python bench.py --deterministic --no-cpu-baseline --no-roofline --no-native-line > gpurun_out/final/bench_det.log 2>&1; tail -1 gpurun_out/final/bench_det.log > gpurun_out/final/r02_bench_f32s_deterministic.json
-# rocprof kernel stats
-tools/profile_bench.sh c2 final/prof_f32s > gpurun_out/final/prof_f32s.txt 2>&1
-tools/profile_bench.sh c2 final/prof_f32 --dtype f32 > gpurun_out/final/prof_f32.txt 2>&1
-tools/profile_bench.sh c2 final/prof_bf16 --dtype bf16 > gpurun_out/final/prof_bf16.txt 2>&1
-tools/profile_bench.sh c3 final/prof_c3 > gpurun_out/final/prof_c3.txt 2>&1
-tools/profile_bench.sh c4 final/prof_c4 --steps 5 --warmup 2 > gpurun_out/final/prof_c4.txt 2>&1
-tools/profile_bench.sh c5hoi final/prof_c5hoi --encoder-only --steps 5 --warmup 2 > gpurun_out/final/prof_c5hoi.txt 2>&1
-tools/profile_bench.sh c5hhi final/prof_c5hhi --encoder-only --steps 5 --warmup 2 > gpurun_out/final/prof_c5hhi.txt 2>&1
-for f in gpurun_out/final/r02_bench_*.json; do python -c "
-import json,sys
-d=json.load(open('$f')); print('$f', d['dtype'][:12], round(d['ms_per_step'],4), round(d['value']), (d.get('roofline') or {}).get('frac'))"; done
+#!/bin/bash
+# usage (GPU box, repo root): tools/final_profiles.sh [round-tag, default r03]
+# Bench lines, rocprofv3 kernel stats and PMC counters of every BASELINE configuration -> gpurun_out/final/ (copy what is to
+# be kept into profiles/). Every step checks its exit code: a failed bench never leaves a half-written JSON behind.
+set -euo pipefail
+R=${1:-r03}
+STAGES=${2:-bench,prof,pmc}      # which parts to run
+OUT=gpurun_out/final
+mkdir -p $OUT
+bench() {   # bench <name> <bench.py args...>
+  local name=$1; shift
+  if python bench.py "$@" > $OUT/bench_$name.log 2>&1; then
+    tail -1 $OUT/bench_$name.log > $OUT/${R}_bench_$name.json
+    python tools/benchline.py $OUT/${R}_bench_$name.json $name
+  else
+    echo "bench $name FAILED"; tail -5 $OUT/bench_$name.log; return 1
+  fi
+}
+prof() {    # prof <config> <name> <bench.py args...>
+  local cfg=$1 name=$2; shift 2
+  tools/profile_bench.sh $cfg final/prof_$name "$@" > $OUT/prof_$name.txt 2>&1 || { echo "profile $name FAILED"; tail -5 $OUT/prof_$name.txt; return 1; }
+  cp gpurun_out/final/prof_${name}_kernel_stats.csv $OUT/${R}_bench_${name}_kernel_stats.csv
+}
+if [[ $STAGES == *bench* ]]; then
+bench f32s
+bench f32 --dtype f32 --no-cpu-baseline
+bench bf16 --dtype bf16 --no-cpu-baseline
+bench c3 --config c3 --no-cpu-baseline
+bench c4 --config c4 --no-cpu-baseline --steps 5 --warmup 2
+bench c5hoi --config c5hoi --no-cpu-baseline --steps 5 --warmup 2
+bench c5hoi_enc --config c5hoi --encoder-only --no-cpu-baseline --steps 5 --warmup 2
+bench c5hhi --config c5hhi --no-cpu-baseline --steps 5 --warmup 2
+bench c5hhi_enc --config c5hhi --encoder-only --no-cpu-baseline --steps 5 --warmup 2
+bench f32s_deterministic --deterministic --no-cpu-baseline --no-roofline --no-native-line
+bench f32s_forcedist --force-dist --no-cpu-baseline --no-roofline --no-native-line
+bench c4_forcedist --config c4 --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_forcedist --config c5hoi --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+fi
+if [[ $STAGES == *prof* ]]; then
+prof c2 f32s
+prof c2 f32 --dtype f32
+prof c2 bf16 --dtype bf16
+prof c3 c3
+prof c4 c4 --steps 5 --warmup 2
+prof c5hoi c5hoi --steps 5 --warmup 2
+prof c5hhi c5hhi --steps 5 --warmup 2
+fi
+if [[ $STAGES == *pmc* ]]; then
+python3 tools/pmc_collect.py f32s > $OUT/pmc_f32s.txt 2>&1 && cp gpurun_out/pmc_f32s.json $OUT/${R}_pmc_c2_f32s.json
+python3 tools/pmc_collect.py bf16 -- --dtype bf16 > $OUT/pmc_bf16.txt 2>&1 && cp gpurun_out/pmc_bf16.json $OUT/${R}_pmc_c2_bf16.json
+python3 tools/pmc_collect.py c3 -- --config c3 > $OUT/pmc_c3.txt 2>&1 && cp gpurun_out/pmc_c3.json $OUT/${R}_pmc_c3_bf16.json
+python3 tools/pmc_collect.py c4 -- --config c4 > $OUT/pmc_c4.txt 2>&1 && cp gpurun_out/pmc_c4.json $OUT/${R}_pmc_c4_bf16.json
+python3 tools/pmc_collect.py c5hoi -- --config c5hoi > $OUT/pmc_c5hoi.txt 2>&1 && cp gpurun_out/pmc_c5hoi.json $OUT/${R}_pmc_c5hoi_bf16.json
+python tools/gemm_bench.py 20 > $OUT/${R}_gemm_bench.txt 2>&1
+tail -n 4 $OUT/pmc_*.txt
+fi

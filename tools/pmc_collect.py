@@ -92,7 +92,7 @@ def main():
     res = {"csrc_sha": bench.csrc_sha(),
            "workload": {"config": a.config, "batch": a.batch, "frames": a.frames, "layers": a.layers, "dtype": a.dtype,
                         "encoder_only": bool(a.encoder_only), "bench_args": bench_args},
-           "steps_profiled": steps + warmup,
+           "steps_profiled": steps + warmup + 1,      # + the eager step bench.py runs to count the library's launches
            "correction": "read_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 half count); write_bytes = WRITE_SIZE KiB x 1024; all values per launch",
            "kernels": kernels}
     path = os.path.join(out_dir, f"pmc_{tag}.json")
@@ -102,7 +102,7 @@ def main():
     for name, o in sorted(kernels.items(), key=lambda kv: -kv[1].get("traffic_bytes", 0) * kv[1].get("launches", 0))[:14]:
         if not name.startswith("egx::"):
             continue
-        per_step = o.get("traffic_bytes", 0) * o.get("launches", 0) / (steps + warmup)
+        per_step = o.get("traffic_bytes", 0) * o.get("launches", 0) / (steps + warmup + 1)
         tot += per_step
         line = f"{name[:48]:48s} n={o.get('launches', 0):5d} read {o.get('read_bytes', 0) / 1e6:8.2f} MB write {o.get('write_bytes', 0) / 1e6:8.2f} MB /launch, {per_step / 1e6:8.1f} MB/step"
         wc = o.get("SQ_WAVE_CYCLES")

@@ -20,4 +20,4 @@ print(f"total kernel time {tot / 1e6:.2f} ms")
 for r in rows[:22]:
     print(r["Name"][:100].ljust(100), r["Calls"].rjust(6), ("%.1f" % (float(r["AverageNs"]) / 1e3)).rjust(9), "us avg", r["Percentage"].rjust(6), "%")
 PY
-tail -c 600 gpurun_out/$tag.log | grep -o '"ms_per_step": [0-9.]*'
+grep -o '"ms_per_step": [0-9.]*' gpurun_out/$tag.log | head -1 || true
