@@ -482,6 +482,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
+        fp.rot_mode = ffn_rot_mode();
         if (pack_weights(pk, st)) return 1;
         return fused_forward(fp, comp, st);
     }
@@ -632,6 +633,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
             bp.seed_ptr = cfg->seed_ptr;
+            bp.rot_mode = ffn_rot_mode();
             const int stage = cfg->bwd_stage;
             EGX_CHECK(stage >= 0 && stage <= 2, "bwd_stage=%d", stage);
             if (stage == 2) bp.zero_buf = nullptr;

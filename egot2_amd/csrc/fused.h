@@ -44,6 +44,7 @@ struct FusedFwdParams {
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
+    int rot_mode;           // hidden-block walk order of the FFN loops (ffn_rot_mode(): tuning aid EGX_FFN_ROT)
     float* tokens_out;      // (B, out_T, 128) or null when only the head output is wanted
     int out_T;              // tokens of every clip that leave the kernel (S, or egx_config.out_tokens)
     FusedHead head; float* logits_out;   // (B, n_out) when head.n_out > 0
@@ -95,7 +96,9 @@ static inline size_t fused_hid_bytes(int B, int d_ff, int bf16) {   // one layer
     return (size_t)B * FUSED_TOK_TILES * (d_ff / 16) * 256 * (bf16 ? 2 : 4);
 }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out);
-bool ffn_dw_bf16_planes();   // bf16 mode hands x1 / g2 over as bf16 planes (the LDS-ring weight-gradient kernel)
+bool ffn_dw_bf16_planes();
+int ffn_rot_mode();         // EGX_FFN_ROT: 4 (default): clips of an XCD start 0..3 hidden blocks apart; 0: every clip at its own block; 1: all in step;
+                            // 2 / 3: 4 / 2 phase groups per XCD; 5: 0..7 blocks apart   // bf16 mode hands x1 / g2 over as bf16 planes (the LDS-ring weight-gradient kernel)
 struct ReducePartialsParams;
 // out[k][i] += sum_z slab[k][z * n[k] + i] for up to SLAB_REDUCE_MAX arrays (three per layer: dW1, dW2^T, db1) in ONE launch
 constexpr int SLAB_REDUCE_MAX = 3 * FUSED_MAX_LAYERS;
@@ -137,6 +140,7 @@ struct FusedBwdParams {
     const float* ln_w; const float* ln_b;
     float eps;
     int nseg, n_layers, B, S, d_ff;
+    int rot_mode;           // hidden-block walk order of the FFN loops (ffn_rot_mode(): tuning aid EGX_FFN_ROT)
     const float* d_tokens;     // (B, out_T, 128), or null when the head is fused (then d_logits drives the backward)
     int out_T;                 // tokens of every clip that carry an upstream gradient (S, or egx_config.out_tokens)
     FusedHead head; const float* d_logits; int head_off;   // head_off: offset of the head section in the partial row

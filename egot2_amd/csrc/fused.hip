@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "fused.h"
 #include "fused_dev.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <vector>
 
@@ -567,9 +568,15 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             WRaw<CM> w2r[8];            // W2 columns of the current hidden block
             float4 b1r[2];
             const int nit = nhb / 4;
-            // Every CU walks the same weights: rotate the starting hidden block per clip so that the CUs of an XCD
-            // spread their L2 requests over all channels instead of hammering the same few lines in lockstep.
-            const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
+            // Every CU walks the same weights. All in step (rot_mode 1) they hammer the same few L2 lines at once (+2.5 % step
+            // time); every clip at its own starting block (rot_mode 0, round 2) the XCD's instantaneous working set is the whole
+            // 3-7.5 MB of packed weights and the 4 MB L2 thrashes (+150 MB of re-fetches per step). Default (rot_mode 4): the
+            // clips of an XCD (clip >> 3 counts them) start 0..3 blocks apart — same speed as mode 0, the traffic of mode 1.
+            const int rot = p.rot_mode == 0 ? (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit)
+                          : p.rot_mode == 2 ? (int)(((unsigned)(clip >> 3) & 3u) * (unsigned)nit / 4u)
+                          : p.rot_mode == 3 ? (int)(((unsigned)(clip >> 3) & 1u) * (unsigned)nit / 2u)
+                          : p.rot_mode == 4 ? (int)(((unsigned)(clip >> 3) & 3u) % (unsigned)nit)
+                          : p.rot_mode == 5 ? (int)(((unsigned)(clip >> 3) & 7u) % (unsigned)nit) : 0;
             auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
             // the dropout keep-scale 1 / (1 - p) is folded into the packed W1 (encoder.hip) and, here, into b1:
             // relu(s (W1 x + b1)) = s relu(W1 x + b1) for s > 0, so the epilogue has no multiply
@@ -868,6 +875,12 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
 #undef EGX_FWD_CASE
     EGX_LAUNCH_CHECK();
     return 0;
+}
+
+int ffn_rot_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_FFN_ROT"); v = e ? atoi(e) : 4; }
+    return v;
 }
 
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {

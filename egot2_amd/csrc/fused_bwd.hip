@@ -1260,7 +1260,11 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             const int nhb = p.d_ff / 32;
             const int nit = nhb / 4;
             const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-            const int rot = (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit);
+            const int rot = p.rot_mode == 0 ? (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit)
+                          : p.rot_mode == 2 ? (int)(((unsigned)(clip >> 3) & 3u) * (unsigned)nit / 4u)
+                          : p.rot_mode == 3 ? (int)(((unsigned)(clip >> 3) & 1u) * (unsigned)nit / 2u)
+                          : p.rot_mode == 4 ? (int)(((unsigned)(clip >> 3) & 3u) % (unsigned)nit)
+                          : p.rot_mode == 5 ? (int)(((unsigned)(clip >> 3) & 7u) % (unsigned)nit) : 0;
             auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
             WRaw<CM> w2r[2][FD / 32], w3r[8];
             uint32_t relu_word;
