@@ -54,7 +54,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--trials", type=int, default=0, help="timed repetitions of --steps (0 = auto: >= 5 and >= --min-seconds of timed region)")
-    ap.add_argument("--min-seconds", type=float, default=3.0, help="auto trials: total timed GPU work to aim for")
+    ap.add_argument("--min-seconds", type=float, default=3.6, help="auto trials: total timed GPU work to aim for")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch clips per GPU; strong: --batch clips in total, sharded over the ranks (SURVEY.md 8e)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi"],

@@ -500,3 +500,30 @@ def test_lossAV_mirror_matches_the_stock_modules(egx_lib, cuda):
     assert rel_err(ours.FC.weight.grad, fc.weight.grad) < 1e-5 and rel_err(ours.FC.bias.grad, fc.bias.grad) < 1e-5
     import numpy as np
     assert np.allclose(ours(x), z[:, 1].detach().cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("extra", [["--force-dist"], ["--force-dist", "--graph-collectives"], ["--force-dist", "--no-overlap"],
+                                   ["--config", "c5hhi", "--batch", "32", "--force-dist"]])
+def test_bench_distributed_code_paths_on_one_rank(cuda, extra):
+    """The RCCL code paths of bench.py (staged-backward overlap, collectives captured inside the step's hipGraph, single
+    collective, per-layer buckets on the wide path) with a one-rank process group: the JSON line must carry the exchange fields.
+    An N > 1 run needs a multi-GPU node; this pins that the paths start, capture and time without one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(43500 + os.getpid() % 2000 + len(extra))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--trials", "1", "--no-cpu-baseline", "--no-roofline",
+           "--no-optimizer-line", "--no-native-line"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["value"] > 0 and out["allreduce_us"] > 0
+    if "c5hhi" in extra:
+        assert out["overlap"] == "bucketed" and out["collectives_per_step"] >= 4      # 3 encoder layers + remainder + the decoder's buffer
+    elif "--no-overlap" in extra:
+        assert out["overlap"] == "none"
+    else:
+        assert out["overlap"] == "staged"

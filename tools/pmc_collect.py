@@ -73,6 +73,8 @@ def main():
                 seen[name].add(row["Dispatch_Id"])
             for name, s in seen.items():
                 launches[name][pname] = len(s)
+            if "--keep-raw" not in sys.argv:       # the raw counter CSVs are tens of MB per pass: gpurun merges back <= 64 MiB
+                subprocess.run(["rm", "-rf", d])
     kernels = {}
     for name, d in per.items():
         o = {}

@@ -21,3 +21,4 @@ for r in rows[:22]:
     print(r["Name"][:100].ljust(100), r["Calls"].rjust(6), ("%.1f" % (float(r["AverageNs"]) / 1e3)).rjust(9), "us avg", r["Percentage"].rjust(6), "%")
 PY
 grep -o '"ms_per_step": [0-9.]*' gpurun_out/$tag.log | head -1 || true
+rm -rf gpurun_out/$tag        # the raw trace (tens of MB); the summary CSV is kept
