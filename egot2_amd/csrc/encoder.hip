@@ -180,14 +180,21 @@ static size_t plane_elem_bytes(const egx_config* cfg) { return cfg->compute == E
 static size_t fused_x1p_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_hid_offset(cfg, segs, pl) + fused_hid_total(cfg, pl);
 }
-static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+// behind them: the input of every layer (L, N, d) and its Q | K | V rows (L, B, 48, 3d), fp32 (the backward loads instead of recomputing)
+static size_t fused_xin_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * pl.d * plane_elem_bytes(cfg), 256) : 0);
+}
+static size_t fused_qkv_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return fused_xin_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.N * pl.d * 4, 256);
+}
+static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return fused_qkv_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * 3 * pl.d * 4, 256);
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
 // partial sums, and the slab area shared by ffn_dw and the split-K GEMMs.
 struct FusedBwdScratch {
-    size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], x_in[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
+    size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes;
     size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
@@ -201,7 +208,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     size_t nd3 = (size_t)pl.B * FUSED_TOK_PAD * pl.d * 6;        // g2 leaves as three bf16 planes on the 48-row clip grid in split mode
     for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
         s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd3); s.attn_o[l] = take(cur, nd);
-        s.g1[l] = take(cur, nd); s.x_in[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
+        s.g1[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
     }
     for (int i = 0; i < pl.nseg; ++i) s.dseg[i] = take(cur, (size_t)pl.B * segs[i].T * pl.d * 4);
     s.P = fused_partial_len(pl.L, pl.nseg) + fused_head_partial_len(head_n_out);
@@ -479,6 +486,8 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
         fp.hid_out = store_hidden() ? (char*)saved + fused_hid_offset(cfg, segs, pl) : nullptr;
         fp.x1p_out = split_planes(cfg) ? (unsigned short*)((char*)saved + fused_x1p_offset(cfg, segs, pl)) : nullptr;
+        fp.xin_out = (float*)((char*)saved + fused_xin_offset(cfg, segs, pl));
+        fp.qkv_out = (float*)((char*)saved + fused_qkv_offset(cfg, segs, pl));
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
@@ -611,7 +620,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 fl.ffn_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN).key;
                 fl.res2_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2).key;
                 fl.x1_out = fptr(scratch, SC.x1[l]); fl.g2_out = fptr(scratch, SC.g2[l]); fl.attn_o_out = fptr(scratch, SC.attn_o[l]);
-                fl.g1_out = fptr(scratch, SC.g1[l]); fl.x_in_out = fptr(scratch, SC.x_in[l]); fl.dqkv_out = fptr(scratch, SC.dqkv[l]);
+                fl.g1_out = fptr(scratch, SC.g1[l]); fl.dqkv_out = fptr(scratch, SC.dqkv[l]);
+                fl.x_in_out = const_cast<float*>((const float*)((const char*)saved + fused_xin_offset(cfg, segs, pl))) + (size_t)l * N * d;      // saved by the forward
             }
             bp.ln_w = ln_w; bp.ln_b = ln_b; bp.eps = cfg->ln_eps;
             bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = B; bp.S = S; bp.d_ff = pl.dff;
@@ -624,6 +634,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             }
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
+            bp.saved_qkv = (const float*)((const char*)saved + fused_qkv_offset(cfg, segs, pl));
             bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
             bp.dhid_out = store_hidden() ? (char*)scratch + SC.dhid : nullptr;
             bp.xg_planes = split_planes(cfg) ? 1 : 0;

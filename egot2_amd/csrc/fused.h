@@ -56,6 +56,9 @@ struct FusedFwdParams {
                             // accumulator order, transposed by the weight-gradient kernel's LDS reads); fp32 or bf16 elements
     unsigned short* x1p_out;    // optional, CM_SPLIT: (L, 3, B*48, 128) the FFN input x1 (clip-padded token grid) as the three bf16 parts the FFN loop multiplies
                                 // (the backward then skips its LayerNorm1 recompute; ffn_dw reads these planes)
+    float* xin_out;         // (L, B*S, 128) the input of every layer: an operand of the in-projection weight gradient (small_dw)
+    float* qkv_out;         // (L, B, 48, 384) Q | K | V rows with bias on the clip-padded token grid: the backward loads them instead of recomputing the layer
+                            // input and its in-projection (22k + 17k of its 300k cycles in split mode; 24 KB + 69 KB per clip)
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
 };
@@ -123,7 +126,8 @@ struct FusedBwdLayer {
     uint32_t attn_thresh, res_thresh, ffn_thresh;
     float drop_inv;
     // per-token tensors handed to the weight-gradient kernels, all (B*S, .) token-major fp32 (g2_out: three bf16 planes
-    // [part][B*48][128] when FusedBwdParams::xg_planes is set)
+    // [part][B*48][128] when FusedBwdParams::xg_planes is set). x_in_out is NOT written by the backward: it points at the
+    // layer input the forward saved (FusedFwdParams::xin_out) and is only read by the weight-gradient launch.
     float* x1_out; float* g2_out; float* attn_o_out; float* g1_out; float* x_in_out; float* dqkv_out;
 };
 
@@ -146,6 +150,7 @@ struct FusedBwdParams {
     FusedHead head; const float* d_logits; int head_off;   // head_off: offset of the head section in the partial row
     const float* saved_pre;    // from the forward
     const float* saved_res;
+    const float* saved_qkv;    // (L, B, 48, 384) from the forward (FusedFwdParams::qkv_out)
     const uint32_t* relu_bits;
     int xg_planes;          // CM_SPLIT: g2_out leaves pre-split (what ffn_dw_stored_kernel<CM_SPLIT> reads) and x1_out is not
                             // written at all: the forward has saved x1 in that form (FusedFwdParams::x1p_out)

@@ -292,8 +292,25 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
         STAMP(2);
         EGX_PHASE();
+        // Q | K | V (with bias) leave for the backward pass, which loads them instead of recomputing the layer input (LayerNorm +
+        // embeddings + dropout hash) and its projection; the layer input itself follows after the projection (operand of the
+        // in-projection weight gradient). Order matters: a global load that is used while stores are in flight waits for the
+        // stores too, so the second half's weights and both halves' biases are requested BEFORE the stores they would wait for.
+        float* qkv_g = p.qkv_out + ((size_t)l * p.B + clip) * SP * (3 * FD);       // all 48 rows of the clip grid: unconditional stores
         // ---- QKV projection: 24 feature tiles, 6 per wave, K = 128
         {
+            WRaw<CM> wa[3][FD / 32];
+            float4 bbn[3];
+            auto request = [&](int half) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int kb = 0; kb < FD / 32; ++kb)
+                        wa[i][kb] = load_w<CM>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
+                    bbn[i] = *reinterpret_cast<const float4*>(w.in_proj_b + (wave * 6 + half * 3 + i) * 16 + 4 * q);
+                }
+            };
+            request(0);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 f32x4 acc[3][NT];
@@ -301,12 +318,6 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-                WRaw<CM> wa[3][FD / 32];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb)
-                        wa[i][kb] = load_w<CM>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
                 __builtin_amdgcn_sched_barrier(0);
                 pin_all(wa);
 #pragma unroll
@@ -321,14 +332,19 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
                     }
                 }
+                float4 bbv[3] = {bbn[0], bbn[1], bbn[2]};
+                __builtin_amdgcn_sched_barrier(0);
+                if (half == 0) request(1);          // into the registers the MFMAs above have just released
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     int f0 = (wave * 6 + half * 3 + i) * 16 + 4 * q;      // 0..383
-                    float4 bb = *reinterpret_cast<const float4*>(w.in_proj_b + f0);
+                    const float4 bb = bbv[i];
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         int tok = t * 16 + r;
                         float4 o = make_float4(acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w);
+                        *reinterpret_cast<float4*>(qkv_g + (size_t)tok * (3 * FD) + f0) = o;
                         if (f0 < FD) {
                             *reinterpret_cast<float4*>(Qs + tok * LDX + f0) = o;
                         } else if (f0 < 2 * FD) {
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     }
                 }
             }
+            store_block(p.xin_out + ((size_t)l * p.B + clip) * S * FD, Xs, S);      // no global load follows before the out-projection
             if (NT < 4) {   // zero the key padding columns SP..63 of V^T
                 for (int i = tid; i < FD * (64 - SP); i += 256) {
                     int c = i / (64 - SP), k = SP + i % (64 - SP);

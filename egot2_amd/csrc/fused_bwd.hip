@@ -1371,6 +1371,13 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             }
         }
         BSTAMP(4);
+        // Q | K | V rows of the clip (48 x 384 fp32, saved by the forward): QKV_PF float4 per thread, requested here and parked in
+        // registers under P5 - P7 (they take ~10k cycles to arrive from HBM); written to LDS when B4 / B5 / Gs are free, after P7.
+        constexpr int QKV_PF = SP * 96 / 256;
+        static_assert(SP * 96 % 256 == 0, "the Q | K | V rows must divide among the threads");
+        // (f32x4 values, not float4 structs: a struct copy is an llvm.memcpy global -> private -> LDS that pins qv[] in scratch memory)
+        const f32x4* qsrc = reinterpret_cast<const f32x4*>(p.saved_qkv + ((size_t)l * p.B + clip) * SP * (3 * FD));   // (L, B, 48, 384)
+        f32x4 qv[QKV_PF];
         // P5: LayerNorm1 backward with dy = dX1 (four wave partials in Gs, B2, B3, B4) + d_res2 (B1); x = res1 (B5, from P3).
         __syncthreads();
         ln_bwd_rows(S, w.norm1_w, p.eps,
@@ -1401,6 +1408,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res1, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);      // g1
+            },
+            [&] {       // behind the request for the LayerNorm weights: the Q | K | V rows (in flight until after P7)
+                int t_ = threadIdx.x;
+                asm volatile("" : "+v"(t_));        // keep the address arithmetic here (see EGX_PHASE)
+#pragma unroll
+                for (int k = 0; k < QKV_PF; ++k) qv[k] = qsrc[t_ + 256 * k];
             });
         __syncthreads();
         store_block(w.g1_out + tok0 * FD, B2, S);
@@ -1432,73 +1445,23 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                         make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
         }
         BSTAMP(6);
-        PackW<CM, 3, 4> wq_pf;        // first half of the W_in fragments of P9: in flight under the x_in recompute
-        pack_issue(wq_pf, w.in_proj_wp, wave * 6, 4, 0);
-        // P8: recompute the layer input x_in -> Gs
-        if (l == 0) {
-            load_block(Gs, p.saved_pre + tok0 * FD);
-            __syncthreads();
-            ln_rows(Gs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-                const float* addv = nullptr; const float* posr = nullptr;
+        // P8 / P9: Q -> B4, K -> B5, V -> Gs, loaded from what the forward saved (FusedFwdParams::qkv_out). Until round 3 the layer
+        // input was recomputed here (LayerNorm + embeddings + dropout hash) and projected again: 13k + 6k of the kernel's 136k
+        // cycles in bf16 mode, 22k + 17k of 300k in split mode.
+        {
+            int t_ = threadIdx.x;
+            asm volatile("" : "+v"(t_));
 #pragma unroll
-                for (int si = 0; si < FUSED_MAX_SEG; ++si)
-                    if (si < p.nseg && row >= p.seg[si].off && row < p.seg[si].off + p.seg[si].T) {
-                        addv = p.seg[si].add_vec;
-                        posr = p.seg[si].pos ? p.seg[si].pos + (size_t)(row - p.seg[si].off) * p.seg[si].pos_stride : nullptr;
-                    }
-                if (addv) { float a[32]; load32(addv + c0, a);
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) y[j] += a[j]; }
-                if (posr) { float a[32]; load32(posr + c0, a);
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) y[j] += a[j]; }
-                if (p.pos_thresh) {
-                    uint32_t orow = (uint32_t)(clip * S + row);
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
-                }
-                store32(Gs + row * LDX + c0, y);
-            });
-        } else {
-            const FusedBwdLayer& wp = p.layer[l - 1];
-            load_block(Gs, p.saved_res + ((size_t)(2 * (l - 1) + 1) * p.B + clip) * S * FD);
-            __syncthreads();
-            ln_rows(Gs, S, wp.norm2_w, wp.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-                store32(Gs + row * LDX + c0, y);
-            });
+            for (int k = 0; k < QKV_PF; ++k) {
+                // rows >= S: bias only (finite; masked like the recomputed ones were)
+                const int i = t_ + 256 * k, row = i / 96, c = (i - row * 96) * 4;
+                float* dst = c < FD ? B4 + c : (c < 2 * FD ? B5 + (c - FD) : Gs + (c - 2 * FD));
+                *reinterpret_cast<f32x4*>(dst + row * LDX) = qv[k];
+            }
         }
         __syncthreads();
-        store_block(w.x_in_out + tok0 * FD, Gs, S);
         BSTAMP(7);
         EGX_PHASE();
-        // P9: QKV recompute: Q -> B4, K -> B5, V -> Gs (written after the barrier: Gs is this GEMM's B operand)
-        {
-            f32x4 acc[6][NT];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            {
-                f32x4 (&a0)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[0]);
-                f32x4 (&a1)[3][NT] = *reinterpret_cast<f32x4 (*)[3][NT]>(&acc[3]);
-                PackW<CM, 3, 4> wq2;
-                pack_issue(wq2, w.in_proj_wp, wave * 6 + 3, 4, 0);      // second half streams in under the first half's MFMAs
-                gemm_packed<CM, 3, NT, 4>(a0, wq_pf, Gs, r, q);
-                gemm_packed<CM, 3, NT, 4>(a1, wq2, Gs, r, q);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                int f0 = (wave * 6 + i) * 16 + 4 * q;
-                float4 bb = *reinterpret_cast<const float4*>(w.in_proj_b + f0);
-                float* dst = f0 < FD ? B4 + f0 : (f0 < 2 * FD ? B5 + (f0 - FD) : Gs + (f0 - 2 * FD));
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    *reinterpret_cast<float4*>(dst + (t * 16 + r) * LDX) =
-                        make_float4(acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w);
-            }
-        }
-        __syncthreads();
         BSTAMP(8);
         EGX_PHASE();
         // P10: attention forward recompute + backward, wave = head. Q = B4, K = B5, V = Gs, dO = B3.

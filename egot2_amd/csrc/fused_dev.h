@@ -405,11 +405,18 @@ __device__ __forceinline__ void load32(const float* src, float (&v)[32]) {
 // Row-parallel LayerNorm backward (4 lanes per row). `get(row, c0, dy[32], x[32])` supplies the upstream gradient
 // and the pre-LN input of the lane's 32 features; `put(row, c0, dy, dx, dyxhat)` consumes the input gradient and
 // the per-row contribution to d(gamma) (= dy * xhat).
-template <class Get, class Put>
-__device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put) {
+// The lane's 32 weights are requested first and unconditionally; `after_w()` runs right behind that request, outside any branch:
+// global loads issued there (prefetches for a later phase) are YOUNGER than the weights, so the wait for the weights leaves
+// them in flight (a load issued before them, or under the row < S branch, would be waited for here).
+template <class Get, class Put, class Hook>
+__device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put, Hook&& after_w) {
     const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int c0 = part * 32;
+    f32x4 wq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(w + c0 + 4 * j);
+    after_w();
     if (row < S) {
-        const int c0 = part * 32;
         float dy[32], x[32], dx[32];
         get(row, c0, dy, x);
         float s = 0.f;
@@ -423,8 +430,7 @@ __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, 
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float4 wv = *reinterpret_cast<const float4*>(w + c0 + 4 * j);
-            float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+            float wj[4] = {wq[j][0], wq[j][1], wq[j][2], wq[j][3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int i = 4 * j + e;
@@ -446,6 +452,11 @@ __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, 
     } else {
         (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f);
     }
+}
+
+template <class Get, class Put>
+__device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put) {
+    ln_bwd_rows(S, w, eps, get, put, [] {});
 }
 
 // Column sums of a token-major LDS block over rows [r0, r1): four independent accumulators so the LDS reads

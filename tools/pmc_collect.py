@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 SQ1 = "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 SQ2 = "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT"
-GROUPS = {"traffic": [("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")], "sq": [("sq1", SQ1), ("sq2", SQ2)]}
+IF1 = "SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+GROUPS = {"ifetch": [("if1", IF1)], "traffic": [("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")], "sq": [("sq1", SQ1), ("sq2", SQ2)]}
 
 
 def kname(raw):
@@ -78,7 +79,7 @@ def main():
     kernels = {}
     for name, d in per.items():
         o = {}
-        for pname, counters in GROUPS["traffic"] + GROUPS["sq"]:
+        for pname, counters in GROUPS["traffic"] + GROUPS["sq"] + GROUPS["ifetch"]:
             n = launches[name].get(pname)
             if not n:
                 continue
