@@ -1089,31 +1089,47 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         lane = t_ & 63; r = lane & 15; q = lane >> 4;            \
     } while (0)
 
-    auto load_block = [&](float* dst, const float* src) {     // (S, 128) global -> token-major LDS, coalesced
-        for (int i = tid; i < S * (FD / 4); i += 256) {
-            int row = i >> 5, c = (i & 31) << 2;
-            *reinterpret_cast<float4*>(dst + row * LDX + c) = *reinterpret_cast<const float4*>(src + (size_t)row * FD + c);
-        }
-    };
     const bool dev_seed = p.seed_ptr != nullptr;
     const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
+    // Saved (S, 128) blocks come in through registers: requested one phase (or more) before their LDS block is free, written
+    // when it is. The requests are unconditional (clamped) loads of f32x4 VALUES: a load under a branch is waited for at the
+    // join, and float4 struct copies become memcpys through a scratch array.
+    constexpr int BPF = SP * (FD / 4) / 256;        // f32x4 per thread of one block
+    static_assert(SP * (FD / 4) % 256 == 0, "a block must divide among the threads");
+    auto blk_request = [&](f32x4 (&v)[BPF], const float* src) {
+        int t_ = threadIdx.x;
+        asm volatile("" : "+v"(t_));        // keep the address arithmetic here (see EGX_PHASE)
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        const int n = S * (FD / 4);
+#pragma unroll
+        for (int k = 0; k < BPF; ++k) { const int i = t_ + 256 * k; v[k] = s4[i < n ? i : n - 1]; }
+    };
+    auto blk_store = [&](const f32x4 (&v)[BPF], float* dst, float* dst2) {      // rows >= S stay as they are
+        int t_ = threadIdx.x;
+        asm volatile("" : "+v"(t_));
+#pragma unroll
+        for (int k = 0; k < BPF; ++k) {
+            const int i = t_ + 256 * k, row = i >> 5, c = (i & 31) << 2;
+            if (i < S * (FD / 4)) {
+                *reinterpret_cast<f32x4*>(dst + row * LDX + c) = v[k];
+                if (dst2) *reinterpret_cast<f32x4*>(dst2 + row * LDX + c) = v[k];
+            }
+        }
+    };
+    f32x4 pf_a[BPF], pf_b[BPF];       // res2 / res1 of the layer about to be processed (pf_a: `pre` for the token preparation)
+    blk_request(pf_a, p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD);
+    blk_request(pf_b, p.saved_res + ((size_t)(2 * (p.n_layers - 1)) * p.B + clip) * S * FD);
     for (int i = tid; i < 6 * BLK; i += 256) lds[i] = 0.f;
     __syncthreads();
+    // res2 -> B1 (LayerNorm2 backward; with the fused head also -> Gs, normalised in place below), res1 -> B5 (P3 / P5)
+    blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);
+    blk_store(pf_b, B5, nullptr);
     if (p.head.n_out > 0) {
         // Fused pooled head backward: rebuild the last layer's output tokens y = LN2(res2), pool them, run the head
         // forward/backward for this clip (wave 0) and broadcast d(tokens) = d(pooled) / S into Gs.
         const FusedBwdLayer& wl = p.layer[p.n_layers - 1];
         float* hp = part + p.head_off;
-        {   // res2 of the last layer -> Gs (normalised in place below) AND B1 (LayerNorm2 backward needs it again: P1 is skipped)
-            const float* src = p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD;
-            for (int i = tid; i < S * (FD / 4); i += 256) {
-                int row = i >> 5, c = (i & 31) << 2;
-                float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * FD + c);
-                *reinterpret_cast<float4*>(Gs + row * LDX + c) = v;
-                *reinterpret_cast<float4*>(B1 + row * LDX + c) = v;
-            }
-        }
         __syncthreads();
         ln_rows(Gs, S, wl.norm2_w, wl.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(Gs + row * LDX + c0, y);
@@ -1166,13 +1182,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
         const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
         const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
-        const float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
-        const float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
         float* pl = part + l * FUSED_P_LAYER;
 
         BSTAMP(0);
-        // P1: res2 -> B1 (already there when the fused head backward loaded it for the last layer)
-        if (!(p.head.n_out > 0 && l == p.n_layers - 1)) load_block(B1, sv_res2);
+        // P1: res2 -> B1, res1 -> B5: requested during the previous layer's P11 / P12 (the last layer's before the LDS zero fill)
+        if (l != p.n_layers - 1) {
+            blk_store(pf_a, B1, nullptr);
+            blk_store(pf_b, B5, nullptr);
+        }
         __syncthreads();
         // P2: LayerNorm2 backward. B1 <- d_res2 (in place), B3 <- dY * xhat, B2 <- g2 = d_res2 .* dropout2 mask
         ln_bwd_rows(S, w.norm2_w, p.eps,
@@ -1198,7 +1215,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         } else {
             pl[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
         }
-        load_block(B5, sv_res1);        // stays in B5 until LayerNorm1 backward (P5): one global read of res1 per layer
+        // (res1 is in B5 since P1 and stays there until LayerNorm1 backward, P5)
         __syncthreads();
         // x1 is only an operand of the weight-gradient kernel; in split / bf16 mode the forward has saved it, as bf16 planes
         if (!(CM != CM_F32 && p.xg_planes)) {
@@ -1662,6 +1679,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         BSTAMP(9);
         PackW<CM, 2, 4> wi_pf;        // W_in^T fragments (dQ part) of P12: in flight under the column sums
         pack_issue(wi_pf, w.in_proj_wtp, wave * 2, 12, 0);
+        // what the next stretch loads first, requested now (lands under P11 / P12): the next layer's residual sums, or `pre`
+        // (no branch around the requests: after layer 0 the second one re-reads `pre` and is dropped)
+        blk_request(pf_a, l > 0 ? p.saved_res + ((size_t)(2 * (l - 1) + 1) * p.B + clip) * S * FD : p.saved_pre + tok0 * FD);
+        blk_request(pf_b, l > 0 ? p.saved_res + ((size_t)(2 * (l - 1)) * p.B + clip) * S * FD : p.saved_pre + tok0 * FD);
         // P11: in_proj_b partials
         if (tid < 128) {
             pl[768 + tid] = colsum_lds(B4, 0, S, tid);
@@ -1703,7 +1724,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     // ---- token preparation backward: Gs = d(x0)
     {
         float* pg = part + p.n_layers * FUSED_P_LAYER;
-        load_block(B1, p.saved_pre + tok0 * FD);
+        blk_store(pf_a, B1, nullptr);       // `pre`, requested before the last P11
         __syncthreads();
         ln_bwd_rows(S, p.ln_w, p.eps,
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
