@@ -129,8 +129,6 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     const bool dev_seed = p.seed_ptr != nullptr;
     const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
-    // zero the padded rows once so that padded tokens stay finite everywhere
-    for (int i = tid; i < SP * LDX; i += 256) { Xs[i] = 0.f; X1[i] = 0.f; }
     if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
     __syncthreads();
     auto seg_of = [&](int i) {      // wave-uniform copy of descriptor i in scalar registers
@@ -235,6 +233,13 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             issue_all(SA{}, cur);
             issue_all(SB{}, n1);
         }
+        // zero the padded rows once so that padded tokens stay finite everywhere: 16-byte writes, under the first steps' loads
+        static_assert((SP * LDX) % 4 == 0, "blocks are zeroed in 16-byte pieces");
+        for (int i = tid; i < SP * LDX / 4; i += 256) {
+            reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0, 0, 0, 0};
+            reinterpret_cast<f32x4*>(X1)[i] = f32x4{0, 0, 0, 0};
+        }
+        __syncthreads();
         for (;;) {
             if (!valid(cur)) break;
             {
@@ -253,32 +258,45 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     }
     __syncthreads();
     STAMP(1);
-    // save pre-LN projections (token order) and apply the shared LN + embeddings
-    store_block(p.saved_pre + (size_t)clip * S * FD, Xs, S);
-    __syncthreads();
-    ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-        int sgi = 0;
-        while (sgi + 1 < p.nseg && row >= segtab[sgi + 1].off) ++sgi;
-        const FusedSeg sg = segtab[sgi];
-        int t = row - sg.off;
+    // save pre-LN projections (token order) and apply the shared LN + embeddings. The task-embedding and positional rows of the
+    // lane's token are requested unconditionally behind the LayerNorm weights (a missing table reads the LayerNorm weights and
+    // is scaled by zero), the save follows them: nothing in this phase waits for a store or for a load under a branch.
+    {
+        f32x4 av[8], pv[8];
+        float a_on = 0.f, p_on = 0.f;
+        ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (sg.add_vec) {
-                float4 a = *reinterpret_cast<const float4*>(sg.add_vec + c0 + 4 * j);
-                y[4 * j] += a.x; y[4 * j + 1] += a.y; y[4 * j + 2] += a.z; y[4 * j + 3] += a.w;
-            }
-            if (sg.pos) {
-                float4 a = *reinterpret_cast<const float4*>(sg.pos + (size_t)t * sg.pos_stride + c0 + 4 * j);
-                y[4 * j] += a.x; y[4 * j + 1] += a.y; y[4 * j + 2] += a.z; y[4 * j + 3] += a.w;
-            }
-        }
-        if (p.pos_thresh) {
-            uint32_t orow = (uint32_t)(clip * S + row);
+            for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
-        }
-        store32(Xs + row * LDX + c0, y);
-    });
+                for (int e = 0; e < 4; ++e) y[4 * j + e] = __builtin_fmaf(p_on, pv[j][e], __builtin_fmaf(a_on, av[j][e], y[4 * j + e]));     // (y + emb) + pos
+            if (p.pos_thresh) {
+                uint32_t orow = (uint32_t)(clip * S + row);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
+            }
+            store32(Xs + row * LDX + c0, y);
+        }, [&] {
+            int t_ = threadIdx.x;
+            asm volatile("" : "+v"(t_));
+            int row = t_ >> 2;
+            row = row < S ? row : S - 1;
+            const int c0 = (t_ & 3) * 32;
+            int sgi = 0;
+            while (sgi + 1 < p.nseg && row >= segtab[sgi + 1].off) ++sgi;
+            const FusedSeg sg = segtab[sgi];
+            const float* ap = sg.add_vec ? sg.add_vec + c0 : p.ln_w + c0;
+            const float* pp = sg.pos ? sg.pos + (size_t)(row - sg.off) * sg.pos_stride + c0 : p.ln_w + c0;
+            a_on = sg.add_vec ? 1.f : 0.f;
+            p_on = sg.pos ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                av[j] = *reinterpret_cast<const f32x4*>(ap + 4 * j);
+                pv[j] = *reinterpret_cast<const f32x4*>(pp + 4 * j);
+            }
+            store_block(p.saved_pre + (size_t)clip * S * FD, Xs, S);
+            __syncthreads();        // the LayerNorm below writes Xs in place
+        });
+    }
     __syncthreads();
 
     for (int l = 0; l < p.n_layers; ++l) {
@@ -515,8 +533,6 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         // CM_SPLIT: x1 is also split into bf16 operand planes for the FFN loop (over Q / K, dead since the out-projection)
         unsigned short* XP = reinterpret_cast<unsigned short*>(Qs);
         constexpr int XPS = SP * LDXH;
-        store_block(sv_res1, X1, S);
-        __syncthreads();
         ln_rows(X1, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(X1 + row * LDX + c0, y);
             if constexpr (CM == CM_SPLIT) {
@@ -524,6 +540,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 split32(y, h, m, lo);
                 store_parts32(XP + row * LDXH + c0, (size_t)XPS, h, m, lo);
             }
+        }, [&] {       // behind the request for the LayerNorm weights, so that their wait does not include these stores
+            store_block(sv_res1, X1, S);
+            __syncthreads();        // X1 is normalised in place
         });
         if constexpr (CM == CM_SPLIT) {     // padded rows of the planes: zero operands
             for (int i = tid; i < 3 * (SP - S) * (LDXH / 4); i += 256) {
@@ -772,11 +791,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
         {
             bool last = (l + 1 == p.n_layers);
-            store_block(sv_res2, X1, S);        // the LayerNorm below leaves X1 alone
             ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 if (last && p.tokens_out && row < p.out_T) store32(p.tokens_out + ((size_t)clip * p.out_T + row) * FD + c0, y);
                 if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
-            });
+            }, [&] { store_block(sv_res2, X1, S); });        // (the LayerNorm leaves X1 alone)
         }
         __syncthreads();
         STAMP(9);

@@ -1120,7 +1120,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     f32x4 pf_a[BPF], pf_b[BPF];       // res2 / res1 of the layer about to be processed (pf_a: `pre` for the token preparation)
     blk_request(pf_a, p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD);
     blk_request(pf_b, p.saved_res + ((size_t)(2 * (p.n_layers - 1)) * p.B + clip) * S * FD);
-    for (int i = tid; i < 6 * BLK; i += 256) lds[i] = 0.f;
+    static_assert((6 * BLK) % 4 == 0, "the blocks are zeroed in 16-byte pieces");
+    for (int i = tid; i < 6 * BLK / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
     // res2 -> B1 (LayerNorm2 backward; with the fused head also -> Gs, normalised in place below), res1 -> B5 (P3 / P5)
     blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);

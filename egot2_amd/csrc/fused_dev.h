@@ -329,12 +329,21 @@ __device__ __forceinline__ float quad_sum4(float v) {
     v += __shfl_xor(v, 2, 64);
     return v;
 }
-template <class Fn>
+template <class Fn, class Hook>
 __device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __restrict__ w, const float* __restrict__ b,
-                                        float eps, Fn&& fn) {
+                                        float eps, Fn&& fn, Hook&& after_w) {
     const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int c0 = part * 32;
+    // the lane's weights and biases are requested first and unconditionally, `after_w()` runs right behind the request and
+    // outside any branch (see ln_bwd_rows): stores and prefetches issued there are younger than the weights
+    f32x4 wq[8], bq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wq[j] = *reinterpret_cast<const f32x4*>(w + c0 + 4 * j);
+        bq[j] = *reinterpret_cast<const f32x4*>(b + c0 + 4 * j);
+    }
+    after_w();
     if (row < S) {
-        const int c0 = part * 32;
         float x[32], y[32];
         float s = 0.f;
 #pragma unroll
@@ -350,12 +359,8 @@ __device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __
         float rstd = rsqrtf(quad_sum4(ss) * (1.f / FD) + eps);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float4 wv = *reinterpret_cast<const float4*>(w + c0 + 4 * j);
-            float4 bv = *reinterpret_cast<const float4*>(b + c0 + 4 * j);
-            y[4 * j + 0] = (x[4 * j + 0] - mean) * rstd * wv.x + bv.x;
-            y[4 * j + 1] = (x[4 * j + 1] - mean) * rstd * wv.y + bv.y;
-            y[4 * j + 2] = (x[4 * j + 2] - mean) * rstd * wv.z + bv.z;
-            y[4 * j + 3] = (x[4 * j + 3] - mean) * rstd * wv.w + bv.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[4 * j + e] = (x[4 * j + e] - mean) * rstd * wq[j][e] + bq[j][e];
         }
         fn(row, c0, x, y);
     } else {
@@ -363,6 +368,11 @@ __device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __
         (void)quad_sum4(0.f);
         (void)quad_sum4(0.f);
     }
+}
+template <class Fn>
+__device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __restrict__ w, const float* __restrict__ b,
+                                        float eps, Fn&& fn) {
+    ln_rows(buf, S, w, b, eps, fn, [] {});
 }
 __device__ __forceinline__ void store32(float* dst, const float (&v)[32]) {
 #pragma unroll
