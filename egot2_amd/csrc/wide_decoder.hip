@@ -271,6 +271,41 @@ __global__ __launch_bounds__(256) void dec_embed_grad_kernel(const int64_t* __re
     if (grp == 0 && c < d) d_emb[(size_t)v * d + c] += ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * scale;
 }
 
+// Small vocabularies (V <= 64: the EgoT2-g task vocabularies): one workgroup per 64 columns walks ALL rows once, every row's
+// gradient is loaded unconditionally (eight rows in flight per wave) and added to the LDS accumulator row of its token; four
+// waves take a quarter of the rows each and are summed in wave order (deterministic). The per-(token, column) kernel above
+// scans the token list once per vocabulary entry with a dependent load per match: 43-61 us at B * sy = 512 against 6 here.
+constexpr int EMB_VMAX = 64;
+__global__ __launch_bounds__(256) void dec_embed_grad_small_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dy, float* __restrict__ d_emb,
+                                                                   float scale, int rows, int d, int V, uint64_t key, uint32_t thresh, float inv) {
+    __shared__ float acc[4][EMB_VMAX][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
+    for (int v = 0; v < V; ++v) acc[grp][v][lane] = 0.f;
+    const int cc = c < d ? c : d - 1;
+    const int per = (rows + 3) / 4, r0 = grp * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int row = r0; row < r1; row += 8) {
+        float g[8];
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = row + u < r1 ? row + u : r1 - 1;
+            g[u] = dy[(size_t)rr * d + cc];
+            t[u] = (int)tok[rr];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (row + u >= r1) break;
+            float gv = g[u];
+            if (thresh) gv *= drop_scale(key, (uint32_t)(row + u), (uint32_t)cc, thresh, inv);
+            if (t[u] >= 0 && t[u] < V) acc[grp][t[u]][lane] += gv;      // lane-private column: no conflict, row order kept
+        }
+    }
+    __syncthreads();
+    if (c < d)
+        for (int v = grp; v < V; v += 4)
+            d_emb[(size_t)v * d + c] += ((acc[0][v][lane] + acc[1][v][lane]) + (acc[2][v][lane] + acc[3][v][lane])) * scale;
+}
+
 struct DLayer {
     size_t w_sa_in, w_sa_in_t, w_sa_o, w_sa_o_t, w_q, w_q_t, w_kv, w_kv_t, w_ca_o, w_ca_o_t, w1, w1_t, w2, w2_t;   // bf16 weights
     size_t x32, x16, qkv, sa, res1, st1, x1_32, x1_16, q, kv, ca, res2, st2, x2_32, x2_16, hid, res3, st3;
@@ -281,7 +316,10 @@ struct DPlan {
     size_t zero, mem16, xL32, qkv32;
     DLayer layer[16];
     size_t saved_bytes;
-    size_t gA, gB, dres, dy16, dhid16, dattn16, dqkv16, dqkv32, dq16, dkv16, slab_all, slab_all_bytes, lnpart, cspart, fcslab, fcslab_bytes, scratch_bytes;
+    size_t gA, gB, dres, dattn16, dqkv32, slab_all, slab_all_bytes, lnpart, cspart, cspart_side, fcslab, fcslab_bytes, scratch_bytes;
+    // operands of the weight-gradient GEMMs: one buffer per (layer, use) — those GEMMs run on a side stream beside the input-gradient
+    // chain (decoder_bwd), so the chain must not overwrite an operand while its weight gradient may still be reading it
+    struct { size_t dy16[3], dhid16, dqkv16, dq16, dkv16; } g[16];
 };
 size_t dtake(size_t& cur, size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
 size_t dmax(size_t a, size_t b) { return a > b ? a : b; }
@@ -330,8 +368,12 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
 
     size_t sc = 0;
     pl.gA = dtake(sc, Md * d * 4); pl.gB = dtake(sc, Md * d * 4); pl.dres = dtake(sc, Md * d * 4);
-    pl.dy16 = dtake(sc, Md * d * 2); pl.dhid16 = dtake(sc, Md * dff * 2); pl.dattn16 = dtake(sc, Md * d * 2);
-    pl.dqkv16 = dtake(sc, Md * 3 * d * 2); pl.dqkv32 = dtake(sc, Md * 3 * d * 4); pl.dq16 = dtake(sc, Md * d * 2); pl.dkv16 = dtake(sc, Nm * 2 * d * 2);
+    pl.dattn16 = dtake(sc, Md * d * 2); pl.dqkv32 = dtake(sc, Md * 3 * d * 4);
+    for (int l = 0; l < pl.L; ++l) {
+        for (int u = 0; u < 3; ++u) pl.g[l].dy16[u] = dtake(sc, Md * d * 2);
+        pl.g[l].dhid16 = dtake(sc, Md * dff * 2); pl.g[l].dqkv16 = dtake(sc, Md * 3 * d * 2);
+        pl.g[l].dq16 = dtake(sc, Md * d * 2); pl.g[l].dkv16 = dtake(sc, Nm * 2 * d * 2);
+    }
     size_t all = 0;
     auto add = [&](int M, int Nn, size_t K) { all += align_up(wide_gemm_tn_scratch(M, Nn, (int)K), 256); };
     for (int l = 0; l < pl.L; ++l) {
@@ -343,6 +385,7 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
     size_t cs = dmax(wide_colsum_scratch((int)Md, 3 * pl.d), wide_colsum_scratch((int)Nm, 2 * pl.d));
     cs = dmax(cs, (size_t)(4 * cdiv((int)Md, 256) + 4) * pl.dff * 4);
     pl.cspart = dtake(sc, cs);
+    pl.cspart_side = dtake(sc, cs);
     pl.fcslab_bytes = dmax(gemm_scratch_bytes(2, pl.V, pl.d, (int)Md), gemm_scratch_bytes(1, (int)Md, pl.d, pl.V));
     pl.fcslab_bytes = dmax(pl.fcslab_bytes, dmax(gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)Md), gemm_scratch_bytes(1, (int)Md, pl.d, 3 * pl.d)));
     pl.fcslab = dtake(sc, pl.fcslab_bytes);
@@ -357,6 +400,33 @@ DDrop ddrop(int training, float p, uint64_t seed, uint32_t layer, uint32_t site)
     return dr;
 }
 enum { DS_SELF = 1, DS_SA_OUT = 2, DS_CROSS = 3, DS_CA_OUT = 4, DS_FFN = 5, DS_FFN_OUT = 6, DS_EMBED = 7 };
+
+// The decoder's weight gradients (small TN GEMMs over B * sy target rows, bias column sums) are off the critical path of its
+// backward: the input-gradient chain is ~16 dependent launches per layer that each occupy 16-64 CUs. They run on a library-owned
+// side stream, forked off the caller's stream by an event after the kernel that produces their operand and joined before the
+// slab reduction (works the same under stream capture: the side stream's launches become a parallel branch of the graph).
+// EGX_DEC_SIDE=0 keeps everything on the caller's stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[8] = {};
+    hipEvent_t kv_ev[16] = {};      // forward: layer l's K | V projection of the memory is done
+    int next = 0;
+    bool on = false;
+};
+SideStream& side_stream() {
+    static SideStream S;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char* e = getenv("EGX_DEC_SIDE");
+        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking) == hipSuccess) {
+            S.on = true;
+            for (auto& v : S.ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) S.on = false;
+            for (auto& v : S.kv_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) S.on = false;
+        }
+    }
+    return S;
+}
 
 }  // namespace
 
@@ -408,19 +478,34 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
                            at<float>(saved, pl.layer[0].x32), at<bf16_t>(saved, pl.layer[0].x16), Md, pl.sy, d, pl.V, de.key, de.thresh, de.inv);
         EGX_LAUNCH_CHECK();
     }
-    auto nt = [&](const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const float* bias, float* Cf, bf16_t* Cb, int relu,
-                  const DDrop& dr, const float* residual) -> int {
+    auto nt_on = [&](hipStream_t s_, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const float* bias, float* Cf, bf16_t* Cb, int relu,
+                     const DDrop& dr, const float* residual) -> int {
         WideGemmParams g;
         g.A = A; g.B = W; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.Cf = Cf; g.Cb = Cb; g.ldc = N; g.bias = bias; g.relu = relu;
         g.drop_key = dr.key; g.drop_thresh = dr.thresh; g.drop_inv = dr.inv; g.residual = residual; g.ldr = N; g.zero_page = zero;
-        return wide_gemm_nt(g, st);
+        return wide_gemm_nt(g, s_);
     };
+    auto nt = [&](const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const float* bias, float* Cf, bf16_t* Cb, int relu,
+                  const DDrop& dr, const float* residual) -> int { return nt_on(st, A, lda, W, M, N, K, bias, Cf, Cb, relu, dr, residual); };
     auto ln = [&](const float* x, const float* w, const float* b, float* stats, float* y32, bf16_t* y16) -> int {
         WideLnFwdParams lp;
         lp.x = x; lp.w = w; lp.b = b; lp.eps = cfg->ln_eps; lp.stats = stats; lp.y32 = y32; lp.y16 = y16; lp.rows = Md; lp.d = d;
         return wide_ln_fwd(lp, st);
     };
     const DDrop none;
+    // the K | V projections of the memory (the one large GEMM of a layer) depend on nothing the target-token chain computes: all
+    // of them go to the side stream now, beside the chain's 16-WG launches; a layer's cross-attention waits for its own
+    SideStream& SS = side_stream();
+    if (SS.on) {
+        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
+        EGX_HIP(hipEventRecord(e, st));
+        EGX_HIP(hipStreamWaitEvent(SS.s, e, 0));
+        for (int l = 0; l < pl.L; ++l) {
+            const DLayer& o = pl.layer[l];
+            if (nt_on(SS.s, mem16, d, cat<bf16_t>(saved, o.w_kv), Nm, 2 * d, d, layers[l].ca_in_b + d, nullptr, at<bf16_t>(saved, o.kv), 0, none, nullptr)) return 1;
+            EGX_HIP(hipEventRecord(SS.kv_ev[l], SS.s));
+        }
+    }
     for (int l = 0; l < pl.L; ++l) {
         const DLayer& o = pl.layer[l];
         const egx_dec_layer& w = layers[l];
@@ -453,7 +538,8 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
         if (ln(cat<float>(saved, o.res1), w.norm1_w, w.norm1_b, at<float>(saved, o.st1), at<float>(saved, o.x1_32), at<bf16_t>(saved, o.x1_16))) return 1;
         // cross-attention onto the memory
         if (nt(cat<bf16_t>(saved, o.x1_16), d, cat<bf16_t>(saved, o.w_q), Md, d, d, w.ca_in_b, nullptr, at<bf16_t>(saved, o.q), 0, none, nullptr)) return 1;
-        if (nt(mem16, d, cat<bf16_t>(saved, o.w_kv), Nm, 2 * d, d, w.ca_in_b + d, nullptr, at<bf16_t>(saved, o.kv), 0, none, nullptr)) return 1;
+        if (SS.on) EGX_HIP(hipStreamWaitEvent(st, SS.kv_ev[l], 0));
+        else if (nt(mem16, d, cat<bf16_t>(saved, o.w_kv), Nm, 2 * d, d, w.ca_in_b + d, nullptr, at<bf16_t>(saved, o.kv), 0, none, nullptr)) return 1;
         {
             DecAttnParams a;
             memset(&a, 0, sizeof(a));
@@ -495,18 +581,27 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     float* gA = at<float>(scratch, pl.gA);
     float* gB = at<float>(scratch, pl.gB);
     float* dres = at<float>(scratch, pl.dres);
-    bf16_t* dy16 = at<bf16_t>(scratch, pl.dy16);
-    bf16_t* dhid16 = at<bf16_t>(scratch, pl.dhid16);
     bf16_t* dattn16 = at<bf16_t>(scratch, pl.dattn16);
-    bf16_t* dqkv16 = at<bf16_t>(scratch, pl.dqkv16);
-    bf16_t* dq16 = at<bf16_t>(scratch, pl.dq16);
-    bf16_t* dkv16 = at<bf16_t>(scratch, pl.dkv16);
     void* lnpart = at<char>(scratch, pl.lnpart);
     float* cspart = at<float>(scratch, pl.cspart);
+    float* cspart_side = at<float>(scratch, pl.cspart_side);
+    // side stream for the weight gradients: fork() orders it behind everything enqueued on `st` so far
+    SideStream& SS = side_stream();
+    hipStream_t sd = SS.on ? SS.s : st;
+    bool forked = false;
+    auto fork = [&]() -> int {
+        if (!SS.on) return 0;
+        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
+        EGX_HIP(hipEventRecord(e, st));
+        EGX_HIP(hipStreamWaitEvent(sd, e, 0));
+        forked = true;
+        return 0;
+    };
     const bf16_t* mem16 = cat<bf16_t>(saved, pl.mem16);
 
     WideReduceBatch rb;
     size_t slab_cur = 0;
+    // (enqueued on the side stream; the caller forks first)
     auto dw_tn = [&](const bf16_t* dy, int ldy, const bf16_t* x, int ldx, float* dW, int n_out, int k_in, int tokens_k) -> int {
         if (!dW) return 0;
         WideGemmParams t;
@@ -516,7 +611,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         EGX_CHECK(slab_cur + need <= pl.slab_all_bytes, "decoder backward: slab region exhausted");
         void* region = at<char>(scratch, pl.slab_all) + slab_cur;
         slab_cur += need;
-        return wide_gemm_tn(t, region, st, &rb);
+        return wide_gemm_tn(t, region, sd, &rb);
     };
     auto nt = [&](const bf16_t* A, int lda, const bf16_t* Wt, int M, int N, int K, float* Cf, bf16_t* Cb, const float* residual,
                   const bf16_t* mask, float mask_scale, float* colsum) -> int {
@@ -525,7 +620,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         g.residual = residual; g.ldr = N; g.mask = mask; g.ldm = N; g.mask_scale = mask_scale; g.colsum = colsum; g.zero_page = zero;
         return wide_gemm_nt(g, st);
     };
-    auto ln_bwd = [&](const float* dy, const float* pre, const float* stats, const float* w, const DDrop& outm, float* dw, float* db, float* dbias) -> int {
+    auto ln_bwd = [&](const float* dy, const float* pre, const float* stats, const float* w, const DDrop& outm, float* dw, float* db, float* dbias, bf16_t* dy16) -> int {
         WideLnBwdParams b;
         b.dy = dy; b.pre = pre; b.stats = stats; b.w = w; b.dx32 = dres; b.dx16 = dy16; b.rows = Md; b.d = d;
         b.out_key = outm.key; b.out_thresh = outm.thresh; b.out_inv = outm.inv;
@@ -552,21 +647,28 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         const DLayer& o = pl.layer[l];
         const egx_dec_layer& w = layers[l];
         const egx_dec_layer_grads& gw = grads[l];
+        bf16_t* dy16a = at<bf16_t>(scratch, pl.g[l].dy16[0]);
+        bf16_t* dy16b = at<bf16_t>(scratch, pl.g[l].dy16[1]);
+        bf16_t* dy16c = at<bf16_t>(scratch, pl.g[l].dy16[2]);
+        bf16_t* dhid16 = at<bf16_t>(scratch, pl.g[l].dhid16);
+        bf16_t* dqkv16 = at<bf16_t>(scratch, pl.g[l].dqkv16);
+        bf16_t* dq16 = at<bf16_t>(scratch, pl.g[l].dq16);
+        bf16_t* dkv16 = at<bf16_t>(scratch, pl.g[l].dkv16);
         // FFN
         if (ln_bwd(g, cat<float>(saved, o.res3), cat<float>(saved, o.st3), w.norm3_w, ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_FFN_OUT),
-                   gw.norm3_w, gw.norm3_b, gw.lin2_b)) return 1;
-        if (dw_tn(dy16, d, cat<bf16_t>(saved, o.hid), dff, gw.lin2_w, d, dff, Md)) return 1;
-        if (nt(dy16, d, cat<bf16_t>(saved, o.w2_t), Md, dff, d, nullptr, dhid16, nullptr, cat<bf16_t>(saved, o.hid),
+                   gw.norm3_w, gw.norm3_b, gw.lin2_b, dy16a)) return 1;
+        if (fork() || dw_tn(dy16a, d, cat<bf16_t>(saved, o.hid), dff, gw.lin2_w, d, dff, Md)) return 1;
+        if (nt(dy16a, d, cat<bf16_t>(saved, o.w2_t), Md, dff, d, nullptr, dhid16, nullptr, cat<bf16_t>(saved, o.hid),
                ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_FFN).inv, gw.lin1_b ? cspart : nullptr)) return 1;
         if (gw.lin1_b && wide_reduce_rows(cspart, wide_gemm_nt_colsum_rows(Md, dff), dff, gw.lin1_b, st)) return 1;
-        if (dw_tn(dhid16, dff, cat<bf16_t>(saved, o.x2_16), d, gw.lin1_w, dff, d, Md)) return 1;
+        if (fork() || dw_tn(dhid16, dff, cat<bf16_t>(saved, o.x2_16), d, gw.lin1_w, dff, d, Md)) return 1;
         float* g1 = (g == gA) ? gB : gA;
         if (nt(dhid16, dff, cat<bf16_t>(saved, o.w1_t), Md, d, dff, g1, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         // cross-attention
         if (ln_bwd(g1, cat<float>(saved, o.res2), cat<float>(saved, o.st2), w.norm2_w, ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_CA_OUT),
-                   gw.norm2_w, gw.norm2_b, gw.ca_out_b)) return 1;
-        if (dw_tn(dy16, d, cat<bf16_t>(saved, o.ca), d, gw.ca_out_w, d, d, Md)) return 1;
-        if (nt(dy16, d, cat<bf16_t>(saved, o.w_ca_o_t), Md, d, d, nullptr, dattn16, nullptr, nullptr, 1.f, nullptr)) return 1;
+                   gw.norm2_w, gw.norm2_b, gw.ca_out_b, dy16b)) return 1;
+        if (fork() || dw_tn(dy16b, d, cat<bf16_t>(saved, o.ca), d, gw.ca_out_w, d, d, Md)) return 1;
+        if (nt(dy16b, d, cat<bf16_t>(saved, o.w_ca_o_t), Md, d, d, nullptr, dattn16, nullptr, nullptr, 1.f, nullptr)) return 1;
         {
             DecAttnParams a;
             memset(&a, 0, sizeof(a));
@@ -578,9 +680,10 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
             a.drop_key = da.key; a.drop_thresh = da.thresh; a.drop_inv = da.inv;
             if (dec_attn<true>(a, dh, false, st)) return 1;
         }
+        if (fork()) return 1;
         if (gw.ca_in_b) {
-            if (wide_colsum_bf16(dq16, Md, d, d, gw.ca_in_b, cspart, st)) return 1;
-            if (wide_colsum_bf16(dkv16, Nm, 2 * d, 2 * d, gw.ca_in_b + d, cspart, st)) return 1;
+            if (wide_colsum_bf16(dq16, Md, d, d, gw.ca_in_b, cspart_side, sd)) return 1;
+            if (wide_colsum_bf16(dkv16, Nm, 2 * d, 2 * d, gw.ca_in_b + d, cspart_side, sd)) return 1;
         }
         if (dw_tn(dq16, d, cat<bf16_t>(saved, o.x1_16), d, gw.ca_in_w, d, d, Md)) return 1;
         if (dw_tn(dkv16, 2 * d, mem16, d, gw.ca_in_w ? gw.ca_in_w + (size_t)d * d : nullptr, 2 * d, d, Nm)) return 1;
@@ -592,9 +695,9 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         if (nt(dq16, d, cat<bf16_t>(saved, o.w_q_t), Md, d, d, g2, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         // self-attention
         if (ln_bwd(g2, cat<float>(saved, o.res1), cat<float>(saved, o.st1), w.norm1_w, ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_SA_OUT),
-                   gw.norm1_w, gw.norm1_b, gw.sa_out_b)) return 1;
-        if (dw_tn(dy16, d, cat<bf16_t>(saved, o.sa), d, gw.sa_out_w, d, d, Md)) return 1;
-        if (nt(dy16, d, cat<bf16_t>(saved, o.w_sa_o_t), Md, d, d, nullptr, dattn16, nullptr, nullptr, 1.f, nullptr)) return 1;
+                   gw.norm1_w, gw.norm1_b, gw.sa_out_b, dy16c)) return 1;
+        if (fork() || dw_tn(dy16c, d, cat<bf16_t>(saved, o.sa), d, gw.sa_out_w, d, d, Md)) return 1;
+        if (nt(dy16c, d, cat<bf16_t>(saved, o.w_sa_o_t), Md, d, d, nullptr, dattn16, nullptr, nullptr, 1.f, nullptr)) return 1;
         const bool f32_self = l == 0;
         float* dqkv32 = at<float>(scratch, pl.dqkv32);
         {
@@ -614,7 +717,8 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
             if (dec_attn<true>(a, dh, f32_self, st)) return 1;
         }
         float* g0 = (g2 == gA) ? gB : gA;
-        if (f32_self) {     // exact fp32 in-projection gradients (see the forward)
+        if (f32_self) {     // exact fp32 in-projection gradients (see the forward); these stay on the caller's stream (they share
+                            // the fp32 slab with the vocabulary head's GEMMs)
             if (gw.sa_in_b && colsum_accum(dqkv32, Md, 3 * d, 3 * d, gw.sa_in_b, st)) return 1;
             if (gw.sa_in_w) {
                 GemmParams t;
@@ -625,17 +729,27 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
             if (wide_cast(dqkv32, Md, 3 * d, 3 * d, dqkv16, nullptr, st)) return 1;
             if (nt(dqkv16, 3 * d, cat<bf16_t>(saved, o.w_sa_in_t), Md, d, 3 * d, g0, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         } else {
-            if (gw.sa_in_b && wide_colsum_bf16(dqkv16, Md, 3 * d, 3 * d, gw.sa_in_b, cspart, st)) return 1;
+            if (fork()) return 1;
+            if (gw.sa_in_b && wide_colsum_bf16(dqkv16, Md, 3 * d, 3 * d, gw.sa_in_b, cspart_side, sd)) return 1;
             if (dw_tn(dqkv16, 3 * d, cat<bf16_t>(saved, o.x16), d, gw.sa_in_w, 3 * d, d, Md)) return 1;
             if (nt(dqkv16, 3 * d, cat<bf16_t>(saved, o.w_sa_in_t), Md, d, 3 * d, g0, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         }
         g = g0;
     }
+    if (forked) {       // join: the slab reduction below (and whatever the caller enqueues next) comes after the side stream's work
+        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
+        EGX_HIP(hipEventRecord(e, sd));
+        EGX_HIP(hipStreamWaitEvent(st, e, 0));
+    }
     if (d_memory && !mem_started) EGX_HIP(hipMemsetAsync(d_memory, 0, pl.Nm * d * sizeof(float), st));
     if (d_emb) {
         DDrop de = ddrop(training, cfg->p_pos, seed, 0, DS_EMBED);
-        hipLaunchKernelGGL(dec_embed_grad_kernel, dim3(cdiv(d, 64), pl.V), dim3(256), 0, st, tokens, g, d_emb, sqrtf((float)d), Md, d, pl.V,
-                           de.key, de.thresh, de.inv);
+        if (pl.V <= EMB_VMAX)
+            hipLaunchKernelGGL(dec_embed_grad_small_kernel, dim3(cdiv(d, 64)), dim3(256), 0, st, tokens, g, d_emb, sqrtf((float)d), Md, d, pl.V,
+                               de.key, de.thresh, de.inv);
+        else
+            hipLaunchKernelGGL(dec_embed_grad_kernel, dim3(cdiv(d, 64), pl.V), dim3(256), 0, st, tokens, g, d_emb, sqrtf((float)d), Md, d, pl.V,
+                               de.key, de.thresh, de.inv);
         EGX_LAUNCH_CHECK();
     }
     return wide_reduce_flush(rb, st);

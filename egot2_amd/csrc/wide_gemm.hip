@@ -425,9 +425,14 @@ int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     if (v == 2) return launch_nt<256, 256, 128, 2>(p, st);
     // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves) below
     if (v == 1) return launch_nt<256, 128, 64, 3>(p, st);
-    static int small_stages = -1;      // tuning aid: EGX_WIDE_SMALL_STAGES = 2 -> two workgroups per CU with two stages each
-    if (small_stages < 0) { const char* e = getenv("EGX_WIDE_SMALL_STAGES"); small_stages = e ? atoi(e) : 2; }
-    return small_stages == 2 ? launch_nt<128, 128, 64, 2>(p, st) : launch_nt<128, 128, 64, 4>(p, st);
+    // 128 x 128 tiles: two workgroups per CU with two stages each once the tiles outnumber the CUs; a launch that cannot
+    // give every CU a second workgroup anyway (the decoder's B * sy <= 2048 target rows: 16-64 tiles) runs four stages deep,
+    // so that a K step costs a third of a memory round trip instead of a whole one (EGX_WIDE_SMALL_STAGES = 2 / 4 forces one)
+    static int small_stages = -1;
+    if (small_stages < 0) { const char* e = getenv("EGX_WIDE_SMALL_STAGES"); small_stages = e ? atoi(e) : 0; }
+    const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int stages = small_stages ? small_stages : (tiles <= 256 ? 4 : 2);
+    return stages == 2 ? launch_nt<128, 128, 64, 2>(p, st) : launch_nt<128, 128, 64, 4>(p, st);
 }
 
 // ---- TN ---------------------------------------------------------------------------------------------------------------
