@@ -71,7 +71,7 @@ __device__ __forceinline__ int xcd_tile(int id, int total) {
 // row / column of the wave's WTM x 64 sub-tile; prow0: its first row of the column-sum partial buffer, one per 64 output rows).
 template <int TJ>
 __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g) {
-    constexpr int JG = TJ / 4;                       // 64-row groups of a wave: one column-sum partial row each
+    constexpr int JG = TJ >= 4 ? TJ / 4 : 1;         // 64-row groups of a wave: one column-sum partial row each (TJ < 4: no column sums, see wide_gemm_nt)
     float cs_part[JG][4][4];
 #pragma unroll
     for (int jg = 0; jg < JG; ++jg)
@@ -153,6 +153,7 @@ __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 0) EGX_WAIT_VM(0);
+    else if constexpr (N == 4) EGX_WAIT_VM(4);
     else if constexpr (N == 6) EGX_WAIT_VM(6);
     else if constexpr (N == 8) EGX_WAIT_VM(8);
     else if constexpr (N == 10) EGX_WAIT_VM(10);
@@ -431,6 +432,14 @@ int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
     static int small_stages = -1;
     if (small_stages < 0) { const char* e = getenv("EGX_WIDE_SMALL_STAGES"); small_stages = e ? atoi(e) : 0; }
     const long tiles = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    // at most one 128 x 128 tile per CU (the decoder's projections of its B * sy target rows: 16-64 tiles; the d = 256 encoder
+    // of the HHI EgoT2-g: 180): 64 x 64 tiles, four waves of 16 x 64 and four stages, put four times as many workgroups on a GEMM
+    // whose duration is a chain of memory round trips, not MFMA time. Same-box sweep of the threshold (64 / 128 / 256 tiles):
+    // C5 HOI 4.02 / 3.98 / 3.99 ms, C5 HHI 2.51 / 2.52 / 2.43 ms, C4 unchanged; without the variant 4.32 / 2.78 ms.
+    // (the column-sum epilogue needs 64-row waves: those launches keep the 128 x 128 tiles)
+    static int tiny = -1;
+    if (tiny < 0) { const char* e = getenv("EGX_WIDE_TINY"); tiny = e ? atoi(e) : 256; }      // threshold in 128 x 128 tiles (0: off)
+    if (tiles <= tiny && !p.colsum) return launch_nt<64, 64, 16, 4>(p, st);
     const int stages = small_stages ? small_stages : (tiles <= 256 ? 4 : 2);
     return stages == 2 ? launch_nt<128, 128, 64, 2>(p, st) : launch_nt<128, 128, 64, 4>(p, st);
 }
