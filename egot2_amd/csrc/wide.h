@@ -24,6 +24,8 @@ struct WideGemmParams {
     const bf16_t* mask = nullptr; int ldm = 0; float mask_scale = 1.f;       // C = mask[m][n] != 0 ? C * mask_scale : 0
     float* colsum = nullptr;      // optional [wide_gemm_nt_colsum_rows(M, N)][N]: column sums per 64 output rows (bias gradients)
     int accumulate = 0;           // TN: C += result (parameter gradients)
+    int tn_max_splits = 0;        // TN: upper bound on the split-K count (0: the cost model's choice). 1 with accumulate == 0 and a dense C
+                                  // (ldc == N) writes C directly: no slab, no reduction (launches that need no parallelism: side stream)
     const void* zero_page = nullptr;   // >= 256 zero bytes in device memory (source of out-of-range operand rows)
 };
 

@@ -273,16 +273,18 @@ __global__ __launch_bounds__(256) void dec_embed_grad_kernel(const int64_t* __re
 
 // Small vocabularies (V <= 64: the EgoT2-g task vocabularies): one workgroup per 64 columns walks ALL rows once, every row's
 // gradient is loaded unconditionally (eight rows in flight per wave) and added to the LDS accumulator row of its token; four
-// waves take a quarter of the rows each and are summed in wave order (deterministic). The per-(token, column) kernel above
+// up to 16 waves take a slice of the rows each and are summed in wave order (deterministic). The per-(token, column) kernel above
 // scans the token list once per vocabulary entry with a dependent load per match: 43-61 us at B * sy = 512 against 6 here.
 constexpr int EMB_VMAX = 64;
-__global__ __launch_bounds__(256) void dec_embed_grad_small_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dy, float* __restrict__ d_emb,
-                                                                   float scale, int rows, int d, int V, uint64_t key, uint32_t thresh, float inv) {
-    __shared__ float acc[4][EMB_VMAX][64];
+__global__ __launch_bounds__(1024) void dec_embed_grad_small_kernel(const int64_t* __restrict__ tok, const float* __restrict__ dy, float* __restrict__ d_emb,
+                                                                    float scale, int rows, int d, int V, uint64_t key, uint32_t thresh, float inv) {
+    extern __shared__ float acc[];          // [G row groups][V][64], G = blockDim.x / 64 (as many as 64 KB hold, at most 16)
+    const int G = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + lane;
-    for (int v = 0; v < V; ++v) acc[grp][v][lane] = 0.f;
+    float* mine = acc + (size_t)grp * V * 64;
+    for (int v = 0; v < V; ++v) mine[v * 64 + lane] = 0.f;
     const int cc = c < d ? c : d - 1;
-    const int per = (rows + 3) / 4, r0 = grp * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const int per = (rows + G - 1) / G, r0 = grp * per, r1 = r0 + per < rows ? r0 + per : rows;
     for (int row = r0; row < r1; row += 8) {
         float g[8];
         int t[8];
@@ -297,13 +299,16 @@ __global__ __launch_bounds__(256) void dec_embed_grad_small_kernel(const int64_t
             if (row + u >= r1) break;
             float gv = g[u];
             if (thresh) gv *= drop_scale(key, (uint32_t)(row + u), (uint32_t)cc, thresh, inv);
-            if (t[u] >= 0 && t[u] < V) acc[grp][t[u]][lane] += gv;      // lane-private column: no conflict, row order kept
+            if (t[u] >= 0 && t[u] < V) mine[t[u] * 64 + lane] += gv;      // lane-private column: no conflict, row order kept
         }
     }
     __syncthreads();
     if (c < d)
-        for (int v = grp; v < V; v += 4)
-            d_emb[(size_t)v * d + c] += ((acc[0][v][lane] + acc[1][v][lane]) + (acc[2][v][lane] + acc[3][v][lane])) * scale;
+        for (int v = grp; v < V; v += G) {
+            float sum = 0.f;
+            for (int k = 0; k < G; ++k) sum += acc[((size_t)k * V + v) * 64 + lane];     // group order
+            d_emb[(size_t)v * d + c] += sum * scale;
+        }
 }
 
 struct DLayer {
@@ -606,7 +611,14 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         if (!dW) return 0;
         WideGemmParams t;
         t.A = dy; t.B = x; t.M = n_out; t.N = k_in; t.K = tokens_k; t.lda = ldy; t.ldb = ldx;
-        t.Cf = dW; t.ldc = k_in; t.accumulate = 1; t.zero_page = zero;
+        t.Cf = dW; t.ldc = k_in; t.zero_page = zero;
+        // written exactly once into the zeroed flat buffer. EGX_DEC_DIRECT=1 (tuning aid, off): over <= 1024 target rows ONE split
+        // straight into dW (no slab, no reduction), at most eight over the B * S memory rows: removes the batched slab reduction
+        // (55-73 us, 230 MB per step) but lengthens the side stream - same-box A/B: C5 HOI 3.95 = 3.95 ms, C5 HHI 2.46 -> 2.62 ms
+        static int direct = -1;
+        if (direct < 0) { const char* e = getenv("EGX_DEC_DIRECT"); direct = e ? atoi(e) : 0; }
+        t.accumulate = 0;
+        t.tn_max_splits = !direct ? 0 : (tokens_k <= 1024 ? 1 : (tokens_k <= 4096 ? 0 : 8));
         const size_t need = align_up(wide_gemm_tn_scratch(n_out, k_in, tokens_k), 256);
         EGX_CHECK(slab_cur + need <= pl.slab_all_bytes, "decoder backward: slab region exhausted");
         void* region = at<char>(scratch, pl.slab_all) + slab_cur;
@@ -745,8 +757,12 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     if (d_emb) {
         DDrop de = ddrop(training, cfg->p_pos, seed, 0, DS_EMBED);
         if (pl.V <= EMB_VMAX)
-            hipLaunchKernelGGL(dec_embed_grad_small_kernel, dim3(cdiv(d, 64)), dim3(256), 0, st, tokens, g, d_emb, sqrtf((float)d), Md, d, pl.V,
-                               de.key, de.thresh, de.inv);
+        {
+            int G = 65536 / (pl.V * 256);
+            G = G > 16 ? 16 : (G < 1 ? 1 : G);
+            hipLaunchKernelGGL(dec_embed_grad_small_kernel, dim3(cdiv(d, 64)), dim3(64 * G), (size_t)G * pl.V * 256, st, tokens, g, d_emb,
+                               sqrtf((float)d), Md, d, pl.V, de.key, de.thresh, de.inv);
+        }
         else
             hipLaunchKernelGGL(dec_embed_grad_kernel, dim3(cdiv(d, 64), pl.V), dim3(256), 0, st, tokens, g, d_emb, sqrtf((float)d), Md, d, pl.V,
                                de.key, de.thresh, de.inv);

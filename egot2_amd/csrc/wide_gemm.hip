@@ -657,9 +657,18 @@ int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st, WideRed
     EGX_CHECK(p.M % TBM == 0 && p.N % TBN == 0 && p.K > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_tn: %dx%dx%d needs M, N multiples of 128 and 16-byte aligned rows", p.M, p.N, p.K);
     int kps = 0;
-    const int splits = tn_splits(p.M, p.N, p.K, &kps);
+    int splits = tn_splits(p.M, p.N, p.K, &kps);
+    if (p.tn_max_splits > 0 && splits > p.tn_max_splits) {
+        kps = cdiv(cdiv(p.K, p.tn_max_splits), TBK) * TBK;
+        splits = cdiv(p.K, kps);
+    }
     const size_t slab_stride = (size_t)p.M * p.N;
     const int v = tn_variant(p.M, p.N);
+    if (splits == 1 && !p.accumulate && p.ldc == p.N) {      // the one slab IS the output
+        if (v == 2) return launch_tn<256, 256, 128, 2>(p, 1, kps, p.Cf, slab_stride, st);
+        if (v == 1) return launch_tn<256, 128, 64, 3>(p, 1, kps, p.Cf, slab_stride, st);
+        return launch_tn<128, 128, 64, 4>(p, 1, kps, p.Cf, slab_stride, st);
+    }
     if (v == 2) { if (launch_tn<256, 256, 128, 2>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
     else if (v == 1) { if (launch_tn<256, 128, 64, 3>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1; }
     else if (launch_tn<128, 128, 64, 4>(p, splits, kps, (float*)scratch, slab_stride, st)) return 1;
