@@ -307,6 +307,8 @@ static int linear_dw(const float* dy, const float* x, float* dW, int M, int N, i
     return gemm(2, g, compute, 1, slab, slab_bytes, st);
 }
 
+int debug_read_ppstamps(unsigned long long* out);       // wide_gemm.hip (development aid)
+
 }  // namespace egx
 
 using namespace egx;
@@ -315,7 +317,7 @@ extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
-int egx_debug_stamps(unsigned long long* out, int n) { return n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n); }
+int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
 int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }
 int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }

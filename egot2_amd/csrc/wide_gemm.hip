@@ -151,6 +151,87 @@ __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc
     }
 }
 
+// Epilogue through LDS (launches without mask / column sums and with N % 8 == 0): the accumulator layout gives a store
+// instruction 16 rows x 32 B (bf16) or 64 B (fp32) - sixteen partial cache lines per instruction, and the CU's one address
+// unit takes ~480 cycles for each: 15.5k of a 256 x 256 x 768 tile's 53.7k cycles were the ISSUE of its 32 stores per wave
+// (stamps; the stores themselves drain in 1.2k). Here bias / ReLU / dropout are applied in the accumulator layout, the wave
+// writes its (TJ * 16) x 64 sub-tile into a private LDS region (the K loop's stages, dead by now) and reads it back row-major:
+// a store instruction then covers 8 full 128-byte lines (bf16) or 4 rows x 256 B (fp32; residual rows are read the same way).
+constexpr int EPI_LDB = 144;                 // bf16 row: 64 columns + pad, 16-byte aligned, 36 dwords (rows spread over the banks)
+constexpr int EPI_LDF = 272;                 // fp32 row: 64 columns + pad
+template <int TJ>
+__device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * EPI_LDB > (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF ? (TJ * 16) * EPI_LDB : (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }
+template <int TJ>
+__device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int r, int g, int lane, unsigned char* region) {
+    // phase A (accumulator layout): bias, ReLU, dropout
+    float4 bb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = nb + i * 16 + 4 * g;
+        bb[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
+    }
+    auto value = [&](int i, int j, float (&v)[4]) {
+        v[0] = acc[i][j][0] + bb[i].x; v[1] = acc[i][j][1] + bb[i].y; v[2] = acc[i][j][2] + bb[i].z; v[3] = acc[i][j][3] + bb[i].w;
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.drop_thresh) {
+            float ds[4];
+            drop_scale4(p.drop_key, (uint32_t)(mb + j * 16 + r), (uint32_t)(nb + i * 16 + 4 * g), p.drop_thresh, p.drop_inv, ds);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= ds[e];
+        }
+    };
+    if (!p.Cf && !p.residual) {
+        // bf16 out only: the whole sub-tile at once
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+                value(i, j, v);
+                *reinterpret_cast<uint2*>(region + (j * 16 + r) * EPI_LDB + (i * 16 + 4 * g) * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+            }
+        const int rr = lane >> 3, ch = lane & 7, n = nb + ch * 8;
+#pragma unroll
+        for (int k = 0; k < TJ * 2; ++k) {
+            const int row = k * 8 + rr, m = mb + row;
+            const uint4 q = *reinterpret_cast<const uint4*>(region + row * EPI_LDB + ch * 16);
+            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = q;
+        }
+        return;
+    }
+    // fp32 (and optionally bf16) out, optional fp32 residual: groups of RG row tiles through the region
+    constexpr int RG = TJ >= 4 ? TJ / 4 : 1;           // row tiles per round (64 x 272 B = 17 KB for the 128-row waves)
+    const int rr = lane >> 4, ch = lane & 15, n = nb + ch * 4;
+#pragma unroll
+    for (int h = 0; h < TJ / RG; ++h) {
+#pragma unroll
+        for (int jj = 0; jj < RG; ++jj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[4];
+                value(i, h * RG + jj, v);
+                *reinterpret_cast<float4*>(region + (jj * 16 + r) * EPI_LDF + (i * 16 + 4 * g) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+        for (int k = 0; k < RG * 4; ++k) {
+            const int row = k * 4 + rr, m = mb + h * RG * 16 + row;
+            float4 q = *reinterpret_cast<const float4*>(region + row * EPI_LDF + ch * 16);
+            if (m < p.M && n < p.N) {
+                if (p.residual) {
+                    const float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
+                    q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
+                }
+                if (p.Cf) *reinterpret_cast<float4*>(p.Cf + (size_t)m * p.ldc + n) = q;
+                if (p.Cb) *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = make_uint2(pack2(q.x, q.y), pack2(q.z, q.w));
+            }
+        }
+    }
+}
+__device__ __forceinline__ bool nt_epilogue_simple(const WideGemmParams& p) { return !p.mask && !p.colsum && (p.N & 7) == 0; }
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 0) EGX_WAIT_VM(0);
     else if constexpr (N == 4) EGX_WAIT_VM(4);
@@ -240,6 +321,13 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_nt_k
         }
     }
 
+    if constexpr (NW * epi_lds_bytes<TJ>() <= D * SB) {
+        if (nt_epilogue_simple(p)) {
+            __syncthreads();        // the last stage's fragment reads are over in every wave: the stages become the wave regions
+            nt_epilogue_lds<TJ>(p, acc, m0 + wm * WTM, n0 + wn * 64, r, g, lane, smem + wave * epi_lds_bytes<TJ>());
+            return;
+        }
+    }
     nt_epilogue<TJ>(p, acc, m0 + wm * WTM, n0 + wn * 64, m0 / 64 + wm * (WTM / 64), r, g);
 }
 
@@ -275,9 +363,18 @@ static int launch_nt(const WideGemmParams& p, hipStream_t st) {
 //   "everything issued five or more phases ago has landed", which is at least one phase earlier than any region is read
 //   (6-7 phases after its issue), and a barrier separates that wait from the reads.
 // WAR: a region's restaging is issued at least one barrier after the lgkmcnt(0) that retired its last reads in BOTH groups.
+#ifdef EGX_STAMPS
+__device__ unsigned long long g_ppstamps[8];
+#define PPSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ppstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+int debug_read_ppstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ppstamps), sizeof(g_ppstamps)) == hipSuccess ? 0 : 1; }
+#else
+#define PPSTAMP(i) do { } while (0)
+int debug_read_ppstamps(unsigned long long*) { return 1; }
+#endif
 __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams p, int ntM, int ntN) {
     constexpr int BM = 256, BN = 256, SB = (BM + BN) * TBK * 2, WOFF = BM * TBK * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PPSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wn = wave & 3;
     const int t = xcd_tile(blockIdx.x, ntM * ntN);
@@ -333,6 +430,7 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     stage_x(1, 0, 2); stage_w(1, 0); stage_w(1, 1);
     EGX_WAIT_VM(10);
     ring_barrier();
+    PPSTAMP(1);
     if (wr == 1) ring_barrier();        // the stagger: waves 4-7 run one barrier behind
 
     bf16x8 fx[4][2], fw[4][2];          // X half (4 row tiles x 2 K sub-steps), W tiles 0..3 (both halves stay live for P4)
@@ -377,13 +475,24 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     }
 #undef EGX_PP_PHASE_TAIL
 #undef EGX_PP_MFMA
+    PPSTAMP(2);
     if (wr == 0) ring_barrier();        // balance the stagger
     EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup
-    nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
+    PPSTAMP(3);
+    if (nt_epilogue_simple(p)) {
+        ring_barrier();     // every wave's LDS-DMA has landed (each waited for its own above): the stages are free for the wave regions
+        nt_epilogue_lds<8>(p, acc, m0 + wr * 128, n0 + wn * 64, r, g, lane, smem + wave * epi_lds_bytes<8>());
+    }
+    else nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
+    PPSTAMP(4);
+#ifdef EGX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PPSTAMP(5);
+#endif
 }
 
 static int launch_nt_pp(const WideGemmParams& p, hipStream_t st) {
-    constexpr int LDS = 2 * (256 + 256) * TBK * 2;
+    constexpr int LDS = 2 * (256 + 256) * TBK * 2 > 8 * 128 * EPI_LDB ? 2 * (256 + 256) * TBK * 2 : 8 * 128 * EPI_LDB;      // the K loop's two stages / the epilogue's eight wave regions
     static bool attr = false;
     if (!attr) {
         EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
