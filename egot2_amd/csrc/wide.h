@@ -27,6 +27,7 @@ struct WideGemmParams {
     int tn_max_splits = 0;        // TN: upper bound on the split-K count (0: the cost model's choice). 1 with accumulate == 0 and a dense C
                                   // (ldc == N) writes C directly: no slab, no reduction (launches that need no parallelism: side stream)
     const void* zero_page = nullptr;   // >= 256 zero bytes in device memory (source of out-of-range operand rows)
+    int epi_lds = 0;              // NT: set by wide_gemm_nt (EGX_WIDE_EPI): epilogue through LDS
 };
 
 // scratch for the TN split-K slabs

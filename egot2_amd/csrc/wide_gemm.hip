@@ -162,7 +162,7 @@ constexpr int EPI_LDF = 272;                 // fp32 row: 64 columns + pad
 template <int TJ>
 __device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * EPI_LDB > (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF ? (TJ * 16) * EPI_LDB : (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }
 template <int TJ>
-__device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int r, int g, int lane, unsigned char* region) {
+__device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
     // phase A (accumulator layout): bias, ReLU, dropout
     float4 bb[4];
 #pragma unroll
@@ -183,7 +183,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
             for (int e = 0; e < 4; ++e) v[e] *= ds[e];
         }
     };
-    if (!p.Cf && !p.residual) {
+    if (!p.Cf && !p.residual && !p.mask && !p.colsum) {
         // bf16 out only: the whole sub-tile at once
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
@@ -202,9 +202,17 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
         }
         return;
     }
-    // fp32 (and optionally bf16) out, optional fp32 residual: groups of RG row tiles through the region
-    constexpr int RG = TJ >= 4 ? TJ / 4 : 1;           // row tiles per round (64 x 272 B = 17 KB for the 128-row waves)
+    // fp32 (and optionally bf16) out, optional bf16 mask, fp32 residual, column sums: groups of RG row tiles through the region
+    constexpr int RG = TJ >= 4 ? TJ / 4 : 1;           // row tiles per round (32 x 272 B for the 128-row waves)
     const int rr = lane >> 4, ch = lane & 15, n = nb + ch * 4;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};                // column sums of the lane's four columns over the current 64-row group
+    auto cs_flush = [&](int jg) {
+        if (!p.colsum) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
+        if (rr == 0 && n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)(prow0 + jg) * p.N + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        cs[0] = cs[1] = cs[2] = cs[3] = 0.f;
+    };
 #pragma unroll
     for (int h = 0; h < TJ / RG; ++h) {
 #pragma unroll
@@ -220,17 +228,39 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
             const int row = k * 4 + rr, m = mb + h * RG * 16 + row;
             float4 q = *reinterpret_cast<const float4*>(region + row * EPI_LDF + ch * 16);
             if (m < p.M && n < p.N) {
+                if (p.mask) {
+                    const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + (size_t)m * p.ldm + n);
+                    q.x = (mk.x & 0xffffu) ? q.x * p.mask_scale : 0.f;
+                    q.y = (mk.x >> 16) ? q.y * p.mask_scale : 0.f;
+                    q.z = (mk.y & 0xffffu) ? q.z * p.mask_scale : 0.f;
+                    q.w = (mk.y >> 16) ? q.w * p.mask_scale : 0.f;
+                }
                 if (p.residual) {
                     const float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
                     q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
                 }
                 if (p.Cf) *reinterpret_cast<float4*>(p.Cf + (size_t)m * p.ldc + n) = q;
-                if (p.Cb) *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = make_uint2(pack2(q.x, q.y), pack2(q.z, q.w));
+                if (p.Cb) {
+                    const uint2 o = make_uint2(pack2(q.x, q.y), pack2(q.z, q.w));
+                    *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = o;
+                    if (p.colsum) {     // sums of the values as stored (bf16-rounded), so that db == colsum(stored dY) exactly
+                        cs[0] += bf2f((bf16_t)(o.x & 0xffffu)); cs[1] += bf2f((bf16_t)(o.x >> 16));
+                        cs[2] += bf2f((bf16_t)(o.y & 0xffffu)); cs[3] += bf2f((bf16_t)(o.y >> 16));
+                    }
+                } else if (p.colsum) {
+                    cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w;
+                }
             }
         }
+        // one partial row per 64 output rows: the rounds cover RG * 16 rows each
+        if (((h + 1) * RG * 16) % 64 == 0 || h + 1 == TJ / RG) cs_flush((h * RG * 16) / 64);
     }
 }
-__device__ __forceinline__ bool nt_epilogue_simple(const WideGemmParams& p) { return !p.mask && !p.colsum && (p.N & 7) == 0; }
+// (TJ < 4: 16-row waves cannot produce the one-partial-row-per-64-rows column sums)
+template <int TJ>
+__device__ __forceinline__ bool nt_epilogue_simple(const WideGemmParams& p) {
+    return (p.N & 7) == 0 && (p.epi_lds == 2 ? (TJ >= 4 || !p.colsum) : (p.epi_lds == 1 && !p.mask && !p.colsum));
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     if constexpr (N == 0) EGX_WAIT_VM(0);
@@ -322,9 +352,9 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_nt_k
     }
 
     if constexpr (NW * epi_lds_bytes<TJ>() <= D * SB) {
-        if (nt_epilogue_simple(p)) {
+        if (nt_epilogue_simple<TJ>(p)) {
             __syncthreads();        // the last stage's fragment reads are over in every wave: the stages become the wave regions
-            nt_epilogue_lds<TJ>(p, acc, m0 + wm * WTM, n0 + wn * 64, r, g, lane, smem + wave * epi_lds_bytes<TJ>());
+            nt_epilogue_lds<TJ>(p, acc, m0 + wm * WTM, n0 + wn * 64, m0 / 64 + wm * (WTM / 64), r, g, lane, smem + wave * epi_lds_bytes<TJ>());
             return;
         }
     }
@@ -479,9 +509,9 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     if (wr == 0) ring_barrier();        // balance the stagger
     EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup
     PPSTAMP(3);
-    if (nt_epilogue_simple(p)) {
+    if (nt_epilogue_simple<8>(p)) {
         ring_barrier();     // every wave's LDS-DMA has landed (each waited for its own above): the stages are free for the wave regions
-        nt_epilogue_lds<8>(p, acc, m0 + wr * 128, n0 + wn * 64, r, g, lane, smem + wave * epi_lds_bytes<8>());
+        nt_epilogue_lds<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g, lane, smem + wave * epi_lds_bytes<8>());
     }
     else nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
     PPSTAMP(4);
@@ -525,7 +555,14 @@ static int nt_variant(int M, int N) {
 // rows of the `colsum` partial buffer written by wide_gemm_nt for an (M, N) output: one per 64 output rows of every tile
 int wide_gemm_nt_colsum_rows(int M, int N) { return nt_variant(M, N) ? cdiv(M, 256) * 4 : cdiv(M, 128) * 2; }     // one per 64 rows of every tile
 
-int wide_gemm_nt(const WideGemmParams& p, hipStream_t st) {
+static int epi_lds_mode() {     // EGX_WIDE_EPI: 0 = accumulator-layout stores, 1 = through LDS without mask / column sums, 2 = through LDS always
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_WIDE_EPI"); v = e ? atoi(e) : 2; }
+    return v;
+}
+int wide_gemm_nt(const WideGemmParams& p_in, hipStream_t st) {
+    WideGemmParams p = p_in;
+    p.epi_lds = epi_lds_mode();
     EGX_CHECK(p.A && p.B && (p.Cf || p.Cb), "wide_gemm_nt: null operand");
     EGX_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "wide_gemm_nt: empty problem %dx%dx%d", p.M, p.N, p.K);
     EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
