@@ -162,6 +162,8 @@ constexpr int EPI_LDF = 272;                 // fp32 row: 64 columns + pad
 template <int TJ>
 __device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * EPI_LDB > (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF ? (TJ * 16) * EPI_LDB : (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }
 template <int TJ>
+__device__ __forceinline__ constexpr int epi_lds_f32_bytes() { return (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }      // fp32 rounds only (TN slabs)
+template <int TJ>
 __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
     // phase A (accumulator layout): bias, ReLU, dropout
     float4 bb[4];
@@ -685,6 +687,15 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_k
         }
     }
     float* out = slabs + (size_t)split * slab_stride;
+    if constexpr (NW * epi_lds_f32_bytes<TJ>() <= D * SB) {
+        if (p.epi_lds) {        // the slab tile through LDS: row-major stores of full cache lines (see nt_epilogue_lds)
+            WideGemmParams q;
+            q.Cf = out; q.ldc = p.N; q.M = p.M; q.N = p.N;
+            __syncthreads();    // the last stage's fragment reads are over in every wave
+            nt_epilogue_lds<TJ>(q, acc, m0 + wm * WTM, n0 + wn * 64, 0, r, g, lane, smem + wave * epi_lds_f32_bytes<TJ>());
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
         const int m = m0 + wm * WTM + j * 16 + r;
@@ -798,7 +809,9 @@ static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs,
     return 0;
 }
 
-int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer) {
+int wide_gemm_tn(const WideGemmParams& p_in, void* scratch, hipStream_t st, WideReduceBatch* defer) {
+    WideGemmParams p = p_in;
+    p.epi_lds = epi_lds_mode();
     EGX_CHECK(p.A && p.B && p.Cf && scratch && p.zero_page, "wide_gemm_tn: null operand");
     EGX_CHECK(p.M % TBM == 0 && p.N % TBN == 0 && p.K > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_tn: %dx%dx%d needs M, N multiples of 128 and 16-byte aligned rows", p.M, p.N, p.K);
