@@ -860,28 +860,36 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
     f32x4 acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = f32x4{0, 0, 0, 0};
-    float4 pg[2], px[4];
-    auto gload = [&](int kb) {
+    // operand tiles of K-block kb + 2 are requested while kb is multiplied (two register sets): one block ahead left every
+    // iteration waiting a memory round trip for ~1k cycles of MFMA + split work (52 % of the wave cycles parked, 14 % MFMA busy).
+    // The loads are unconditional (clamped addresses, zeroed by a select afterwards): a load under a branch is waited for at once.
+    float4 pgA[2], pxA[4], pgB[2], pxB[4];
+    auto gload = [&](int kb, float4 (&pg)[2], float4 (&px)[4]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int f = tid + i * 256, row = f >> 4, c4 = (f & 15) << 2;
             int n = kb * 32 + row, c = row0 + c4;
-            pg[i] = (n < pr.K && c < pr.R) ? *reinterpret_cast<const float4*>(pr.G + (size_t)n * pr.ldg + c) : make_float4(0, 0, 0, 0);
+            const bool ok = n < pr.K && c < pr.R;
+            float4 v = *reinterpret_cast<const float4*>(pr.G + (size_t)(ok ? n : 0) * pr.ldg + (ok ? c : 0));
+            pg[i] = ok ? v : make_float4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int f = tid + i * 256, row = f >> 5, c4 = (f & 31) << 2;
             int n = kb * 32 + row, c = col0 + c4;
-            px[i] = (n < pr.K && c < pr.C) ? *reinterpret_cast<const float4*>(pr.X + (size_t)n * pr.ldx + c) : make_float4(0, 0, 0, 0);
+            const bool ok = n < pr.K && c < pr.C;
+            float4 v = *reinterpret_cast<const float4*>(pr.X + (size_t)(ok ? n : 0) * pr.ldx + (ok ? c : 0));
+            px[i] = ok ? v : make_float4(0, 0, 0, 0);
         }
     };
-    auto lstore = [&](float* gt, float* xt) {
+    auto lstore = [&](float* gt, float* xt, const float4 (&pg)[2], const float4 (&px)[4]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) { int f = tid + i * 256; *reinterpret_cast<float4*>(gt + (f >> 4) * LDG + ((f & 15) << 2)) = pg[i]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { int f = tid + i * 256; *reinterpret_cast<float4*>(xt + (f >> 5) * LDXS + ((f & 31) << 2)) = px[i]; }
     };
-    gload(kb_beg);
+    gload(kb_beg, pgA, pxA);
+    gload(kb_beg + 1 < kb_end ? kb_beg + 1 : kb_beg, pgB, pxB);
     if constexpr (CM == CM_SPLIT) {
         // Operands are split ONCE per K-block while staging (three bf16 planes per tile, single-buffered: 42 KB) and read back
         // as token-along-K fragments by the hardware-transposed ds_read_b64_tr_b16: no per-wave gather or split work.
@@ -912,36 +920,42 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
             *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m0, m1);
             *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l0, l1);
         };
-        for (int kb = kb_beg; kb < kb_end; ++kb) {
+        auto block = [&](int kb, float4 (&pg)[2], float4 (&px)[4]) {
             if (kb > kb_beg) __syncthreads();           // everyone is done reading the previous K-block
 #pragma unroll
             for (int i = 0; i < 2; ++i) { int f = tid + i * 256; put(gp + (f >> 4) * LGH + ((f & 15) << 2), GPL, pg[i]); }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { int f = tid + i * 256; put(xp + (f >> 5) * LXH + ((f & 31) << 2), XPL, px[i]); }
             __syncthreads();
-            if (kb + 1 < kb_end) gload(kb + 1);
+            gload(kb + 2 < kb_end ? kb + 2 : kb, pg, px);      // (past the end: a re-read that nobody uses)
             Frag<CM_SPLIT> a = tr_frag(gp, LGH, GPL, wave * 16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 Frag<CM_SPLIT> b = tr_frag(xp, LXH, XPL, j * 16);
                 mma<CM_SPLIT>(acc[j], a, b);
             }
+        };
+        for (int kb = kb_beg; kb < kb_end; kb += 2) {
+            block(kb, pgA, pxA);
+            if (kb + 1 < kb_end) block(kb + 1, pgB, pxB);
         }
     } else {
-    int cur = 0;
-    for (int kb = kb_beg; kb < kb_end; ++kb) {
+    auto block = [&](int kb, int cur, float4 (&pg)[2], float4 (&px)[4]) {
         float* gt = lds + cur * (32 * LDG + 32 * LDXS);
         float* xt = gt + 32 * LDG;
-        lstore(gt, xt);
+        lstore(gt, xt, pg, px);
         __syncthreads();
-        if (kb + 1 < kb_end) gload(kb + 1);
+        gload(kb + 2 < kb_end ? kb + 2 : kb, pg, px);
         Frag<CM> a = gather_frag<CM>(gt, wave * 16 + r, 0, q, 31, LDG);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             Frag<CM> b = gather_frag<CM>(xt, j * 16 + r, 0, q, 31, LDXS);
             mma<CM>(acc[j], a, b);
         }
-        cur ^= 1;
+    };
+    for (int kb = kb_beg; kb < kb_end; kb += 2) {
+        block(kb, 0, pgA, pxA);
+        if (kb + 1 < kb_end) block(kb + 1, 1, pgB, pxB);
     }
     }
     if (p.slabs) {      // deterministic: dense tile per workgroup, summed in split order by small_dw_reduce_kernel
