@@ -157,18 +157,20 @@ __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc
 // (stamps; the stores themselves drain in 1.2k). Here bias / ReLU / dropout are applied in the accumulator layout, the wave
 // writes its (TJ * 16) x 64 sub-tile into a private LDS region (the K loop's stages, dead by now) and reads it back row-major:
 // a store instruction then covers 8 full 128-byte lines (bf16) or 4 rows x 256 B (fp32; residual rows are read the same way).
-constexpr int EPI_LDB = 144;                 // bf16 row: 64 columns + pad, 16-byte aligned, 36 dwords (rows spread over the banks)
-constexpr int EPI_LDF = 272;                 // fp32 row: 64 columns + pad
-template <int TJ>
-__device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * EPI_LDB > (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF ? (TJ * 16) * EPI_LDB : (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }
-template <int TJ>
-__device__ __forceinline__ constexpr int epi_lds_f32_bytes() { return (TJ >= 4 ? TJ * 4 : 16) * EPI_LDF; }      // fp32 rounds only (TN slabs)
-template <int TJ>
-__device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
+// (NI = W tiles of 16 columns per wave: 4, or 3 for the 256 x 192 tile)
+template <int NI> __host__ __device__ __forceinline__ constexpr int epi_ldb() { return NI * 32 + 16; }     // bf16 row + pad: 16-byte aligned, rows spread over the banks
+template <int NI> __host__ __device__ __forceinline__ constexpr int epi_ldf() { return NI * 64 + 16; }     // fp32 row + pad
+template <int TJ, int NI = 4>
+__host__ __device__ __forceinline__ constexpr int epi_lds_f32_bytes() { return (TJ >= 4 ? TJ * 4 : 16) * epi_ldf<NI>(); }      // fp32 rounds only (TN slabs)
+template <int TJ, int NI = 4>
+__host__ __device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * epi_ldb<NI>() > epi_lds_f32_bytes<TJ, NI>() ? (TJ * 16) * epi_ldb<NI>() : epi_lds_f32_bytes<TJ, NI>(); }
+template <int TJ, int NI = 4>
+__device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[NI][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
+    constexpr int EPI_LDB = epi_ldb<NI>(), EPI_LDF = epi_ldf<NI>();
     // phase A (accumulator layout): bias, ReLU, dropout
-    float4 bb[4];
+    float4 bb[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int n = nb + i * 16 + 4 * g;
         bb[i] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0, 0, 0, 0);
     }
@@ -190,23 +192,29 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 float v[4];
                 value(i, j, v);
                 *reinterpret_cast<uint2*>(region + (j * 16 + r) * EPI_LDB + (i * 16 + 4 * g) * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
             }
-        const int rr = lane >> 3, ch = lane & 7, n = nb + ch * 8;
+        // a row is NI * 2 pieces of 16 bytes: RPI rows per instruction (NI = 3: 10 rows, four lanes idle)
+        constexpr int LPR = NI * 2, RPI = 64 / LPR, WR = TJ * 16;
+        const int rr = lane / LPR, ch = lane - rr * LPR, n = nb + ch * 8;
 #pragma unroll
-        for (int k = 0; k < TJ * 2; ++k) {
-            const int row = k * 8 + rr, m = mb + row;
-            const uint4 q = *reinterpret_cast<const uint4*>(region + row * EPI_LDB + ch * 16);
-            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = q;
+        for (int k = 0; k < (WR + RPI - 1) / RPI; ++k) {
+            const int row = k * RPI + rr, m = mb + row;
+            if (rr < RPI && row < WR) {
+                const uint4 q = *reinterpret_cast<const uint4*>(region + row * EPI_LDB + ch * 16);
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = q;
+            }
         }
         return;
     }
     // fp32 (and optionally bf16) out, optional bf16 mask, fp32 residual, column sums: groups of RG row tiles through the region
     constexpr int RG = TJ >= 4 ? TJ / 4 : 1;           // row tiles per round (32 x 272 B for the 128-row waves)
-    const int rr = lane >> 4, ch = lane & 15, n = nb + ch * 4;
+    constexpr int LPR = NI * 4, RPI = 64 / LPR;        // lanes per row (16-byte pieces), rows per instruction (NI = 3: 5 rows, four lanes idle)
+    static_assert(NI == 4 || NI == 3, "column sums below assume four lane rows (NI = 4)");
+    const int rr = lane / LPR, ch = lane - rr * LPR, n = nb + ch * 4;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};                // column sums of the lane's four columns over the current 64-row group
     auto cs_flush = [&](int jg) {
         if (!p.colsum) return;
@@ -220,14 +228,15 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
 #pragma unroll
         for (int jj = 0; jj < RG; ++jj)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 float v[4];
                 value(i, h * RG + jj, v);
                 *reinterpret_cast<float4*>(region + (jj * 16 + r) * EPI_LDF + (i * 16 + 4 * g) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
-        for (int k = 0; k < RG * 4; ++k) {
-            const int row = k * 4 + rr, m = mb + h * RG * 16 + row;
+        for (int k = 0; k < (RG * 16 + RPI - 1) / RPI; ++k) {
+            const int row = k * RPI + rr, m = mb + h * RG * 16 + row;
+            if (!(rr < RPI && row < RG * 16)) continue;
             float4 q = *reinterpret_cast<const float4*>(region + row * EPI_LDF + ch * 16);
             if (m < p.M && n < p.N) {
                 if (p.mask) {
@@ -259,9 +268,9 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
     }
 }
 // (TJ < 4: 16-row waves cannot produce the one-partial-row-per-64-rows column sums)
-template <int TJ>
+template <int TJ, int NI = 4>
 __device__ __forceinline__ bool nt_epilogue_simple(const WideGemmParams& p) {
-    return (p.N & 7) == 0 && (p.epi_lds == 2 ? (TJ >= 4 || !p.colsum) : (p.epi_lds == 1 && !p.mask && !p.colsum));
+    return (p.N & 7) == 0 && (p.epi_lds == 2 ? ((TJ >= 4 && NI == 4) || !p.colsum) : (p.epi_lds == 1 && !p.mask && !p.colsum));
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -403,8 +412,14 @@ int debug_read_ppstamps(unsigned long long* out) { return hipMemcpyFromSymbol(ou
 #define PPSTAMP(i) do { } while (0)
 int debug_read_ppstamps(unsigned long long*) { return 1; }
 #endif
+// NWT = W tiles (16 output columns) per wave: 4 -> the 256 x 256 tile described above; 3 -> a 256 x 192 tile for outputs whose
+// 256-column tiles leave the chip's last round half empty (N = 768: 384 tiles = 1.5 rounds, 512 tiles of 192 columns = 2 full
+// rounds of 0.75 the work). Its W half 1 is one tile (P2 / P3: 8 MFMAs), staged by one instruction per wave in P4: seven LDS-DMA
+// loads per K tile, so the uniform wait is vmcnt(8) - any five consecutive phases issue at least eight.
+template <int NWT>
 __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams p, int ntM, int ntN) {
-    constexpr int BM = 256, BN = 256, SB = (BM + BN) * TBK * 2, WOFF = BM * TBK * 2;
+    constexpr int BM = 256, BN = 64 * NWT, WC = 16 * NWT, SB = (BM + BN) * TBK * 2, WOFF = BM * TBK * 2;
+    constexpr int H1 = NWT - 2;                  // tiles of W half 1 (half 0: tiles 0, 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     PPSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     // staging: one instruction = 8 rows x 128 B; lane -> row (lane >> 3), 16-byte chunk (lane & 7) ^ row of the SOURCE
     const int srow = lane >> 3, lch = (lane & 7) ^ srow;
     const bf16_t* srcX[4];      // X quarter q: rows 64 q + 8 wave .. + 8
-    const bf16_t* srcW[4];      // W pieces 2 wave, 2 wave + 1 of the P1 rows (j = 0, 1) and of the P2 rows (j = 2, 3)
+    const bf16_t* srcW[4];      // W pieces of the P1 rows (j = 0, 1) and of the P2 rows (j = 2, 3; NWT = 3: j = 2 only)
     int dstX[4], dstW[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -427,8 +442,11 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int idx = wave * 2 + (j & 1);                                   // 16 pieces of 8 rows per half
-        const int row = (idx >> 2) * 64 + (j >> 1) * 32 + (idx & 3) * 8;      // wave wn reads rows 64 wn + [0, 32) in P1, + [32, 64) in P2
+        // wave-column wn reads W rows WC wn + [0, 32) in P1 and WC wn + [32, WC) in P2; pieces of 8 rows
+        int row;
+        if (j < 2) { const int idx = wave * 2 + j; row = (idx >> 2) * WC + (idx & 3) * 8; }                       // 16 pieces of half 0
+        else if (NWT == 4) { const int idx = wave * 2 + (j & 1); row = (idx >> 2) * WC + 32 + (idx & 3) * 8; }      // 16 pieces of half 1
+        else { row = (wave >> 1) * WC + 32 + (wave & 1) * 8; }                                                      // 8 pieces of half 1 (j = 2)
         int gn = n0 + row + srow; gn = gn < p.N ? gn : p.N - 1;
         srcW[j] = p.B + (size_t)gn * p.ldb + lch * 8;
         dstW[j] = WOFF + row * 128;
@@ -444,35 +462,36 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
         unsigned char* st = smem + (kt & 1) * SB;
         const int k0 = koff(kt);
         glds16(srcW[2 * h] + k0, st + dstW[2 * h]);
-        glds16(srcW[2 * h + 1] + k0, st + dstW[2 * h + 1]);
+        if (h == 0 || NWT == 4) glds16(srcW[2 * h + 1] + k0, st + dstW[2 * h + 1]);
     };
 
     const int r = lane & 15, g = lane >> 4;
-    const int offX = (wr * 128 + r) * 128, offW = WOFF + (wn * 64 + r) * 128;
+    const int offX = (wr * 128 + r) * 128, offW = WOFF + (wn * WC + r) * 128;
     const int c0 = ((0 * 4 + g) ^ (r & 7)) * 16, c1 = ((1 * 4 + g) ^ (r & 7)) * 16;
 
-    f32x4 acc[4][8];
+    f32x4 acc[NWT][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NWT; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+#define EGX_PP_WAIT() do { if (NWT == 4) EGX_WAIT_VM(10); else EGX_WAIT_VM(8); } while (0)
     // prologue, in the order the steady state would have issued them: tile 0 complete, tile 1 up to its P2-P4 regions
     stage_x(0, 0, 2); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1, 3);
     stage_x(1, 0, 2); stage_w(1, 0); stage_w(1, 1);
-    EGX_WAIT_VM(10);
+    EGX_PP_WAIT();          // all but the first four (X quarters 0, 2 and W half 0 of tile 0) may still be in flight
     ring_barrier();
     PPSTAMP(1);
     if (wr == 1) ring_barrier();        // the stagger: waves 4-7 run one barrier behind
 
-    bf16x8 fx[4][2], fw[4][2];          // X half (4 row tiles x 2 K sub-steps), W tiles 0..3 (both halves stay live for P4)
+    bf16x8 fx[4][2], fw[NWT][2];        // X half (4 row tiles x 2 K sub-steps), W tiles (both halves stay live for P4)
 #define EGX_PP_PHASE_TAIL()                                  \
-    EGX_WAIT_VM(10);                                         \
+    EGX_PP_WAIT();                                           \
     ring_barrier();                                          \
     __builtin_amdgcn_s_setprio(1);
-#define EGX_PP_MFMA(XH, I0)                                                                                              \
+#define EGX_PP_MFMA(XH, I0, NI_)                                                                                         \
     _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NI_; ++i)                                                                  \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
                 acc[I0 + i][XH * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[I0 + i][s], fx[j][s], acc[I0 + i][XH * 4 + j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                                       \
@@ -487,35 +506,37 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
         for (int i = 0; i < 2; ++i) { fw[i][0] = lds_read128(st + offW + i * 2048 + c0); fw[i][1] = lds_read128(st + offW + i * 2048 + c1); }
         stage_x(kt + 1, 1, 3);
         EGX_PP_PHASE_TAIL();
-        EGX_PP_MFMA(0, 0);
+        EGX_PP_MFMA(0, 0, 2);
         // P2: W half 1
 #pragma unroll
-        for (int i = 2; i < 4; ++i) { fw[i][0] = lds_read128(st + offW + i * 2048 + c0); fw[i][1] = lds_read128(st + offW + i * 2048 + c1); }
+        for (int i = 2; i < NWT; ++i) { fw[i][0] = lds_read128(st + offW + i * 2048 + c0); fw[i][1] = lds_read128(st + offW + i * 2048 + c1); }
         stage_x(kt + 2, 0, 2);
         EGX_PP_PHASE_TAIL();
-        EGX_PP_MFMA(0, 2);
+        EGX_PP_MFMA(0, 2, H1);
         // P3: X half 1 (the registers of half 0 are dead)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { fx[j][0] = lds_read128(st + offX + (4 + j) * 2048 + c0); fx[j][1] = lds_read128(st + offX + (4 + j) * 2048 + c1); }
         stage_w(kt + 2, 0);
         EGX_PP_PHASE_TAIL();
-        EGX_PP_MFMA(1, 2);
+        EGX_PP_MFMA(1, 2, H1);
         // P4: no reads
         stage_w(kt + 2, 1);
         EGX_PP_PHASE_TAIL();
-        EGX_PP_MFMA(1, 0);
+        EGX_PP_MFMA(1, 0, 2);
     }
 #undef EGX_PP_PHASE_TAIL
 #undef EGX_PP_MFMA
+#undef EGX_PP_WAIT
     PPSTAMP(2);
     if (wr == 0) ring_barrier();        // balance the stagger
     EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup
     PPSTAMP(3);
-    if (nt_epilogue_simple<8>(p)) {
+    if (NWT != 4 || nt_epilogue_simple<8, NWT>(p)) {
         ring_barrier();     // every wave's LDS-DMA has landed (each waited for its own above): the stages are free for the wave regions
-        nt_epilogue_lds<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g, lane, smem + wave * epi_lds_bytes<8>());
+        nt_epilogue_lds<8, NWT>(p, acc, m0 + wr * 128, n0 + wn * WC, m0 / 64 + wr * 2, r, g, lane, smem + wave * epi_lds_bytes<8, NWT>());
+    } else if constexpr (NWT == 4) {
+        nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
     }
-    else nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
     PPSTAMP(4);
 #ifdef EGX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -523,16 +544,19 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
 #endif
 }
 
+template <int NWT>
 static int launch_nt_pp(const WideGemmParams& p, hipStream_t st) {
-    constexpr int LDS = 2 * (256 + 256) * TBK * 2 > 8 * 128 * EPI_LDB ? 2 * (256 + 256) * TBK * 2 : 8 * 128 * EPI_LDB;      // the K loop's two stages / the epilogue's eight wave regions
+    constexpr int BN = 64 * NWT;
+    constexpr int STAGES = 2 * (256 + BN) * TBK * 2, EPI = 8 * epi_lds_bytes<8, NWT>();
+    constexpr int LDS = STAGES > EPI ? STAGES : EPI;        // the K loop's two stages / the epilogue's eight wave regions
     static bool attr = false;
     if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel<NWT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
-    const int ntM = cdiv(p.M, 256), ntN = cdiv(p.N, 256);
+    const int ntM = cdiv(p.M, 256), ntN = cdiv(p.N, BN);
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL(wide_gemm_nt_pp_kernel, dim3(ntM * ntN), dim3(512), LDS, st, p, ntM, ntN);
+    hipLaunchKernelGGL(wide_gemm_nt_pp_kernel<NWT>, dim3(ntM * ntN), dim3(512), LDS, st, p, ntM, ntN);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -570,7 +594,18 @@ int wide_gemm_nt(const WideGemmParams& p_in, hipStream_t st) {
     EGX_CHECK(p.K % TBK == 0 && p.N % 4 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
               "wide_gemm_nt: %dx%dx%d needs K %% 64 == 0, N %% 4 == 0, 16-byte aligned rows", p.M, p.N, p.K);
     const int v = nt_variant(p.M, p.N);
-    if (v == 3) return launch_nt_pp(p, st);
+    if (v == 3) {
+        // 256 x 192 tiles when they fill the last round better (cost = rounds x tile width): N = 768 is 1.5 rounds of 256-column
+        // tiles (2 rounds of time) or exactly 2 rounds of 192-column tiles (1.5). EGX_WIDE_PP192=0 keeps the 256 x 256 tile.
+        static int pp192 = -1;
+        if (pp192 < 0) { const char* e = getenv("EGX_WIDE_PP192"); pp192 = e ? atoi(e) : 1; }
+        if (pp192 && !p.colsum && p.N % 192 == 0) {
+            const long tm = cdiv(p.M, 256);
+            const long c256 = cdiv(tm * cdiv(p.N, 256), 256) * 256, c192 = cdiv(tm * cdiv(p.N, 192), 256) * 192;
+            if (c192 * 5 <= c256 * 4) return launch_nt_pp<3>(p, st);       // a 192-column tile costs ~0.87, not 0.75, of a 256-column one (measured: N = 2304, 0.9 of the rounds x width, lost 9 %)
+        }
+        return launch_nt_pp<4>(p, st);
+    }
     if (v == 2) return launch_nt<256, 256, 128, 2>(p, st);
     // 256-row tiles (8 waves, 3-stage ring) once they fill the chip twice over; 128-row tiles (4 waves) below
     if (v == 1) return launch_nt<256, 128, 64, 3>(p, st);
