@@ -4,7 +4,7 @@
 # be kept into profiles/). Every step checks its exit code: a failed bench never leaves a half-written JSON behind.
 set -euo pipefail
 R=${1:-r03}
-STAGES=${2:-bench,prof,pmc}      # which parts to run
+STAGES=${2:-bench,prof,trace,pmc}      # which parts to run (run pmc first and copy its files into profiles/ when the bench lines are to carry the counters)
 OUT=gpurun_out/final
 mkdir -p $OUT
 bench() {   # bench <name> <bench.py args...>
@@ -44,6 +44,11 @@ prof c3 c3
 prof c4 c4 --steps 5 --warmup 2
 prof c5hoi c5hoi --steps 5 --warmup 2
 prof c5hhi c5hhi --steps 5 --warmup 2
+fi
+if [[ $STAGES == *trace* ]]; then      # one step's kernels in launch order (eager launches)
+for c in c2 c3 c4 c5hoi c5hhi; do
+  python3 tools/step_trace.py $c -- --config $c > /dev/null 2>&1 && cp gpurun_out/steptrace_$c.txt $OUT/${R}_steptrace_$c.txt
+done
 fi
 if [[ $STAGES == *pmc* ]]; then
 python3 tools/pmc_collect.py f32s > $OUT/pmc_f32s.txt 2>&1 && cp gpurun_out/pmc_f32s.json $OUT/${R}_pmc_c2_f32s.json
