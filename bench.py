@@ -547,7 +547,8 @@ def committed_counters(config, dtype, B, T, L, encoder_only=False):
             w = d.get("workload", {})
             if (w.get("config"), w.get("batch"), w.get("frames"), w.get("layers") or 0, bool(w.get("encoder_only"))) != (config, B, T, L or 0, bool(encoder_only)):
                 continue
-            if (w.get("dtype") or dtype) != dtype or "kernels" not in d:
+            wd = w.get("dtype") or ("f32s" if config in ("c1", "c2") else "bf16")      # pmc_collect records the --dtype ARGUMENT (None = the default)
+            if wd != dtype or "kernels" not in d:
                 continue
             if d.get("csrc_sha") != sha:
                 stale = stale or f"{os.path.relpath(f, here)} was taken on other kernel sources (csrc_sha {d.get('csrc_sha')} != {sha}): dropped"
