@@ -612,13 +612,17 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         WideGemmParams t;
         t.A = dy; t.B = x; t.M = n_out; t.N = k_in; t.K = tokens_k; t.lda = ldy; t.ldb = ldx;
         t.Cf = dW; t.ldc = k_in; t.zero_page = zero;
-        // written exactly once into the zeroed flat buffer. EGX_DEC_DIRECT=1 (tuning aid, off): over <= 1024 target rows ONE split
+        // EGX_DEC_DIRECT=1 (tuning aid, off): over <= 1024 target rows ONE split
         // straight into dW (no slab, no reduction), at most eight over the B * S memory rows: removes the batched slab reduction
         // (55-73 us, 230 MB per step) but lengthens the side stream - same-box A/B: C5 HOI 3.95 = 3.95 ms, C5 HHI 2.46 -> 2.62 ms
         static int direct = -1;
         if (direct < 0) { const char* e = getenv("EGX_DEC_DIRECT"); direct = e ? atoi(e) : 0; }
-        t.accumulate = 0;
-        t.tn_max_splits = !direct ? 0 : (tokens_k <= 1024 ? 1 : (tokens_k <= 4096 ? 0 : 8));
+        // a target inside the buffer this call has just zero-filled is overwritten (saves the read of the += ), anything else keeps
+        // the += contract of the header
+        const char* zb = (const char*)zero_buf;
+        const bool zeroed = zb && (const char*)dW >= zb && (const char*)(dW + (size_t)n_out * k_in) <= zb + zero_bytes;
+        t.accumulate = zeroed ? 0 : 1;
+        t.tn_max_splits = !(direct && zeroed) ? 0 : (tokens_k <= 1024 ? 1 : (tokens_k <= 4096 ? 0 : 8));
         const size_t need = align_up(wide_gemm_tn_scratch(n_out, k_in, tokens_k), 256);
         EGX_CHECK(slab_cur + need <= pl.slab_all_bytes, "decoder backward: slab region exhausted");
         void* region = at<char>(scratch, pl.slab_all) + slab_cur;

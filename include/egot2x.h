@@ -383,7 +383,9 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
                     const egx_dec_layer* layers, const float* fc_w, const float* fc_b, int B, float* logits, void* saved, void* scratch,
                     int training, uint64_t seed, void* stream);
 /* d_memory (B * S, d) is overwritten (=); every parameter gradient is accumulated (+=) — `zero_buf` / `zero_bytes` (optional):
- * a buffer the first operation of the call zero-fills (the caller's flat gradient buffer holding all += targets). */
+ * a buffer the first operation of the call zero-fills (the caller's flat gradient buffer holding all += targets).
+ * Both calls are asynchronous on `stream`; internally the K | V projections (forward) and the weight gradients (backward) run on one
+ * library-owned side stream that is forked off and joined back inside the call (also under stream capture). */
 int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_dec_layer* layers, const float* fc_w, int B, const float* d_logits,
                     const void* saved, void* scratch, float* d_memory, float* d_emb, const egx_dec_layer_grads* grads, float* d_fc_w,
                     float* d_fc_b, void* zero_buf, size_t zero_bytes, int training, uint64_t seed, void* stream);

@@ -25,9 +25,15 @@ def _stream():
 
 @pytest.mark.parametrize("M,N,K,bias,relu,res", [(135, 256, 256, True, False, False), (1024, 768, 2048, True, True, False),
                                                  (300, 2304, 768, False, False, True), (128, 128, 64, True, False, True),
-                                                 (4097, 512, 8192, True, False, False), (77, 2048, 768, True, True, True)])
+                                                 (4097, 512, 8192, True, False, False), (77, 2048, 768, True, True, True),
+                                                 # round 3 tile variants: 256 x 192 ping-pong (N = 768 / 1536, >= 256 tiles), 256 x 256
+                                                 # ping-pong, 64 x 64 (<= 256 tiles of 128 x 128), each with ragged M
+                                                 (32768 - 37, 768, 768, True, False, True), (16384, 1536, 256, True, True, False),
+                                                 (32768, 1024, 128, False, False, True), (512, 512, 2048, True, False, True),
+                                                 (11520 - 5, 256, 1024, True, True, False)])
 def test_wide_gemm_nt(egx_lib, cuda, M, N, K, bias, relu, res):
-    """C = A B^T (+ bias) (ReLU) (+ residual): ragged M (clamped loads, masked stores), every epilogue, both output types."""
+    """C = A B^T (+ bias) (ReLU) (+ residual): ragged M (clamped loads, masked stores), every epilogue, both output types,
+    every tile variant (the stores go through LDS since round 3)."""
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(cuda).bfloat16()
     B = (torch.randn(N, K, generator=g) / K ** 0.5).to(cuda).bfloat16()
