@@ -164,7 +164,8 @@ template <int TJ, int NI = 4>
 __host__ __device__ __forceinline__ constexpr int epi_lds_f32_bytes() { return (TJ >= 4 ? TJ * 4 : 16) * epi_ldf<NI>(); }      // fp32 rounds only (TN slabs)
 template <int TJ, int NI = 4>
 __host__ __device__ __forceinline__ constexpr int epi_lds_bytes() { return (TJ * 16) * epi_ldb<NI>() > epi_lds_f32_bytes<TJ, NI>() ? (TJ * 16) * epi_ldb<NI>() : epi_lds_f32_bytes<TJ, NI>(); }
-template <int TJ, int NI = 4>
+// R16: rounds of one 16-row tile through a region of 16 rows (the persistent kernel's epilogue beside its K-loop stages)
+template <int TJ, int NI = 4, bool R16 = false>
 __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[NI][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
     constexpr int EPI_LDB = epi_ldb<NI>(), EPI_LDF = epi_ldf<NI>();
     // phase A (accumulator layout): bias, ReLU, dropout
@@ -189,29 +190,32 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
     };
     if (!p.Cf && !p.residual && !p.mask && !p.colsum) {
         // bf16 out only: the whole sub-tile at once
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                float v[4];
-                value(i, j, v);
-                *reinterpret_cast<uint2*>(region + (j * 16 + r) * EPI_LDB + (i * 16 + 4 * g) * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
-            }
         // a row is NI * 2 pieces of 16 bytes: RPI rows per instruction (NI = 3: 10 rows, four lanes idle)
-        constexpr int LPR = NI * 2, RPI = 64 / LPR, WR = TJ * 16;
+        constexpr int LPR = NI * 2, RPI = 64 / LPR, JR = R16 ? 1 : TJ, WR = JR * 16;      // JR row tiles per round
         const int rr = lane / LPR, ch = lane - rr * LPR, n = nb + ch * 8;
 #pragma unroll
-        for (int k = 0; k < (WR + RPI - 1) / RPI; ++k) {
-            const int row = k * RPI + rr, m = mb + row;
-            if (rr < RPI && row < WR) {
-                const uint4 q = *reinterpret_cast<const uint4*>(region + row * EPI_LDB + ch * 16);
-                if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = q;
+        for (int h = 0; h < TJ / JR; ++h) {
+#pragma unroll
+            for (int jj = 0; jj < JR; ++jj)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    float v[4];
+                    value(i, h * JR + jj, v);
+                    *reinterpret_cast<uint2*>(region + (jj * 16 + r) * EPI_LDB + (i * 16 + 4 * g) * 2) = make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3]));
+                }
+#pragma unroll
+            for (int k = 0; k < (WR + RPI - 1) / RPI; ++k) {
+                const int row = k * RPI + rr, m = mb + h * WR + row;
+                if (rr < RPI && row < WR) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(region + row * EPI_LDB + ch * 16);
+                    if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(p.Cb + (size_t)m * p.ldc + n) = q;
+                }
             }
         }
         return;
     }
     // fp32 (and optionally bf16) out, optional bf16 mask, fp32 residual, column sums: groups of RG row tiles through the region
-    constexpr int RG = TJ >= 4 ? TJ / 4 : 1;           // row tiles per round (32 x 272 B for the 128-row waves)
+    constexpr int RG = 1;                              // row tiles per round (two per round cost the 256-register ping-pong kernel 140 B of scratch)
     constexpr int LPR = NI * 4, RPI = 64 / LPR;        // lanes per row (16-byte pieces), rows per instruction (NI = 3: 5 rows, four lanes idle)
     static_assert(NI == 4 || NI == 3, "column sums below assume four lane rows (NI = 4)");
     const int rr = lane / LPR, ch = lane - rr * LPR, n = nb + ch * 4;
@@ -223,6 +227,26 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
         if (rr == 0 && n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)(prow0 + jg) * p.N + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
         cs[0] = cs[1] = cs[2] = cs[3] = 0.f;
     };
+    // Residual / mask rows of round h + 1 are requested BEFORE the stores of round h, unconditionally (clamped addresses): a load
+    // that is used while older stores are in flight waits for those stores, and a load under a branch is waited for at once -
+    // with the loads inside the store loop every one of the 32 row groups of a 256 x 256 tile paid a store round trip (the
+    // fp32 + residual epilogue cost 55k cycles per tile: FFN2 forward 152 us against 99 us for the plain GEMM).
+    constexpr int KI = (RG * 16 + RPI - 1) / RPI;
+    f32x4 rs[KI];            // (one set: round h + 1 is requested behind the last use of round h)
+    uint2 mk[KI];
+    const bool side = p.residual || p.mask;
+    auto fetch = [&](int h) {
+        if (!side) return;
+        const int nn = n < p.N ? n : 0;
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
+            int m = mb + h * RG * 16 + k * RPI + rr;
+            m = m < p.M ? m : p.M - 1;
+            if (p.residual) rs[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ldr + nn);
+            if (p.mask) mk[k] = *reinterpret_cast<const uint2*>(p.mask + (size_t)m * p.ldm + nn);
+        }
+    };
+    fetch(0);
 #pragma unroll
     for (int h = 0; h < TJ / RG; ++h) {
 #pragma unroll
@@ -233,33 +257,39 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
                 value(i, h * RG + jj, v);
                 *reinterpret_cast<float4*>(region + (jj * 16 + r) * EPI_LDF + (i * 16 + 4 * g) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             }
+        f32x4 qq[KI];           // (vector values: struct arrays end up in scratch memory)
 #pragma unroll
-        for (int k = 0; k < (RG * 16 + RPI - 1) / RPI; ++k) {
+        for (int k = 0; k < KI; ++k) {
+            const int row = k * RPI + rr;
+            const int rowc = (rr < RPI && row < RG * 16) ? row : 0;            // idle lanes re-read row 0 (never stored)
+            f32x4 q = *reinterpret_cast<const f32x4*>(region + rowc * EPI_LDF + ch * 16);
+            if (p.mask) {
+                const uint2 mv = mk[k];
+                q[0] = (mv.x & 0xffffu) ? q[0] * p.mask_scale : 0.f;
+                q[1] = (mv.x >> 16) ? q[1] * p.mask_scale : 0.f;
+                q[2] = (mv.y & 0xffffu) ? q[2] * p.mask_scale : 0.f;
+                q[3] = (mv.y >> 16) ? q[3] * p.mask_scale : 0.f;
+            }
+            if (p.residual) q += rs[k];
+            qq[k] = q;
+        }
+        if (h + 1 < TJ / RG) fetch(h + 1);
+#pragma unroll
+        for (int k = 0; k < KI; ++k) {
             const int row = k * RPI + rr, m = mb + h * RG * 16 + row;
             if (!(rr < RPI && row < RG * 16)) continue;
-            float4 q = *reinterpret_cast<const float4*>(region + row * EPI_LDF + ch * 16);
+            const f32x4 q = qq[k];
             if (m < p.M && n < p.N) {
-                if (p.mask) {
-                    const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + (size_t)m * p.ldm + n);
-                    q.x = (mk.x & 0xffffu) ? q.x * p.mask_scale : 0.f;
-                    q.y = (mk.x >> 16) ? q.y * p.mask_scale : 0.f;
-                    q.z = (mk.y & 0xffffu) ? q.z * p.mask_scale : 0.f;
-                    q.w = (mk.y >> 16) ? q.w * p.mask_scale : 0.f;
-                }
-                if (p.residual) {
-                    const float4 rs = *reinterpret_cast<const float4*>(p.residual + (size_t)m * p.ldr + n);
-                    q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
-                }
-                if (p.Cf) *reinterpret_cast<float4*>(p.Cf + (size_t)m * p.ldc + n) = q;
+                if (p.Cf) *reinterpret_cast<f32x4*>(p.Cf + (size_t)m * p.ldc + n) = q;
                 if (p.Cb) {
-                    const uint2 o = make_uint2(pack2(q.x, q.y), pack2(q.z, q.w));
+                    const uint2 o = make_uint2(pack2(q[0], q[1]), pack2(q[2], q[3]));
                     *reinterpret_cast<uint2*>(p.Cb + (size_t)m * p.ldc + n) = o;
                     if (p.colsum) {     // sums of the values as stored (bf16-rounded), so that db == colsum(stored dY) exactly
                         cs[0] += bf2f((bf16_t)(o.x & 0xffffu)); cs[1] += bf2f((bf16_t)(o.x >> 16));
                         cs[2] += bf2f((bf16_t)(o.y & 0xffffu)); cs[3] += bf2f((bf16_t)(o.y >> 16));
                     }
                 } else if (p.colsum) {
-                    cs[0] += q.x; cs[1] += q.y; cs[2] += q.z; cs[3] += q.w;
+                    cs[0] += q[0]; cs[1] += q[1]; cs[2] += q[2]; cs[3] += q[3];
                 }
             }
         }
@@ -416,7 +446,12 @@ int debug_read_ppstamps(unsigned long long*) { return 1; }
 // 256-column tiles leave the chip's last round half empty (N = 768: 384 tiles = 1.5 rounds, 512 tiles of 192 columns = 2 full
 // rounds of 0.75 the work). Its W half 1 is one tile (P2 / P3: 8 MFMAs), staged by one instruction per wave in P4: seven LDS-DMA
 // loads per K tile, so the uniform wait is vmcnt(8) - any five consecutive phases issue at least eight.
-template <int NWT>
+// PERSIST: the launch has one workgroup per CU and each walks tiles id, id + grid, ...: the next tile's prologue (14 LDS-DMA loads
+// into the K-loop stages) is issued BEFORE the epilogue of the finished tile, which then goes through a small LDS region of its
+// own behind the stages (rounds of 16 rows) - the 3.5k-cycle prologue and part of the store drain disappear under the epilogue.
+// bytes of a wave's 16-row epilogue region in the persistent kernel: bf16 rows only for the 256-column tile (its fp32 rounds do not fit)
+template <int NWT> __host__ __device__ __forceinline__ constexpr int pp_region_bytes() { return NWT == 4 ? 16 * epi_ldb<4>() : epi_lds_f32_bytes<1, NWT>(); }
+template <int NWT, bool PERSIST>
 __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams p, int ntM, int ntN) {
     constexpr int BM = 256, BN = 64 * NWT, WC = 16 * NWT, SB = (BM + BN) * TBK * 2, WOFF = BM * TBK * 2;
     constexpr int H1 = NWT - 2;                  // tiles of W half 1 (half 0: tiles 0, 1)
@@ -424,8 +459,8 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     PPSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wn = wave & 3;
-    const int t = xcd_tile(blockIdx.x, ntM * ntN);
-    const int m0 = (t / ntN) * BM, n0 = (t % ntN) * BN;
+    const int ntiles = ntM * ntN;
+    int id = blockIdx.x, m0, n0;
     const int nk = p.K / TBK;
 
     // staging: one instruction = 8 rows x 128 B; lane -> row (lane >> 3), 16-byte chunk (lane & 7) ^ row of the SOURCE
@@ -433,6 +468,9 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     const bf16_t* srcX[4];      // X quarter q: rows 64 q + 8 wave .. + 8
     const bf16_t* srcW[4];      // W pieces of the P1 rows (j = 0, 1) and of the P2 rows (j = 2, 3; NWT = 3: j = 2 only)
     int dstX[4], dstW[4];
+    auto set_tile = [&](int tid_) {
+    const int t = xcd_tile(tid_, ntiles);
+    m0 = (t / ntN) * BM; n0 = (t % ntN) * BN;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 64 * q + 8 * wave;
@@ -451,6 +489,8 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
         srcW[j] = p.B + (size_t)gn * p.ldb + lch * 8;
         dstW[j] = WOFF + row * 128;
     }
+    };
+    set_tile(id);
     auto koff = [&](int kt) { return (kt < nk ? kt : nk - 1) * TBK; };      // tiles past the end re-fetch the last one (never read)
     auto stage_x = [&](int kt, int qa, int qb) {
         unsigned char* st = smem + (kt & 1) * SB;
@@ -470,16 +510,21 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
     const int c0 = ((0 * 4 + g) ^ (r & 7)) * 16, c1 = ((1 * 4 + g) ^ (r & 7)) * 16;
 
     f32x4 acc[NWT][8];
+
+#define EGX_PP_WAIT() do { if (NWT == 4) EGX_WAIT_VM(10); else EGX_WAIT_VM(8); } while (0)
+    // prologue, in the order the steady state would have issued them: tile 0 complete, tile 1 up to its P2-P4 regions
+    auto prologue = [&]() {
+        stage_x(0, 0, 2); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1, 3);
+        stage_x(1, 0, 2); stage_w(1, 0); stage_w(1, 1);
+    };
+    prologue();
+    for (;;) {
 #pragma unroll
     for (int i = 0; i < NWT; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-#define EGX_PP_WAIT() do { if (NWT == 4) EGX_WAIT_VM(10); else EGX_WAIT_VM(8); } while (0)
-    // prologue, in the order the steady state would have issued them: tile 0 complete, tile 1 up to its P2-P4 regions
-    stage_x(0, 0, 2); stage_w(0, 0); stage_w(0, 1); stage_x(0, 1, 3);
-    stage_x(1, 0, 2); stage_w(1, 0); stage_w(1, 1);
-    EGX_PP_WAIT();          // all but the first four (X quarters 0, 2 and W half 0 of tile 0) may still be in flight
+    EGX_PP_WAIT();          // all but the first four (X quarters 0, 2 and W half 0 of tile 0) may still be in flight (after an
+                            // epilogue its stores are younger than the prologue: the wait covers some of them too - safe)
     ring_barrier();
     PPSTAMP(1);
     if (wr == 1) ring_barrier();        // the stagger: waves 4-7 run one barrier behind
@@ -524,19 +569,31 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
         EGX_PP_PHASE_TAIL();
         EGX_PP_MFMA(1, 0, 2);
     }
+    PPSTAMP(2);
+    if (wr == 0) ring_barrier();        // balance the stagger
+    EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup (the over-fetched K tiles; they are never read)
+    PPSTAMP(3);
+    if constexpr (PERSIST) {
+        ring_barrier();     // every wave's LDS-DMA has landed, every fragment read is over: the stages may be refilled
+        const int mc = m0, nc = n0, nid = id + (int)gridDim.x;
+        const bool more = nid < ntiles;
+        if (more) { set_tile(nid); prologue(); }
+        nt_epilogue_lds<8, NWT, true>(p, acc, mc + wr * 128, nc + wn * WC, mc / 64 + wr * 2, r, g, lane, smem + 2 * SB + wave * pp_region_bytes<NWT>());
+        if (!more) break;
+        id = nid;
+    } else {
+        if (NWT != 4 || nt_epilogue_simple<8, NWT>(p)) {
+            ring_barrier();     // every wave's LDS-DMA has landed (each waited for its own above): the stages are free for the wave regions
+            nt_epilogue_lds<8, NWT>(p, acc, m0 + wr * 128, n0 + wn * WC, m0 / 64 + wr * 2, r, g, lane, smem + wave * epi_lds_bytes<8, NWT>());
+        } else if constexpr (NWT == 4) {
+            nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
+        }
+        break;
+    }
+    }
 #undef EGX_PP_PHASE_TAIL
 #undef EGX_PP_MFMA
 #undef EGX_PP_WAIT
-    PPSTAMP(2);
-    if (wr == 0) ring_barrier();        // balance the stagger
-    EGX_WAIT_VM(0);                     // no LDS-DMA may outlive the workgroup
-    PPSTAMP(3);
-    if (NWT != 4 || nt_epilogue_simple<8, NWT>(p)) {
-        ring_barrier();     // every wave's LDS-DMA has landed (each waited for its own above): the stages are free for the wave regions
-        nt_epilogue_lds<8, NWT>(p, acc, m0 + wr * 128, n0 + wn * WC, m0 / 64 + wr * 2, r, g, lane, smem + wave * epi_lds_bytes<8, NWT>());
-    } else if constexpr (NWT == 4) {
-        nt_epilogue<8>(p, acc, m0 + wr * 128, n0 + wn * 64, m0 / 64 + wr * 2, r, g);
-    }
     PPSTAMP(4);
 #ifdef EGX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,22 +601,47 @@ __global__ __launch_bounds__(512, 1) void wide_gemm_nt_pp_kernel(WideGemmParams 
 #endif
 }
 
-template <int NWT>
-static int launch_nt_pp(const WideGemmParams& p, hipStream_t st) {
+// persistent launch (one workgroup per CU walking the tiles): when the output needs more than one round of tiles and the
+// epilogue's 16-row regions fit behind the two stages (fp32 rows of the 256-column tile do not: 131 072 + 8 x 4 352 > 160 KB)
+// OFF by default (EGX_WIDE_PERSIST=1 enables it): with the uniform vmcnt(10) waits the first phases of the next tile wait for
+// the epilogue's stores anyway, and the 16-row epilogue rounds cost more than the hidden prologue saves - same-box C4 9.31 ms
+// without, 9.61 ms with; gemm_bench +4 % / -2 % / -2.5 % / +3 %. Worth revisiting with exact store counts.
+static int pp_persist_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_WIDE_PERSIST"); v = e ? atoi(e) : 0; }
+    return v;
+}
+template <int NWT, bool PERSIST>
+static int launch_nt_pp_impl(const WideGemmParams& p, hipStream_t st) {
     constexpr int BN = 64 * NWT;
     constexpr int STAGES = 2 * (256 + BN) * TBK * 2, EPI = 8 * epi_lds_bytes<8, NWT>();
-    constexpr int LDS = STAGES > EPI ? STAGES : EPI;        // the K loop's two stages / the epilogue's eight wave regions
+    constexpr int LDS = PERSIST ? STAGES + 8 * pp_region_bytes<NWT>() : (STAGES > EPI ? STAGES : EPI);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr = false;
     if (!attr) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel<NWT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_nt_pp_kernel<NWT, PERSIST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
     const int ntM = cdiv(p.M, 256), ntN = cdiv(p.N, BN);
+    int grid = ntM * ntN;
+    if (PERSIST) {
+        static int cus = 0;
+        if (!cus) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus < 8) cus = 256; cus &= ~7; }
+        if (grid > cus) grid = cus;      // a multiple of 8: the workgroup -> XCD mapping of xcd_tile() stays valid for id + k * grid
+    }
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL(wide_gemm_nt_pp_kernel<NWT>, dim3(ntM * ntN), dim3(512), LDS, st, p, ntM, ntN);
+    hipLaunchKernelGGL((wide_gemm_nt_pp_kernel<NWT, PERSIST>), dim3(grid), dim3(512), LDS, st, p, ntM, ntN);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
+}
+template <int NWT>
+static int launch_nt_pp(const WideGemmParams& p, hipStream_t st) {
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 64 * NWT);
+    const bool fp32_rounds = p.Cf || p.residual || p.mask || p.colsum;
+    if (pp_persist_mode() && tiles > 256 && p.epi_lds && (p.N & 7) == 0 && !p.colsum && !(NWT == 4 && fp32_rounds))
+        return launch_nt_pp_impl<NWT, true>(p, st);
+    return launch_nt_pp_impl<NWT, false>(p, st);
 }
 
 // tile choice. 256 x 256 (EGX_WIDE_TILE=512 forces it, =256 / =128 force the others): N a multiple of 256 and at least 3.5

@@ -11,7 +11,8 @@ torch.manual_seed(0)
 bad = 0
 for M, N, K in [(256, 256, 64), (256, 256, 128), (512, 256, 192), (300, 260, 256), (1024, 768, 768), (4096, 2304, 768), (32768, 768, 2048),
                 (1000, 1000, 1024), (8192, 768, 8192), (777, 516, 320),
-                (32768, 768, 768), (32768, 768, 2304), (32700, 768, 768), (16384, 1536, 512), (65536, 384, 256)]:      # 256 x 192 tiles
+                (32768, 768, 768), (32768, 768, 2304), (32700, 768, 768), (16384, 1536, 512), (65536, 384, 256),       # 256 x 192 tiles
+                (32768, 2048, 256), (24576 - 100, 1024, 320)]:     # persistent 256 x 256 launches (bf16 output)
     A = torch.randn(M, K, device=dev).bfloat16(); B = torch.randn(N, K, device=dev).bfloat16()
     bias = torch.randn(N, device=dev)
     ref = (A.float() @ B.float().t()) + bias
