@@ -227,13 +227,43 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
         if (rr == 0 && n < p.N) *reinterpret_cast<float4*>(p.colsum + (size_t)(prow0 + jg) * p.N + n) = make_float4(cs[0], cs[1], cs[2], cs[3]);
         cs[0] = cs[1] = cs[2] = cs[3] = 0.f;
     };
+    constexpr int KI = (RG * 16 + RPI - 1) / RPI;
     // Residual / mask rows of round h + 1 are requested BEFORE the stores of round h, unconditionally (clamped addresses): a load
     // that is used while older stores are in flight waits for those stores, and a load under a branch is waited for at once -
     // with the loads inside the store loop every one of the 32 row groups of a 256 x 256 tile paid a store round trip (the
     // fp32 + residual epilogue cost 55k cycles per tile: FFN2 forward 152 us against 99 us for the plain GEMM).
-    constexpr int KI = (RG * 16 + RPI - 1) / RPI;
     f32x4 rs[KI];            // (one set: round h + 1 is requested behind the last use of round h)
     uint2 mk[KI];
+    // Fast path for the commonest fp32 epilogue - C = acc (+ bias ...) + residual into fp32, nothing else, the wave's sub-tile fully
+    // inside the output: every load and store below is unconditional, so hipcc counts them and the wait for round h + 1's
+    // residual rows is vmcnt(stores of round h) instead of vmcnt(0). Idle lanes (NI = 3) mirror lane row 0 / row 15.
+    if (p.Cf && p.residual && !p.Cb && !p.mask && !p.colsum && mb + TJ * 16 <= p.M && nb + NI * 16 <= p.N) {
+        int rowl[KI];
+#pragma unroll
+        for (int k = 0; k < KI; ++k) { int rw = k * RPI + (rr < RPI ? rr : 0); rowl[k] = rw < 16 ? rw : 15; }
+        f32x4 ra[KI];
+#pragma unroll
+        for (int k = 0; k < KI; ++k) ra[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(mb + rowl[k]) * p.ldr + n);
+#pragma unroll
+        for (int h = 0; h < TJ; ++h) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float v[4];
+                value(i, h, v);
+                *reinterpret_cast<float4*>(region + r * EPI_LDF + (i * 16 + 4 * g) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            f32x4 qv[KI];
+#pragma unroll
+            for (int k = 0; k < KI; ++k) qv[k] = *reinterpret_cast<const f32x4*>(region + rowl[k] * EPI_LDF + ch * 16) + ra[k];
+            if (h + 1 < TJ) {
+#pragma unroll
+                for (int k = 0; k < KI; ++k) ra[k] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(mb + (h + 1) * 16 + rowl[k]) * p.ldr + n);
+            }
+#pragma unroll
+            for (int k = 0; k < KI; ++k) *reinterpret_cast<f32x4*>(p.Cf + (size_t)(mb + h * 16 + rowl[k]) * p.ldc + n) = qv[k];
+        }
+        return;
+    }
     const bool side = p.residual || p.mask;
     auto fetch = [&](int h) {
         if (!side) return;
