@@ -275,10 +275,10 @@ def run(args) -> int:
             return args.trials
         sync()
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(20):     # (three steps put the sync latency into the estimate: 2.95 s of timed work for a 3.6 s target)
             step_fn()
         sync()
-        est = (time.perf_counter() - t0) / 3 * steps
+        est = (time.perf_counter() - t0) / 20 * steps
         n = max(5, int(args.min_seconds / max(est, 1e-6)) + 1)
         n = min(n, 2000)
         if multi:       # every rank must run the same number of trials
