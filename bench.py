@@ -384,6 +384,8 @@ def run(args) -> int:
             # wide / generic paths (c4, c5*): the backward announces its gradient buffer slice by slice (per encoder layer, last
             # layer first; the decoder's buffer as a whole) and every slice is all-reduced while the rest of the backward runs
             def step_bucketed():
+                for p in params:            # the exchange requires a backward that CREATES every .grad
+                    p.grad = None
                 with ddp.BucketedExchange(params, force=args.force_dist) as ex:
                     fwd_bwd()
                 exch["collectives"] = ex.collectives

@@ -169,15 +169,22 @@ def load() -> C.CDLL:
     # libegot2x.so binds to the SAME runtime instance; loading ours first splits the process across two runtimes.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
-    variant = bool(os.environ.get("EGX_LIB"))       # a variant build (A/B aid) may predate the newest entry points
+    # EGX_LIB=<path> loads a variant build (A/B aid). It goes through the SAME ABI-version and symbol checks: a stale variant
+    # with other struct layouts would corrupt memory instead of failing. EGX_LIB_UNSAFE=1 (development only) skips them.
+    variant = bool(os.environ.get("EGX_LIB"))
+    unsafe = variant and os.environ.get("EGX_LIB_UNSAFE") == "1"
+    if variant:
+        import warnings
+        warnings.warn(f"egot2_amd: EGX_LIB is set, loading {LIB_PATH} instead of the product library"
+                      + (" WITHOUT ABI checks (EGX_LIB_UNSAFE=1)" if unsafe else ""))
     for name, (res, args) in SIGNATURES.items():
-        if variant and not hasattr(lib, name):
+        if unsafe and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
     ver = lib.egx_abi_version()
-    if ver != EGX_ABI_VERSION and not variant:
+    if ver != EGX_ABI_VERSION and not unsafe:
         raise EgxError(f"libegot2x ABI version {ver} != binding version {EGX_ABI_VERSION}; rebuild the library")
     _lib = lib
     return lib

@@ -12,6 +12,7 @@
 // Supported: compute = bf16, d_model a multiple of 128 in [256, 1024], head dim 32 or 64, sy <= 8, S <= 64; anything else
 // stays on the composed path (egot2_amd/decoder.py).
 #include <string.h>
+#include <mutex>
 
 #include "../../include/egot2x.h"
 #include "common.h"
@@ -417,20 +418,53 @@ struct SideStream {
     hipEvent_t kv_ev[16] = {};      // forward: layer l's K | V projection of the memory is done
     int next = 0;
     bool on = false;
-};
-SideStream& side_stream() {
-    static SideStream S;
-    static bool init = false;
-    if (!init) {
-        init = true;
-        const char* e = getenv("EGX_DEC_SIDE");
-        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking) == hipSuccess) {
-            S.on = true;
-            for (auto& v : S.ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) S.on = false;
-            for (auto& v : S.kv_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) S.on = false;
-        }
+    std::mutex mu;                  // forward and (autograd-thread) backward share the event ring
+    // `to` continues behind everything enqueued on `from` so far. Record + wait of one ring event under the lock: two threads
+    // picking the same event between the record and the wait would wait for each other's position.
+    int order(hipStream_t from, hipStream_t to) {
+        std::lock_guard<std::mutex> lk(mu);
+        hipEvent_t e = ev[next]; next = (next + 1) % 8;
+        EGX_HIP(hipEventRecord(e, from));
+        EGX_HIP(hipStreamWaitEvent(to, e, 0));
+        return 0;
     }
-    return S;
+};
+// one side stream per DEVICE, created on that device the first time a decoder call runs there (a process-global stream made
+// on whichever device was current first would be the wrong device's stream for every other one)
+SideStream& side_stream() {
+    enum { MAXDEV = 16 };
+    static SideStream S[MAXDEV];
+    static std::once_flag once[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) dev = 0;
+    std::call_once(once[dev], [dev]() {
+        SideStream& T = S[dev];
+        const char* e = getenv("EGX_DEC_SIDE");
+        if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&T.s, hipStreamNonBlocking) == hipSuccess) {
+            T.on = true;
+            for (auto& v : T.ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) T.on = false;
+            for (auto& v : T.kv_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) T.on = false;
+        }
+    });
+    return S[dev];
+}
+// joins the side stream back into the caller's stream when a call leaves — on the error paths too: an un-joined fork
+// would invalidate an active stream capture (and leave work running that the caller's next launch may overwrite)
+struct SideJoin {
+    SideStream& SS; hipStream_t st; bool forked = false;
+    SideJoin(SideStream& ss, hipStream_t s) : SS(ss), st(s) {}
+    int join() { if (!forked) return 0; forked = false; return SS.order(SS.s, st); }
+    ~SideJoin() { if (forked) (void)SS.order(SS.s, st); }
+};
+// a host seed is baked into a captured graph: every replay would redraw the SAME masks. The encoder's fused kernels have the
+// device-resident seed (egx_config.seed_ptr) for that; the decoder has not, so training-mode dropout under capture is refused.
+int refuse_captured_dropout(const egx_dec_config* cfg, int training, hipStream_t st) {
+    if (!training || !(cfg->p_drop > 0.f || cfg->p_pos > 0.f)) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    EGX_CHECK(cs == hipStreamCaptureStatusNone, "egx_decoder: training-mode dropout (p > 0) cannot be captured in a hipGraph: the host seed "
+              "would be baked in and every replay would repeat the same masks; launch eagerly or capture with p = 0");
+    return 0;
 }
 
 }  // namespace
@@ -456,6 +490,7 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
     if (make_dplan(cfg, B, pl)) return 1;
     EGX_CHECK(tokens && memory && emb && pe && layers && fc_w && logits && saved && scratch, "egx_decoder_fwd: null pointer argument");
     hipStream_t st = (hipStream_t)stream;
+    if (refuse_captured_dropout(cfg, training, st)) return 1;
     const int d = pl.d, dff = pl.dff, Md = (int)pl.Md, Nm = (int)pl.Nm, dh = d / pl.H;
     EGX_HIP(hipMemsetAsync(at<char>(saved, pl.zero), 0, 1024, st));
     const void* zero = at<char>(saved, pl.zero);
@@ -501,10 +536,10 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
     // the K | V projections of the memory (the one large GEMM of a layer) depend on nothing the target-token chain computes: all
     // of them go to the side stream now, beside the chain's 16-WG launches; a layer's cross-attention waits for its own
     SideStream& SS = side_stream();
+    SideJoin sj(SS, st);        // error paths: join whatever was forked
     if (SS.on) {
-        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
-        EGX_HIP(hipEventRecord(e, st));
-        EGX_HIP(hipStreamWaitEvent(SS.s, e, 0));
+        if (SS.order(st, SS.s)) return 1;
+        sj.forked = true;
         for (int l = 0; l < pl.L; ++l) {
             const DLayer& o = pl.layer[l];
             if (nt_on(SS.s, mem16, d, cat<bf16_t>(saved, o.w_kv), Nm, 2 * d, d, layers[l].ca_in_b + d, nullptr, at<bf16_t>(saved, o.kv), 0, none, nullptr)) return 1;
@@ -570,6 +605,7 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
         g.A = cat<float>(saved, pl.xL32); g.B = fc_w; g.C = logits; g.M = Md; g.N = pl.V; g.K = d; g.lda = d; g.ldb = d; g.ldc = pl.V; g.bias = fc_b;
         if (gemm(0, g, 0, 0, nullptr, 0, st)) return 1;
     }
+    sj.forked = false;      // joined already: every layer's cross-attention waited for its kv_ev, the last side-stream operation
     return 0;
 }
 
@@ -580,6 +616,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     if (make_dplan(cfg, B, pl)) return 1;
     EGX_CHECK(tokens && layers && fc_w && d_logits && saved && scratch && grads, "egx_decoder_bwd: null pointer argument");
     hipStream_t st = (hipStream_t)stream;
+    if (refuse_captured_dropout(cfg, training, st)) return 1;
     const int d = pl.d, dff = pl.dff, Md = (int)pl.Md, Nm = (int)pl.Nm, dh = d / pl.H;
     const void* zero = cat<char>(saved, pl.zero);
     if (zero_buf && zero_bytes) EGX_HIP(hipMemsetAsync(zero_buf, 0, zero_bytes, st));
@@ -593,13 +630,11 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     // side stream for the weight gradients: fork() orders it behind everything enqueued on `st` so far
     SideStream& SS = side_stream();
     hipStream_t sd = SS.on ? SS.s : st;
-    bool forked = false;
+    SideJoin sj(SS, st);
     auto fork = [&]() -> int {
         if (!SS.on) return 0;
-        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
-        EGX_HIP(hipEventRecord(e, st));
-        EGX_HIP(hipStreamWaitEvent(sd, e, 0));
-        forked = true;
+        if (SS.order(st, sd)) return 1;
+        sj.forked = true;
         return 0;
     };
     const bf16_t* mem16 = cat<bf16_t>(saved, pl.mem16);
@@ -752,11 +787,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         }
         g = g0;
     }
-    if (forked) {       // join: the slab reduction below (and whatever the caller enqueues next) comes after the side stream's work
-        hipEvent_t e = SS.ev[SS.next]; SS.next = (SS.next + 1) % 8;
-        EGX_HIP(hipEventRecord(e, sd));
-        EGX_HIP(hipStreamWaitEvent(st, e, 0));
-    }
+    if (sj.join()) return 1;    // the slab reduction below (and whatever the caller enqueues next) comes after the side stream's work
     if (d_memory && !mem_started) EGX_HIP(hipMemsetAsync(d_memory, 0, pl.Nm * d * sizeof(float), st));
     if (d_emb) {
         DDrop de = ddrop(training, cfg->p_pos, seed, 0, DS_EMBED);

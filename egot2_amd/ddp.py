@@ -155,7 +155,11 @@ class BucketedExchange:
     laid out in that order — the sequence decoder its whole buffer (it runs before the encoder's backward). Each announcement
     starts an asynchronous all-reduce of that slice; RCCL orders it behind the kernels enqueued so far and runs it beside the
     ones enqueued afterwards. Leaving the block waits for the collectives and exchanges the gradients that were not announced
-    (task heads computed by torch) the way allreduce_gradients does. `force` runs the collectives in a one-rank group."""
+    (task heads computed by torch) the way allreduce_gradients does. `force` runs the collectives in a one-rank group.
+
+    Precondition (checked on entry): no parameter holds a .grad yet — the block must wrap a backward that starts from
+    `zero_grad(set_to_none=True)`. Only PARAMETER gradients live in the announced buffer: activation gradients the backward
+    returns (d(feature) of a trainable upstream head) are separate tensors and are never exchanged."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True, force: bool = False):
         self.params, self.group, self.average, self.force = list(params), group, average, force
@@ -178,6 +182,14 @@ class BucketedExchange:
         if self.active:
             if F_egx.bucket_hook is not None:
                 raise RuntimeError("BucketedExchange: another exchange is active")
+            # Precondition: the wrapped backward must CREATE every .grad (as a view of the announced flat buffer). With a
+            # .grad already present autograd accumulates `p.grad += view` on the compute stream while the asynchronous
+            # all-reduce rewrites that view, and the parameter would be exchanged a second time on exit.
+            stale = sum(1 for p in self.params if p.grad is not None)
+            if stale:
+                raise RuntimeError(f"BucketedExchange: {stale} parameter(s) already hold a .grad; call "
+                                   "optimizer.zero_grad(set_to_none=True) first. For gradient accumulation wrap only the LAST "
+                                   "micro-batch's backward in allreduce_gradients(...) after it instead of this exchange")
             F_egx.bucket_hook = self._on_bucket
         return self
 

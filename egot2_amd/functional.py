@@ -61,6 +61,13 @@ class EncoderSpec:
 
 
 _scratch_cache = {}
+_last_impl = [EGX_IMPL_AUTO]
+
+
+def last_encoder_impl() -> str:
+    """Diagnostic: the implementation the most recent encoder forward ran ("fused" | "wide" | "generic" | ...)."""
+    return {v: k for k, v in IMPL.items()}.get(_last_impl[0], "auto")
+
 # EGX_POISON=1 (testing aid): every workspace handed to the library is filled with 0xFF bytes (NaN in fp32 and bf16) first,
 # so that a kernel reading memory nobody wrote shows up as NaNs instead of passing on whatever the allocator left there
 _POISON = bool(int(__import__("os").environ.get("EGX_POISON", "0") or 0))
@@ -296,6 +303,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.py_slice, ctx.S = py_slice, S
         ctx.spec = spec
         ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
+        _last_impl[0] = ctx.impl
         ctx.fused_path = ctx.impl == EGX_IMPL_FUSED
         ctx.B = B
         ctx.nseg, ctx.nproj, ctx.nhead = nseg, nproj, nhead
@@ -335,7 +343,10 @@ class EncoderFn(torch.autograd.Function):
         i_pos = pk.add(pos_table, need[2], rank=_rr)
         i_lnw = pk.add(ln_w, need[3], rank=_rr)
         i_lnb = pk.add(ln_b, need[4], rank=_rr)
-        i_feat = [pk.add(f, need[5 + i], rank=_rr) for i, f in enumerate(feats)]
+        # d(feature) is a per-sample ACTIVATION gradient: it must never sit in the flat buffer that the data-parallel exchange
+        # all-reduces (in place, on the collective's stream, while autograd hands the same memory to the upstream module).
+        # Every implementation overwrites it (input-gradient GEMM / LayerNorm backward), so it needs no zero fill either.
+        feat_grads = [torch.empty(f.shape, dtype=torch.float32, device=device) if need[5 + i] else None for i, f in enumerate(feats)]
         # proj: (w, b) pairs; layer: 12 tensors in _LAYER_FIELDS order, in_proj_w / out_proj_w are indices 0 and 2
         i_proj = [pk.add(t, need[5 + nseg + i], late=(i % 2 == 0) and bucket_hook is None, rank=_rr) for i, t in enumerate(proj)]
         hook = bucket_hook
@@ -359,7 +370,7 @@ class EncoderFn(torch.autograd.Function):
             segs[i].d_in = ss.d_in
             segs[i].feat_bf16 = int(f.dtype == torch.bfloat16)
             segs[i].pool = int(ss.pool)
-            sgr[i].feat = ptr(g(i_feat[i]))
+            sgr[i].feat = ptr(feat_grads[i])
             if ss.has_proj:
                 segs[i].proj_w, segs[i].proj_b = ptr(proj[2 * pi]), ptr(proj[2 * pi + 1])
                 sgr[i].proj_w, sgr[i].proj_b = ptr(g(i_proj[2 * pi])), ptr(g(i_proj[2 * pi + 1]))
@@ -387,10 +398,18 @@ class EncoderFn(torch.autograd.Function):
         if hook is not None and ctx.impl == EGX_IMPL_WIDE:
             flat_for_cb, spans = pk.flat, dict(pk.rank_span)
 
+            cb_error = []
+
             def _cb(_user, bucket):       # host callback from wide_encoder_bwd: layer n_l - 1 - bucket is complete on the stream
-                if bucket in spans and bucket not in announced:
-                    announced.add(bucket)
+                # ctypes swallows an exception raised in a callback ("Exception ignored"): keep it, leave the bucket
+                # un-announced (the remainder pass below then covers its slice) and re-raise once the launch has returned
+                if cb_error or bucket not in spans or bucket in announced:
+                    return
+                try:
                     hook(flat_for_cb, spans[bucket][0], spans[bucket][1])
+                    announced.add(bucket)
+                except BaseException as e:     # noqa: BLE001
+                    cb_error.append(e)
             cb_keep = _lib.BUCKET_CB(_cb)
             cfg.bucket_cb = C.cast(cb_keep, C.c_void_p)
         defer = bool(spec.defer_small) and ctx.fused_path
@@ -422,6 +441,8 @@ class EncoderFn(torch.autograd.Function):
                                           ptr(scratch), sgr, p_lnw, p_lnb, lgr, int(spec.training), seed,
                                           _stream()))
         launch(cfg)
+        if cb_keep is not None and cb_error:
+            raise cb_error[0]
         if hook is not None and not defer:
             # whatever the per-layer callbacks did not announce (other implementations: everything) is complete now
             done = sorted(pk.rank_span[b] for b in announced)
@@ -442,7 +463,7 @@ class EncoderFn(torch.autograd.Function):
                 launch(cfg2)
             _deferred.append(finish)
         out = [None, g(i_te), g(i_pos), g(i_lnw), g(i_lnb)]
-        out += [g(i) for i in i_feat] + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
+        out += feat_grads + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
         return tuple(out)
 
 

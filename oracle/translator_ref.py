@@ -49,8 +49,9 @@ def sinusoid_table(max_len: int, d: int, dtype=torch.float32) -> torch.Tensor:
     return pe.to(dtype)
 
 
-def self_attention(x: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int) -> torch.Tensor:
-    """x: (B, S, d). Packed in-projection rows = [Wq; Wk; Wv]; per-head softmax(QK^T / sqrt(d_h)) V; out-projection."""
+def self_attention(x: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int, attn_mask=None) -> torch.Tensor:
+    """x: (B, S, d). Packed in-projection rows = [Wq; Wk; Wv]; per-head softmax(QK^T / sqrt(d_h)) V; out-projection.
+    attn_mask (B, H, S, S): keep-scale of the dropout on the probabilities (F.multi_head_attention_forward: dropout(softmax))."""
     B, S, d = x.shape
     dh = d // n_heads
     qkv = linear(x, in_w, in_b)  # (B, S, 3d)
@@ -64,23 +65,39 @@ def self_attention(x: torch.Tensor, in_w, in_b, out_w, out_b, n_heads: int) -> t
     scores = scores - scores.max(dim=-1, keepdim=True).values
     p = torch.exp(scores)
     p = p / p.sum(dim=-1, keepdim=True)
+    if attn_mask is not None:
+        p = p * attn_mask
     o = (p @ v).permute(0, 2, 1, 3).reshape(B, S, d)
     return linear(o, out_w, out_b)
 
 
-def encoder_layer(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_heads: int, eps: float = 1e-5) -> torch.Tensor:
+def _m(x: torch.Tensor, masks, name: str) -> torch.Tensor:
+    """Apply an explicit dropout keep-scale (0 or 1 / (1 - p) per element) when the caller supplies one."""
+    if masks is None or masks.get(name) is None:
+        return x
+    return x * masks[name].to(x.dtype)
+
+
+def encoder_layer(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_heads: int, eps: float = 1e-5,
+                  masks=None) -> torch.Tensor:
+    """`masks` (train mode with EXPLICIT masks; None = eval): dict of keep-scales at nn.TransformerEncoderLayer's four dropout
+    sites — "attn" (B, H, S, S) on the softmax output, "res1" (B, S, d) = dropout1 on the attention branch, "ffn" (B, S, d_ff)
+    = dropout on the activated hidden, "res2" (B, S, d) = dropout2 on the FFN branch (torch 1.12 transformer.py
+    _sa_block / _ff_block as constructed at HHI/models/ttm/model_taskspecific.py:211-215)."""
     g = lambda k: sd[prefix + k]  # noqa: E731
     a = self_attention(x, g("self_attn.in_proj_weight"), g("self_attn.in_proj_bias"),
-                       g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_heads)
-    x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"), eps)
-    h = torch.relu(linear(x, g("linear1.weight"), g("linear1.bias")))
+                       g("self_attn.out_proj.weight"), g("self_attn.out_proj.bias"), n_heads,
+                       None if masks is None else masks.get("attn"))
+    x = layer_norm(x + _m(a, masks, "res1"), g("norm1.weight"), g("norm1.bias"), eps)
+    h = _m(torch.relu(linear(x, g("linear1.weight"), g("linear1.bias"))), masks, "ffn")
     f = linear(h, g("linear2.weight"), g("linear2.bias"))
-    return layer_norm(x + f, g("norm2.weight"), g("norm2.bias"), eps)
+    return layer_norm(x + _m(f, masks, "res2"), g("norm2.weight"), g("norm2.bias"), eps)
 
 
-def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_layers: int, n_heads: int) -> torch.Tensor:
+def encoder(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_layers: int, n_heads: int, masks=None) -> torch.Tensor:
+    """masks: None, or {"layers": [per-layer dict for encoder_layer, ...]}."""
     for i in range(n_layers):
-        x = encoder_layer(x, sd, f"{prefix}layers.{i}.", n_heads)
+        x = encoder_layer(x, sd, f"{prefix}layers.{i}.", n_heads, masks=None if masks is None else masks["layers"][i])
     return x
 
 
@@ -91,45 +108,53 @@ def n_layers_of(sd: Dict[str, torch.Tensor], prefix: str) -> int:
     return n
 
 
-def encode_prepare(feat: torch.Tensor, proj_w, proj_b, ln_w, ln_b, task_vec, pe_rows) -> torch.Tensor:
-    """(B, T, d_in) -> (B, T, d): LN_shared(proj(feat)) + task_embed[k] + pe[0:T] (position restarts per task)."""
+def encode_prepare(feat: torch.Tensor, proj_w, proj_b, ln_w, ln_b, task_vec, pe_rows, pos_mask=None) -> torch.Tensor:
+    """(B, T, d_in) -> (B, T, d): LN_shared(proj(feat)) + task_embed[k] + pe[0:T] (position restarts per task).
+    pos_mask (B, T, d): keep-scale of PositionalEncoding's dropout, applied to the SUM (reference :149-151)."""
     x = feat if proj_w is None else linear(feat, proj_w, proj_b)
     x = layer_norm(x, ln_w, ln_b)
     if task_vec is not None:
         x = x + task_vec
     if pe_rows is not None:
         x = x + pe_rows
+    if pos_mask is not None:
+        x = x * pos_mask.to(x.dtype)
     return x
 
 
 # ---- HHI: TTM translators ------------------------------------------------------------------------
-def hhi_tokens(sd, feats: Sequence[torch.Tensor], names: Sequence[str], task_ids: Sequence[int]) -> torch.Tensor:
+def hhi_tokens(sd, feats: Sequence[torch.Tensor], names: Sequence[str], task_ids: Sequence[int], masks=None) -> torch.Tensor:
+    """masks["pos"] (B, S, d) in PACKED token order: segment k takes its own T_k rows."""
     pe = sd["pos_embed.pe"][:, 0, :]
     xs = []
+    off = 0
     for f, n, k in zip(feats, names, task_ids):
         T = f.shape[1]
+        pm = None if masks is None or masks.get("pos") is None else masks["pos"][:, off:off + T]
         xs.append(encode_prepare(f, sd[f"proj_{n}.weight"], sd[f"proj_{n}.bias"], sd["ln.weight"], sd["ln.bias"],
-                                 sd["task_embed"][0, k], pe[:T]))
+                                 sd["task_embed"][0, k], pe[:T], pm))
+        off += T
     return torch.cat(xs, dim=1)
 
 
-def ttm_forward(sd, n_heads: int, ttm_out, lam_out, asd_out=None) -> torch.Tensor:
-    """TaskFusionMFTransformer{2,3}Task.forward on backbone features -> (B, 2) logits."""
+def ttm_forward(sd, n_heads: int, ttm_out, lam_out, asd_out=None, masks=None) -> torch.Tensor:
+    """TaskFusionMFTransformer{2,3}Task.forward on backbone features -> (B, 2) logits.
+    masks = {"pos": ..., "layers": [...]}: train-mode forward under explicit dropout masks (tests/dropmask.py)."""
     feats, names, ids = [ttm_out, lam_out], ["ttm", "lam"], [0, 1]
     if asd_out is not None:
         feats.append(asd_out); names.append("asd"); ids.append(2)
-    x = hhi_tokens(sd, feats, names, ids)
-    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    x = hhi_tokens(sd, feats, names, ids, masks)
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads, masks)
     pooled = x.mean(dim=1)
     y = layer_norm(pooled, sd["linear_head.0.weight"], sd["linear_head.0.bias"])
     return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])
 
 
-def asd_forward(sd, n_heads: int, ttm_out, lam_out, asd_out) -> torch.Tensor:
+def asd_forward(sd, n_heads: int, ttm_out, lam_out, asd_out, masks=None) -> torch.Tensor:
     """HHI/models/asd TaskFusionMFTransformer3Task: token order asd, ttm, lam (task ids 2, 0, 1); returns the
     encoded ASD block as (B*T, d)."""
-    x = hhi_tokens(sd, [asd_out, ttm_out, lam_out], ["asd", "ttm", "lam"], [2, 0, 1])
-    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads)
+    x = hhi_tokens(sd, [asd_out, ttm_out, lam_out], ["asd", "ttm", "lam"], [2, 0, 1], masks)
+    x = encoder(x, sd, "transformer_encoder.", n_layers_of(sd, "transformer_encoder."), n_heads, masks)
     B, T = asd_out.shape[0], asd_out.shape[1]
     return x[:, :T, :].reshape(B * T, -1)
 
@@ -159,18 +184,22 @@ def weighted_ce(logits: torch.Tensor, target: torch.Tensor, weight: Sequence[flo
 
 
 # ---- HOI translators ----------------------------------------------------------------------------
-def hoi_tokens(sd, feats: Sequence[torch.Tensor], proj_names: Sequence[Optional[str]]) -> torch.Tensor:
-    """cat(proj_k(feat_k)) -> shared LN -> + learned pe (1, S, d)."""
+def hoi_tokens(sd, feats: Sequence[torch.Tensor], proj_names: Sequence[Optional[str]], masks=None) -> torch.Tensor:
+    """cat(proj_k(feat_k)) -> shared LN -> + learned pe (1, S, d).
+    masks["feat"][k] (B, T_k, d): keep-scale of the feature dropout `self.dp(proj_k(feat_k))`
+    (HOI/models/pnr/video_model_transfer_3task.py:249-252), None entries = no dropout on that segment."""
     xs = [f if n is None else linear(f, sd[f"{n}.weight"], sd[f"{n}.bias"]) for f, n in zip(feats, proj_names)]
+    if masks is not None and masks.get("feat") is not None:
+        xs = [x if m is None else x * m.to(x.dtype) for x, m in zip(xs, masks["feat"])]
     x = torch.cat(xs, dim=1)
     return layer_norm(x, sd["ln.weight"], sd["ln.bias"]) + sd["pe"]
 
 
-def lta4_forward(sd, n_heads: int, feat_pnr, feat_oscc, feat_action, feat_lta, num_classes: Sequence[int]):
+def lta4_forward(sd, n_heads: int, feat_pnr, feat_oscc, feat_action, feat_lta, num_classes: Sequence[int], masks=None):
     """TaskFusionMFTransformerLTA4Task.forward (training-mode head, no activation) on features:
     pnr/oscc (B, n, 8192), action (B, n, d), lta (B, n, 2048) -> [(B, Z, n_verbs), (B, Z, n_nouns)]."""
-    x = hoi_tokens(sd, [feat_pnr, feat_oscc, feat_action, feat_lta], ["proj_pnr", "proj_oscc", None, "proj_lta"])
-    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+    x = hoi_tokens(sd, [feat_pnr, feat_oscc, feat_action, feat_lta], ["proj_pnr", "proj_oscc", None, "proj_lta"], masks)
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads, masks)
     pooled = x.mean(dim=1)
     z = 0
     outs = []
@@ -181,11 +210,11 @@ def lta4_forward(sd, n_heads: int, feat_pnr, feat_oscc, feat_action, feat_lta, n
     return list(torch.split(y, list(num_classes), dim=-1))
 
 
-def pnr3_forward(sd, n_heads: int, pnr_feat, oscc_feat, slow_feat, fast_feat) -> torch.Tensor:
-    """TaskFusionMFTransformer3TaskDropout.forward on features (eval / p = 0): the shared `ln` is also the first
-    element of linear_head."""
-    x = hoi_tokens(sd, [pnr_feat, oscc_feat, slow_feat, fast_feat], ["proj1", "proj2", "proj3_slow", "proj3_fast"])
-    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads)
+def pnr3_forward(sd, n_heads: int, pnr_feat, oscc_feat, slow_feat, fast_feat, masks=None) -> torch.Tensor:
+    """TaskFusionMFTransformer3TaskDropout.forward on features (eval / p = 0, or train mode under explicit `masks`): the
+    shared `ln` is also the first element of linear_head."""
+    x = hoi_tokens(sd, [pnr_feat, oscc_feat, slow_feat, fast_feat], ["proj1", "proj2", "proj3_slow", "proj3_fast"], masks)
+    x = encoder(x, sd, "transformer.", n_layers_of(sd, "transformer."), n_heads, masks)
     pooled = x.mean(dim=1)
     y = layer_norm(pooled, sd["ln.weight"], sd["ln.bias"])
     return linear(y, sd["linear_head.1.weight"], sd["linear_head.1.bias"])

@@ -408,6 +408,77 @@ def test_two_rank_wide_bucketed_exchange_equals_single_process(egx_lib, cuda):
         assert (got - ref).norm().item() <= 2e-2 * ref.norm().item() + 1e-6, k      # bf16 operands: the batch split changes roundings
 
 
+def _action_head(dev):
+    """Stand-in for the trainable SlowFast head whose output is the LTA translator's (unprojected) action stream."""
+    torch.manual_seed(5)
+    return torch.nn.Linear(256, 256).to(dev)
+
+
+def _wide_featgrad_worker(rank, world, port, q):
+    """the action features of the LTA translators come from a TRAINABLE head, so the encoder's backward
+    returns d(feature). That activation gradient must stay out of the exchanged flat buffer (it is per-sample, and autograd
+    hands it upstream while the collectives run)."""
+    import os
+    import torch.distributed as dist
+    from egot2_amd import ddp, functional as F_egx
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    m, head = _lta_small(dev), _action_head(dev)
+    ddp.broadcast_parameters(m)
+    sf = [f.to(dev) for f in ddp.shard_batch(seeded_feats(43, _LTA_SHAPES), rank, world)]
+    params = [p for p in m.parameters() if p.requires_grad] + list(head.parameters())
+    seen = []
+    act = head(sf[2])
+    act.retain_grad()
+    with ddp.BucketedExchange(params) as ex:
+        inner = F_egx.bucket_hook
+
+        def spy(flat, lo, hi):
+            seen.append((flat.data_ptr() + 4 * lo, flat.data_ptr() + 4 * hi))
+            inner(flat, lo, hi)
+        F_egx.bucket_hook = spy
+        _lta_loss(m, [sf[0], sf[1], act, sf[3]]).backward()
+    torch.cuda.synchronize()
+    a = act.grad.data_ptr()
+    outside = all(not (lo <= a < hi) for lo, hi in seen)
+    if rank == 0:
+        q.put((outside, act.grad.float().cpu().numpy().copy(),
+               {k: p.grad.float().cpu().numpy().copy() for k, p in list(m.named_parameters()) + [("acthead." + k, p) for k, p in head.named_parameters()]
+                if p.grad is not None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucketed_exchange_keeps_feature_gradients_private(egx_lib, cuda):
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 43500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_wide_featgrad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outside, dact, grads = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert outside, "d(feature) lies inside a slice of the flat buffer that was all-reduced"
+    m, head = _lta_small(cuda), _action_head(cuda)
+    feats = [f.to(cuda) for f in seeded_feats(43, _LTA_SHAPES)]
+    act = head(feats[2])
+    act.retain_grad()
+    _lta_loss(m, [feats[0], feats[1], act, feats[3]]).backward()
+    # rank 0's d(feature) is the PER-SAMPLE gradient of its own shard (x world: its loss is a mean over half the batch), untouched by the exchange
+    ref = 2.0 * act.grad[:4].float().cpu()
+    got = torch.from_numpy(dact)
+    assert (got - ref).norm().item() <= 3e-2 * ref.norm().item() + 1e-7
+    named = dict(list(m.named_parameters()) + [("acthead." + k, p) for k, p in head.named_parameters()])
+    for k, g in grads.items():
+        ref, got = named[k].grad.float().cpu(), torch.from_numpy(g)
+        assert (got - ref).norm().item() <= 3e-2 * ref.norm().item() + 1e-6, k
+
+
 @pytest.mark.parametrize("compute,impl", [("f32", "fused"), ("bf16", "fused"), ("f32s", "fused"), ("f32", "generic"), ("bf16", "generic")])
 def test_deterministic_mode_gives_bit_identical_gradients(egx_lib, cuda, compute, impl):
     """same inputs + same dropout seed => bit-identical logits and gradients across runs with
