@@ -11,10 +11,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 11
+EGX_ABI_VERSION = 12
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
-EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE = 0, 1, 2, 3
+EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED = 0, 1, 2, 3, 4
 
 _fp = C.c_void_p  # all device pointers travel as raw addresses
 

@@ -31,6 +31,7 @@ struct LayerOff {
 };
 struct Plan {
     int B = 0, S = 0, d = 0, H = 0, dff = 0, L = 0, nseg = 0;
+    int vB = 0, tpc = 1;    // fused kernels: workgroups ("virtual clips") and 48-token tiles per clip; vB = B unless the tiled mode (S > 48) is planned
     size_t N = 0;
     int seg_off[EGX_MAX_SEGMENTS];
     size_t seg_pre[EGX_MAX_SEGMENTS], seg_stats[EGX_MAX_SEGMENTS];
@@ -60,7 +61,7 @@ static int make_plan(const egx_config* cfg, const egx_segment* segs, int B, Plan
     EGX_CHECK(cfg->compute == EGX_F32 || cfg->compute == EGX_BF16 || cfg->compute == EGX_F32_SPLIT, "compute=%d unknown", cfg->compute);
     EGX_CHECK(B > 0, "empty batch (B=%d)", B);
     EGX_CHECK(cfg->out_tokens >= 0, "out_tokens=%d", cfg->out_tokens);
-    pl.B = B; pl.d = cfg->d_model; pl.H = cfg->n_heads; pl.dff = cfg->d_ff; pl.L = cfg->n_layers; pl.nseg = cfg->n_segments;
+    pl.B = B; pl.vB = B; pl.tpc = 1; pl.d = cfg->d_model; pl.H = cfg->n_heads; pl.dff = cfg->d_ff; pl.L = cfg->n_layers; pl.nseg = cfg->n_segments;
     int S = 0;
     for (int i = 0; i < pl.nseg; ++i) {
         EGX_CHECK(segs[i].T > 0, "segment %d has T=%d", i, segs[i].T);
@@ -131,7 +132,7 @@ static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan&
     for (int i = 0; i < pl.nseg; ++i) { d_in[i] = segs[i].d_in; T[i] = segs[i].T; hp[i] = segs[i].proj_w != nullptr; }
     return fused_supported(pl.d, pl.H, pl.dff, pl.S, pl.nseg, d_in, T, hp);
 }
-static size_t fused_mask_words(const Plan& pl) { return (size_t)pl.L * pl.B * (pl.dff / 32) * 64; }
+static size_t fused_mask_words(const Plan& pl) { return (size_t)pl.L * pl.vB * (pl.dff / 32) * 64; }
 static size_t fused_res_bytes(const Plan& pl) { return align_up((size_t)(1 + 2 * pl.L) * pl.N * pl.d * 4, 256); }
 // saved = [pre + 2L residual blocks][ReLU sign bits of the FFN hidden: one u32 per (layer, clip, hidden block, lane)][packs]
 static size_t fused_act_bytes(const Plan& pl) { return fused_res_bytes(pl) + align_up(fused_mask_words(pl) * 4, 256); }
@@ -166,7 +167,7 @@ static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segmen
 // operand tiles instead of being recomputed there (ffn_dw_kernel, the recompute variant, is kept as the egx_ffn_dw unit hook).
 static bool store_hidden() { return true; }     // (the recompute variant of the clip kernels was dropped in round 3: their FFN loops store unconditionally)
 static size_t fused_hid_total(const egx_config* cfg, const Plan& pl) {
-    return store_hidden() ? align_up((size_t)pl.L * fused_hid_bytes(pl.B, pl.dff, cfg->compute == EGX_BF16), 256) : 0;
+    return store_hidden() ? align_up((size_t)pl.L * fused_hid_bytes(pl.vB, pl.dff, cfg->compute == EGX_BF16), 256) : 0;
 }
 // saved = [activations][packed weights][H tiles]
 static size_t fused_hid_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
@@ -182,13 +183,44 @@ static size_t fused_x1p_offset(const egx_config* cfg, const egx_segment* segs, c
 }
 // behind them: the input of every layer (L, N, d) and its Q | K | V rows (L, B, 48, 3d), fp32 (the backward loads instead of recomputing)
 static size_t fused_xin_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * pl.d * plane_elem_bytes(cfg), 256) : 0);
+    return fused_x1p_offset(cfg, segs, pl) + (split_planes(cfg) ? align_up((size_t)pl.L * pl.vB * FUSED_TOK_PAD * pl.d * plane_elem_bytes(cfg), 256) : 0);
 }
 static size_t fused_qkv_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_xin_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.N * pl.d * 4, 256);
 }
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    return fused_qkv_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.B * FUSED_TOK_PAD * 3 * pl.d * 4, 256);
+    return fused_qkv_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.vB * FUSED_TOK_PAD * 3 * pl.d * 4, 256);
+}
+// ---- tiled mode (d = 128, 48 < S <= 512): the same kernels over 48-token tiles, attention between the launches. Behind the fused
+// layout of the tile grid: every layer's attention output (L, N, d) and log-sum-exp (L, B, H, S), then room for the output tokens
+// and the pooled vector of a translator call
+static void plan_tiled(Plan& pl) { pl.tpc = cdiv(pl.S, FUSED_TOK_PAD); pl.vB = pl.B * pl.tpc; }
+static size_t tiled_attn_offset(const egx_config* cfg, const egx_segment* segs, const Plan& vp) { return align_up(fused_saved_bytes(cfg, segs, vp), 256); }
+static size_t tiled_lse_offset(const egx_config* cfg, const egx_segment* segs, const Plan& vp) { return tiled_attn_offset(cfg, segs, vp) + align_up((size_t)vp.L * vp.N * vp.d * 4, 256); }
+static size_t tiled_tokens_offset(const egx_config* cfg, const egx_segment* segs, const Plan& vp) { return tiled_lse_offset(cfg, segs, vp) + align_up((size_t)vp.L * vp.B * vp.H * vp.S * 4, 256); }
+static size_t tiled_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& vp) {
+    return tiled_tokens_offset(cfg, segs, vp) + align_up((vp.N + (size_t)vp.B) * vp.d * 4, 256);
+}
+static bool tiled_ok(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    if (pl.d != 128 || pl.H != 4 || pl.dff % 128 != 0 || pl.dff < 128) return false;
+    if (pl.S <= FUSED_TOK_PAD || pl.S > TILED_MAX_S) return false;
+    if (pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1) return false;
+    if (packed_feats(segs, pl.nseg) || cfg->p_feat > 0.f) return false;
+    if (cfg->compute != EGX_BF16 && cfg->compute != EGX_F32_SPLIT) return false;     // exact-fp32 MFMA: the generic kernels
+    if (cfg->compute == EGX_BF16 && !ffn_dw_bf16_planes()) return false;
+    if (cfg->out_tokens != 0 && cfg->out_tokens != pl.S) return false;
+    for (int i = 0; i < pl.nseg; ++i)
+        if (!segs[i].proj_w || segs[i].d_in % 128 != 0) return false;
+    return true;
+}
+static bool use_tiled(const egx_config* cfg, const egx_segment* segs, const Plan& pl, bool* err) {
+    *err = false;
+    const bool ok = tiled_ok(cfg, segs, pl);
+    if (cfg->impl == EGX_IMPL_TILED) {
+        if (!ok) { set_error("tiled implementation does not support this configuration (needs d=128, h=4, 48 < S <= %d, compute bf16 or f32s, d_ff%%128==0, projected segments, <=4 layers)", TILED_MAX_S); *err = true; }
+        return ok;
+    }
+    return cfg->impl == EGX_IMPL_AUTO && ok;
 }
 
 // scratch of the fused backward: per layer the operands of the weight-gradient kernels, then d(seg), the per-clip
@@ -197,6 +229,7 @@ struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes;
+    size_t datt, dres, delta, dtok;         // tiled mode only
     size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
     int P;
 };
@@ -205,14 +238,14 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     memset(&s, 0, sizeof(s));
     size_t cur = 0;
     size_t nd = pl.N * pl.d * 4;
-    size_t nd3 = (size_t)pl.B * FUSED_TOK_PAD * pl.d * 6;        // g2 leaves as three bf16 planes on the 48-row clip grid in split mode
+    size_t nd3 = (size_t)pl.vB * FUSED_TOK_PAD * pl.d * 6;        // g2 leaves as three bf16 planes on the 48-row clip grid in split mode
     for (int l = 0; l < pl.L && l < FUSED_MAX_LAYERS; ++l) {
         s.x1[l] = take(cur, nd); s.g2[l] = take(cur, nd3); s.attn_o[l] = take(cur, nd);
         s.g1[l] = take(cur, nd); s.dqkv[l] = take(cur, 3 * nd);
     }
     for (int i = 0; i < pl.nseg; ++i) s.dseg[i] = take(cur, (size_t)pl.B * segs[i].T * pl.d * 4);
     s.P = fused_partial_len(pl.L, pl.nseg) + fused_head_partial_len(head_n_out);
-    s.partials = take(cur, (size_t)pl.B * s.P * 4);
+    s.partials = take(cur, (size_t)pl.vB * s.P * 4);
     size_t slab = ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr);
     slab = size_max(slab, gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)pl.N));
     slab = size_max(slab, gemm_scratch_bytes(2, pl.d, pl.d, (int)pl.N));
@@ -223,6 +256,11 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     s.ffn_slab[0] = s.slabs;
     for (int l = 1; l < pl.L && l < FUSED_MAX_LAYERS; ++l) s.ffn_slab[l] = take(cur, ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr));
     s.dhid = take(cur, fused_hid_total(cfg, pl));
+    if (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) {       // tiled mode: d(attention output), the residual gradient, delta, d(tokens) of a translator call
+        s.datt = take(cur, nd); s.dres = take(cur, nd);
+        s.delta = take(cur, (size_t)pl.B * pl.H * pl.S * 4);
+        s.dtok = take(cur, nd);
+    }
     s.bytes = cur;
     return s;
 }
@@ -388,8 +426,15 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     if (make_plan(cfg, segs, B, pl)) return 1;
     size_t wsv = 0, wsc = 0;
     if (wide_ok(cfg, segs, B)) wide_workspace(cfg, segs, B, &wsv, &wsc);
-    if (saved_bytes) *saved_bytes = size_max(size_max(pl.saved_bytes, wsv), fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
-    if (scratch_bytes) *scratch_bytes = size_max(size_max(pl.scratch_bytes, wsc), fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
+    size_t tsv = 0, tsc = 0;
+    if (tiled_ok(cfg, segs, pl)) {
+        Plan vp = pl;
+        plan_tiled(vp);
+        tsv = tiled_saved_bytes(cfg, segs, vp);
+        tsc = fused_bwd_scratch(cfg, segs, vp, 0).bytes;
+    }
+    if (saved_bytes) *saved_bytes = size_max(size_max(size_max(pl.saved_bytes, wsv), tsv), fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
+    if (scratch_bytes) *scratch_bytes = size_max(size_max(size_max(pl.scratch_bytes, wsc), tsc), fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
     return 0;
 }
 
@@ -405,6 +450,8 @@ int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B) {
     if (make_plan(cfg, segs, B, pl)) return -1;
     bool ferr;
     if (use_fused(cfg, segs, pl, &ferr)) return EGX_IMPL_FUSED;
+    if (ferr) return -1;
+    if (use_tiled(cfg, segs, pl, &ferr)) return EGX_IMPL_TILED;
     if (ferr) return -1;
     if (use_wide(cfg, segs, pl, &ferr)) return EGX_IMPL_WIDE;
     if (ferr) return -1;
@@ -429,8 +476,12 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     EGX_CHECK(with_head ? (logits_out != nullptr) : (tokens_out != nullptr), "null output pointer");
     EGX_CHECK(!with_head || (head->ln_w && head->ln_b && head->b && head->n_out >= 1 && head->n_out <= FUSED_HEAD_MAX_OUT),
               "head needs ln_w, ln_b, W, b and 1 <= n_out <= %d", FUSED_HEAD_MAX_OUT);
-    bool ferr;
-    if (use_fused(cfg, segs, pl, &ferr)) {
+    bool ferr, terr = false;
+    const bool fused = use_fused(cfg, segs, pl, &ferr);
+    const bool tiled = !fused && !ferr && use_tiled(cfg, segs, pl, &terr);
+    if (fused || tiled) {
+        Plan vp = pl;               // sizes of the tile grid: vp.vB workgroups ("virtual clips"); vp.B / vp.N stay the real clips / tokens
+        if (tiled) plan_tiled(vp);
         FusedFwdParams fp;
         memset(&fp, 0, sizeof(fp));
         // rewrite the weights into MFMA-fragment order (once per forward; they live behind the saved activations)
@@ -438,7 +489,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         memset(&pk, 0, sizeof(pk));
         pk.mode = comp;
         pk.seed_advance = (cfg->advance_seed && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
-        FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
+        FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, (char*)saved + fused_act_bytes(vp));
         auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose, float scale = 1.f) -> const void* {
             PackDesc& dsc = pk.d[pk.n++];
             dsc.src = src; dsc.dst = dst; dsc.R = R; dsc.K = K; dsc.ld = ld; dsc.transpose = transpose; dsc.scale = scale;
@@ -453,6 +504,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, PL.proj[i], d, segs[i].d_in, segs[i].d_in, 0); fs.proj_b = segs[i].proj_b;
             fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos;
             fs.T = segs[i].T; fs.d_in = segs[i].d_in; fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
+            fs.row0 = 0; fs.Tfull = segs[i].T;
         }
         for (int l = 0; l < pl.L; ++l) {
             FusedLayer& fl = fp.layer[l];
@@ -476,28 +528,54 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fl.res2_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2).key;
         }
         fp.ln_w = ln_w; fp.ln_b = ln_b; fp.eps = cfg->ln_eps;
-        fp.nseg = pl.nseg; fp.n_layers = pl.L; fp.B = B; fp.S = S; fp.d_ff = pl.dff;
+        fp.nseg = pl.nseg; fp.n_layers = pl.L; fp.B = vp.vB; fp.S = tiled ? FUSED_TOK_PAD : S; fp.d_ff = pl.dff;
+        fp.tpc = vp.tpc; fp.S_clip = S; fp.Ntok = pl.N; fp.mode = FUSED_MODE_FULL;
         fp.tokens_out = tokens_out;
         fp.out_T = cfg->out_tokens > 0 ? cfg->out_tokens : S;
-        if (with_head) {
+        if (with_head && !tiled) {
             fp.head.ln_w = head->ln_w; fp.head.ln_b = head->ln_b; fp.head.W = head->W; fp.head.b = head->b; fp.head.n_out = head->n_out;
             fp.logits_out = logits_out;
         }
         fp.saved_pre = (float*)saved;
         fp.saved_res = (float*)saved + (size_t)N * d;
-        fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(pl));
-        fp.hid_out = store_hidden() ? (char*)saved + fused_hid_offset(cfg, segs, pl) : nullptr;
-        fp.x1p_out = split_planes(cfg) ? (unsigned short*)((char*)saved + fused_x1p_offset(cfg, segs, pl)) : nullptr;
-        fp.xin_out = (float*)((char*)saved + fused_xin_offset(cfg, segs, pl));
-        fp.qkv_out = (float*)((char*)saved + fused_qkv_offset(cfg, segs, pl));
+        fp.relu_bits = (uint32_t*)((char*)saved + fused_res_bytes(vp));
+        fp.hid_out = store_hidden() ? (char*)saved + fused_hid_offset(cfg, segs, vp) : nullptr;
+        fp.x1p_out = split_planes(cfg) ? (unsigned short*)((char*)saved + fused_x1p_offset(cfg, segs, vp)) : nullptr;
+        fp.xin_out = (float*)((char*)saved + fused_xin_offset(cfg, segs, vp));
+        fp.qkv_out = (float*)((char*)saved + fused_qkv_offset(cfg, segs, vp));
         Drop dpz = make_drop(training, cfg->p_pos, seed, 0, SITE_POS);
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
         fp.rot_mode = ffn_rot_mode();
         if (pack_weights(pk, st)) return 1;
-        return fused_forward(fp, comp, st);
+        if (!tiled) return fused_forward(fp, comp, st);
+        // tiled mode: token preparation + Q | K | V of layer 0, then per layer [attention of every clip] [out-projection .. LayerNorm2
+        // + Q | K | V of the next layer] (2 L + 1 launches), then the pooled head on the output tokens
+        float* attn = (float*)((char*)saved + tiled_attn_offset(cfg, segs, vp));
+        float* lse = (float*)((char*)saved + tiled_lse_offset(cfg, segs, vp));
+        float* extra = (float*)((char*)saved + tiled_tokens_offset(cfg, segs, vp));
+        if (!fp.tokens_out) fp.tokens_out = extra;
+        fp.attn_in = attn;
+        fp.mode = FUSED_MODE_PRE;
+        if (fused_forward(fp, comp, st)) return 1;
+        for (int l = 0; l < pl.L; ++l) {
+            TiledAttnParams ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.qkv = fp.qkv_out + (size_t)l * vp.vB * FUSED_TOK_PAD * 3 * d;
+            ap.attn_o = attn + (size_t)l * N * d;
+            ap.lse = lse + (size_t)l * B * pl.H * S;
+            ap.B = B; ap.S = S; ap.tpc = vp.tpc;
+            ap.drop_key = fp.layer[l].attn_key; ap.drop_thresh = fp.layer[l].attn_thresh; ap.drop_inv = fp.layer[l].drop_inv;
+            ap.seed_ptr = cfg->seed_ptr; ap.layer = l;
+            if (tiled_attn_fwd(ap, comp, st)) return 1;
+            fp.mode = FUSED_MODE_POST; fp.l0 = l;
+            if (fused_forward(fp, comp, st)) return 1;
+        }
+        if (with_head)
+            return pool_head_fwd(fp.tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, extra + (size_t)N * d, logits_out, st);
+        return 0;
     }
-    if (ferr) return 1;
+    if (ferr || terr) return 1;
     {
         bool werr;
         EGX_CHECK(cfg->out_tokens == 0 || cfg->out_tokens == S, "out_tokens is implemented by the fused per-clip kernels only (egx_encoder_impl() == EGX_IMPL_FUSED)");
@@ -593,19 +671,23 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     const bool with_head = head && head->W;
     EGX_CHECK((with_head ? (const void*)d_logits : (const void*)d_tokens) && saved && scratch && ln_w, "null pointer argument");
     {
-        bool ferr;
-        if (use_fused(cfg, segs, pl, &ferr)) {
+        bool ferr, terr = false;
+        const bool fused = use_fused(cfg, segs, pl, &ferr);
+        const bool tiled = !fused && !ferr && use_tiled(cfg, segs, pl, &terr);
+        if (fused || tiled) {
             hipStream_t st = (hipStream_t)stream;
             const int d = pl.d, S = pl.S, comp = cfg->compute;
             const int N = (int)pl.N;
-            FusedPackLayout PL = fused_pack_layout(cfg, segs, pl, (char*)saved + fused_act_bytes(pl));
-            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, pl, with_head ? head->n_out : 0);
+            Plan vp = pl;
+            if (tiled) plan_tiled(vp);
+            FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, (char*)saved + fused_act_bytes(vp));
+            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, (with_head && !tiled) ? head->n_out : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int i = 0; i < pl.nseg; ++i) {
                 FusedSeg& fs = bp.seg[i];
                 fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos; fs.T = segs[i].T; fs.d_in = segs[i].d_in;
-                fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
+                fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride; fs.row0 = 0; fs.Tfull = segs[i].T;
                 bp.dseg_out[i] = fptr(scratch, SC.dseg[i]);
             }
             for (int l = 0; l < pl.L; ++l) {
@@ -623,21 +705,24 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 fl.res2_key = make_drop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2).key;
                 fl.x1_out = fptr(scratch, SC.x1[l]); fl.g2_out = fptr(scratch, SC.g2[l]); fl.attn_o_out = fptr(scratch, SC.attn_o[l]);
                 fl.g1_out = fptr(scratch, SC.g1[l]); fl.dqkv_out = fptr(scratch, SC.dqkv[l]);
-                fl.x_in_out = const_cast<float*>((const float*)((const char*)saved + fused_xin_offset(cfg, segs, pl))) + (size_t)l * N * d;      // saved by the forward
+                fl.x_in_out = const_cast<float*>((const float*)((const char*)saved + fused_xin_offset(cfg, segs, vp))) + (size_t)l * N * d;      // saved by the forward
+                // tiled mode: the attention output was saved by the forward too (the per-clip kernels recompute it in P10)
+                if (tiled) fl.attn_o_out = const_cast<float*>((const float*)((const char*)saved + tiled_attn_offset(cfg, segs, vp))) + (size_t)l * N * d;
             }
             bp.ln_w = ln_w; bp.ln_b = ln_b; bp.eps = cfg->ln_eps;
-            bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = B; bp.S = S; bp.d_ff = pl.dff;
+            bp.nseg = pl.nseg; bp.n_layers = pl.L; bp.B = vp.vB; bp.S = tiled ? FUSED_TOK_PAD : S; bp.d_ff = pl.dff;
+            bp.tiled = tiled ? 1 : 0; bp.tpc = vp.tpc; bp.S_clip = S; bp.Ntok = pl.N;
             bp.d_tokens = d_tokens;
             bp.out_T = cfg->out_tokens > 0 ? cfg->out_tokens : S;
-            if (with_head) {
+            if (with_head && !tiled) {
                 bp.head.ln_w = head->ln_w; bp.head.ln_b = head->ln_b; bp.head.W = head->W; bp.head.b = head->b; bp.head.n_out = head->n_out;
                 bp.d_logits = d_logits;
                 bp.head_off = fused_partial_len(pl.L, pl.nseg);
             }
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
-            bp.saved_qkv = (const float*)((const char*)saved + fused_qkv_offset(cfg, segs, pl));
-            bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(pl));
+            bp.saved_qkv = (const float*)((const char*)saved + fused_qkv_offset(cfg, segs, vp));
+            bp.relu_bits = (const uint32_t*)((const char*)saved + fused_res_bytes(vp));
             bp.dhid_out = store_hidden() ? (char*)scratch + SC.dhid : nullptr;
             bp.xg_planes = split_planes(cfg) ? 1 : 0;
             EGX_CHECK(cfg->zero_bytes % 16 == 0 && (((uintptr_t)cfg->zero_buf) & 15) == 0, "zero_buf must be 16-byte aligned and sized");
@@ -650,12 +735,43 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             const int stage = cfg->bwd_stage;
             EGX_CHECK(stage >= 0 && stage <= 2, "bwd_stage=%d", stage);
             if (stage == 2) bp.zero_buf = nullptr;
-            if (stage != 2 && fused_backward(bp, comp, st)) return 1;
+            if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
+            if (stage != 2 && tiled) {
+                // L + 1 launches of the tile kernel with the attention backward of every clip between them
+                if (with_head) {        // pooled head backward -> d(tokens); it accumulates into the caller's buffer: zero that first
+                    const float* extra = (const float*)((const char*)saved + tiled_tokens_offset(cfg, segs, vp));
+                    float* dt = fptr(scratch, SC.dtok);
+                    if (bp.zero_buf) { EGX_HIP(hipMemsetAsync(bp.zero_buf, 0, bp.zero_n * 4, st)); bp.zero_buf = nullptr; }
+                    if (pool_head_bwd(d_logits, extra + (size_t)N * d, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->n_out, dt,
+                                      head_grads ? head_grads->ln_w : nullptr, head_grads ? head_grads->ln_b : nullptr,
+                                      head_grads ? head_grads->W : nullptr, head_grads ? head_grads->b : nullptr, st)) return 1;
+                    bp.d_tokens = dt;
+                }
+                bp.datt = fptr(scratch, SC.datt); bp.dres = fptr(scratch, SC.dres);
+                const float* lse = (const float*)((const char*)saved + tiled_lse_offset(cfg, segs, vp));
+                for (int l = pl.L - 1; l >= 0; --l) {
+                    bp.l_back = l; bp.l_front = l + 1 < pl.L ? l + 1 : -1;
+                    if (fused_backward(bp, comp, st)) return 1;
+                    bp.zero_buf = nullptr;
+                    TiledAttnParams ap;
+                    memset(&ap, 0, sizeof(ap));
+                    ap.qkv = bp.saved_qkv + (size_t)l * vp.vB * FUSED_TOK_PAD * 3 * d;
+                    ap.attn_o = bp.layer[l].attn_o_out;
+                    ap.lse = const_cast<float*>(lse) + (size_t)l * B * pl.H * S;
+                    ap.d_o = bp.datt; ap.delta = fptr(scratch, SC.delta); ap.dqkv = bp.layer[l].dqkv_out;
+                    ap.B = B; ap.S = S; ap.tpc = vp.tpc;
+                    ap.drop_key = bp.layer[l].attn_key; ap.drop_thresh = bp.layer[l].attn_thresh; ap.drop_inv = bp.layer[l].drop_inv;
+                    ap.seed_ptr = cfg->seed_ptr; ap.layer = l;
+                    if (tiled_attn_bwd(ap, comp, st)) return 1;
+                }
+                bp.l_back = -1; bp.l_front = 0;
+                if (fused_backward(bp, comp, st)) return 1;
+            }
 
             // small parameter gradients: sum the per-clip partials
             ReducePartialsParams rp;
             memset(&rp, 0, sizeof(rp));
-            rp.B = B; rp.P = SC.P; rp.partials = bp.partials;
+            rp.B = vp.vB; rp.P = SC.P; rp.partials = bp.partials;
             auto add_dst = [&](float* dst, int off, int len) { if (dst) { rp.d[rp.n].dst = dst; rp.d[rp.n].off = off; rp.d[rp.n].len = len; ++rp.n; } };
             for (int l = 0; l < pl.L; ++l) {
                 const egx_layer_grads& gw = layer_grads[l];
@@ -672,7 +788,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(seg_grads[i].add_vec, og + 256 + i * 256, 128);
                 add_dst(seg_grads[i].proj_b, og + 256 + i * 256 + 128, 128);
             }
-            if (with_head && head_grads) {
+            if (with_head && head_grads && !tiled) {
                 int oh = fused_partial_len(pl.L, pl.nseg);
                 add_dst(head_grads->ln_w, oh, 128); add_dst(head_grads->ln_b, oh + 128, 128);
                 add_dst(head_grads->b, oh + 256, head->n_out);
@@ -695,12 +811,12 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                     fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
                     fp.seed_ptr = cfg->seed_ptr; fp.layer = l;
                     if (store_hidden()) {
-                        size_t lo = (size_t)l * fused_hid_bytes(B, pl.dff, comp == EGX_BF16);
-                        fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, pl) + lo;
+                        size_t lo = (size_t)l * fused_hid_bytes(vp.vB, pl.dff, comp == EGX_BF16);
+                        fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, vp) + lo;
                         fp.dhs = (const char*)scratch + SC.dhid + lo;
-                        fp.B = B;
+                        fp.B = vp.vB;
                         fp.xg_planes = bp.xg_planes;
-                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, pl) + (size_t)l * B * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
+                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, vp) + (size_t)l * vp.vB * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
                     }
                     // every layer's slabs (and the partial rows) are summed by ONE launch behind the last layer's kernel
                     if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, (char*)scratch + SC.ffn_slab[l], st, nullptr, cfg->deterministic != 0, &red)) return 1;
@@ -751,7 +867,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             }
             return 0;
         }
-        if (ferr) return 1;
+        if (ferr || terr) return 1;
     }
     {
         bool werr;

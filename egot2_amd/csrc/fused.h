@@ -14,6 +14,7 @@ struct FusedSeg {
     const float* add_vec;   // [128] or null
     const float* pos;       // rows of 128 with stride pos_stride, or null
     int T, d_in, off, pos_stride;
+    int row0, Tfull;        // tiled mode (S > 48): this descriptor covers frames [row0, row0 + T) of a segment of Tfull frames (else 0, T)
 };
 
 struct FusedLayer {
@@ -61,7 +62,15 @@ struct FusedFwdParams {
                             // input and its in-projection (22k + 17k of its 300k cycles in split mode; 24 KB + 69 KB per clip)
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;   // when non-null the dropout keys are derived in-kernel from *seed_ptr (hipGraph replay)
+    // ---- tiled mode (d = 128 with 48 < S <= 512, fused_tiled.hip drives it): a workgroup is one 48-token TILE of a clip ("virtual
+    // clip" v = clip * tpc + j holds tokens [48 j, 48 j + 48) of the clip); B = number of tiles; the dense (N, .) arrays are
+    // addressed by the global token index, the 48-row grids by the tile. Attention runs between the launches (tiled_attn.hip).
+    int tpc, S_clip;        // tiles per clip, tokens per clip (full mode: 1, S)
+    size_t Ntok;            // real tokens B_clips * S_clip: the layer stride of the dense saved arrays
+    int mode, l0;           // FUSED_MODE_*; POST: the layer whose attention output `attn_in` holds
+    const float* attn_in;   // (L, Ntok, 128) attention outputs (before the out-projection), written by tiled_attn_fwd
 };
+enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2 };
 
 // one matrix to rewrite into MFMA-fragment order (A operand, rows = M dimension); transpose reads src[k][row]
 struct PackDesc {
@@ -159,6 +168,12 @@ struct FusedBwdParams {
     float* partials; int P;
     uint64_t pos_key; uint32_t pos_thresh; float pos_inv;
     const uint64_t* seed_ptr;
+    // ---- tiled mode (see FusedFwdParams): one launch runs [the in-projection input gradient of layer l_front] + [LayerNorm2 ..
+    // out-projection input gradient of layer l_back] or, with l_back < 0, the token-preparation backward
+    int tpc, S_clip; size_t Ntok;
+    int tiled, l_front, l_back;     // l_front < 0: the launch starts from d_tokens; l_back < 0: it ends with the token preparation
+    float* datt;                    // (Ntok, 128) gradient w.r.t. the attention output of layer l_back (written) 
+    float* dres;                    // (Ntok, 128) gradient reaching the layer input through the residual (written for l_back, read for l_front)
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 
@@ -198,6 +213,23 @@ void timing_enable(int on);
 void timing_begin(int which, hipStream_t st);
 void timing_end(int which, hipStream_t st);
 int timing_read(int which, double* total_ms, int* count);
+
+// ---- attention of the tiled mode (tiled_attn.hip): one workgroup per (clip, head, query / key range), K | V (forward, dQ pass) or
+// Q | dO (dK / dV pass) of the whole clip in LDS, every score of a 16-query tile in accumulator registers (S <= 512)
+struct TiledAttnParams {
+    const float* qkv;       // (B * tpc * 48, 384) Q | K | V rows on the 48-row tile grid = clip c's tokens at rows c * tpc * 48 + s
+    float* attn_o;          // (Ntok, 128) forward: written; backward: read (delta = rowsum(dO . O))
+    float* lse;             // (B, 4, S) log-sum-exp of the scaled scores
+    const float* d_o;       // backward: (Ntok, 128) gradient w.r.t. attn_o
+    float* delta;           // backward: (B, 4, S) sum_k P dP per query (written by the dQ pass, read by the dK / dV pass)
+    float* dqkv;            // backward: (Ntok, 384) dense
+    int B, S, tpc;
+    uint64_t drop_key; uint32_t drop_thresh; float drop_inv;
+    const uint64_t* seed_ptr; int layer;
+};
+constexpr int TILED_MAX_S = 512;
+int tiled_attn_fwd(const TiledAttnParams& p, int compute, hipStream_t st);
+int tiled_attn_bwd(const TiledAttnParams& p, int compute, hipStream_t st);
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);
 size_t fused_lds_bytes(int NT);

@@ -97,7 +97,11 @@ int debug_read_stamps(unsigned long long* out, int n) {
 }
 
 // ---- forward kernel -------------------------------------------------------------------------------
-template <int CM, int NT>
+// TILED (48 < S <= 512, see FusedFwdParams): the workgroup is one 48-token tile of a clip and the kernel is cut at the attention:
+// FUSED_MODE_PRE = token preparation + Q | K | V of layer 0; FUSED_MODE_POST = out-projection .. LayerNorm2 of layer l0 on the
+// attention output tiled_attn_fwd left in `attn_in`, then Q | K | V of layer l0 + 1 (or the output tokens). The full-clip
+// instantiation (TILED = false) compiles to the code it was before the tiled mode existed.
+template <int CM, int NT, bool TILED>
 __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SP = NT * 16;                 // padded token count
@@ -114,8 +118,17 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int clip = blockIdx.x;
-    const int S = p.S;
+    const int clip = blockIdx.x;            // TILED: the tile ("virtual clip"): index of every 48-row grid
+    int S, c_real, t0;                      // tokens of this workgroup, the clip they belong to, their first token within it
+    size_t tokbase;                         // global index of the first token: row of the dense (Ntok, .) arrays, dropout row key
+    if constexpr (TILED) {
+        c_real = clip / p.tpc;
+        t0 = (clip - c_real * p.tpc) * 48;
+        S = min(48, p.S_clip - t0);
+        tokbase = (size_t)c_real * p.S_clip + t0;
+    } else {
+        c_real = clip; t0 = 0; S = p.S; tokbase = (size_t)clip * S;
+    }
     // keep lane-constant fragment addresses local to their phase (hipcc otherwise hoists them all to kernel entry
     // and spills them around the phases)
 #define EGX_PHASE()                                              \
@@ -129,8 +142,23 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     const bool dev_seed = p.seed_ptr != nullptr;
     const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
-    if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
+    int* const nseg_slot = reinterpret_cast<int*>(segtab + FUSED_MAX_SEG);
+    if constexpr (TILED) {
+        // the segments that intersect this tile, as descriptors of their own: frames [row0, row0 + T) at tile rows [off, off + T)
+        if (tid == 0) {
+            int n = 0;
+            for (int i = 0; i < p.nseg; ++i) {
+                FusedSeg o = p.seg[i];
+                const int lo = max(o.off, t0), hi = min(o.off + o.T, t0 + 48);
+                if (hi > lo) { o.Tfull = o.T; o.row0 = lo - o.off; o.T = hi - lo; o.off = lo - t0; segtab[n++] = o; }
+            }
+            *nseg_slot = n;
+        }
+    } else {
+        if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
+    }
     __syncthreads();
+    const int nseg_t = TILED ? *nseg_slot : p.nseg;
     auto seg_of = [&](int i) {      // wave-uniform copy of descriptor i in scalar registers
         static_assert(sizeof(FusedSeg) % 4 == 0, "descriptor is copied word by word");
         FusedSeg o;
@@ -142,6 +170,28 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     };
     STAMP(10);
 
+    bool skip_front = false;        // TILED / POST: the first layer of this launch starts behind its attention
+    int l_begin = 0;
+    if constexpr (TILED) {
+        if (p.mode == FUSED_MODE_POST) {
+            // layer input -> Xs (residual), attention output -> Qs (operand of the out-projection); padded rows zero
+            skip_front = true; l_begin = p.l0;
+            for (int i = tid; i < SP * LDX / 4; i += 256) {
+                reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0, 0, 0, 0};
+                reinterpret_cast<f32x4*>(Qs)[i] = f32x4{0, 0, 0, 0};
+                reinterpret_cast<f32x4*>(X1)[i] = f32x4{0, 0, 0, 0};
+            }
+            __syncthreads();
+            const f32x4* xs = reinterpret_cast<const f32x4*>(p.xin_out + ((size_t)p.l0 * p.Ntok + tokbase) * FD);
+            const f32x4* as = reinterpret_cast<const f32x4*>(p.attn_in + ((size_t)p.l0 * p.Ntok + tokbase) * FD);
+            for (int i = tid; i < S * (FD / 4); i += 256) {
+                const int row = i >> 5, c = (i & 31) << 2;
+                *reinterpret_cast<f32x4*>(Xs + row * LDX + c) = xs[i];
+                *reinterpret_cast<f32x4*>(Qs + row * LDX + c) = as[i];
+            }
+        }
+    }
+    if (!TILED || !skip_front) {
     // ---- token preparation: proj GEMM (feature-major) -> LDS token-major -> LN + task embedding + position.
     // Steps = (segment, 16-row tile, 128-wide K chunk), two register sets. ROLLING REFILL as in the FFN loop: a fragment's
     // registers are reloaded with the same fragment of step i + 2 right behind the MFMAs that consumed it, every load is
@@ -150,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     // steps of a clip each paid a full HBM / L2 round trip (40k cycles for 0.8 GF; the weight stream alone needs ~12k).
     {
         struct Step { int sgi, t0, k0; };
-        auto valid = [&](const Step& s) { return s.sgi < p.nseg; };
+        auto valid = [&](const Step& s) { return s.sgi < nseg_t; };
         auto advance = [&](Step s) {
             s.k0 += 128;
             const int d_in = __builtin_amdgcn_readfirstlane(segtab[s.sgi].d_in), T = __builtin_amdgcn_readfirstlane(segtab[s.sgi].T);
@@ -163,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             const FusedSeg sg = seg_of(s.sgi);
             const int trow = s.t0 + r;
             Src o;
-            o.frow = sg.feat + ((size_t)clip * sg.T + (trow < sg.T ? trow : 0)) * sg.d_in + s.k0;   // rows >= T read row 0 (discarded at the store)
+            o.frow = sg.feat + ((size_t)c_real * (TILED ? sg.Tfull : sg.T) + (TILED ? sg.row0 : 0) + (trow < sg.T ? trow : 0)) * sg.d_in + s.k0;   // rows >= T read row 0 (discarded at the store)
             o.wp = sg.proj_wp; o.nkb = sg.d_in / 32; o.kb0 = s.k0 / 32;
             o.bias = sg.proj_b + wave * 32 + 4 * q;
             return o;
@@ -270,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[4 * j + e] = __builtin_fmaf(p_on, pv[j][e], __builtin_fmaf(a_on, av[j][e], y[4 * j + e]));     // (y + emb) + pos
             if (p.pos_thresh) {
-                uint32_t orow = (uint32_t)(clip * S + row);
+                uint32_t orow = (uint32_t)(tokbase + row);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) y[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
             }
@@ -282,10 +332,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             row = row < S ? row : S - 1;
             const int c0 = (t_ & 3) * 32;
             int sgi = 0;
-            while (sgi + 1 < p.nseg && row >= segtab[sgi + 1].off) ++sgi;
+            while (sgi + 1 < nseg_t && row >= segtab[sgi + 1].off) ++sgi;
             const FusedSeg sg = segtab[sgi];
             const float* ap = sg.add_vec ? sg.add_vec + c0 : p.ln_w + c0;
-            const float* pp = sg.pos ? sg.pos + (size_t)(row - sg.off) * sg.pos_stride + c0 : p.ln_w + c0;
+            const float* pp = sg.pos ? sg.pos + (size_t)(row - sg.off + (TILED ? sg.row0 : 0)) * sg.pos_stride + c0 : p.ln_w + c0;
             a_on = sg.add_vec ? 1.f : 0.f;
             p_on = sg.pos ? 1.f : 0.f;
 #pragma unroll
@@ -293,21 +343,23 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 av[j] = *reinterpret_cast<const f32x4*>(ap + 4 * j);
                 pv[j] = *reinterpret_cast<const f32x4*>(pp + 4 * j);
             }
-            store_block(p.saved_pre + (size_t)clip * S * FD, Xs, S);
+            store_block(p.saved_pre + tokbase * FD, Xs, S);
             __syncthreads();        // the LayerNorm below writes Xs in place
         });
     }
+    }       // token preparation
     __syncthreads();
 
-    for (int l = 0; l < p.n_layers; ++l) {
+    for (int l = l_begin; l < p.n_layers; ++l) {
         const FusedLayer& w = p.layer[l];
         const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
         const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
         const uint64_t k_ffn = dev_seed ? site_key(seed_dev, l, SITE_FFN) : w.ffn_key;
         const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
-        float* sv_res1 = p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
-        float* sv_res2 = p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
+        float* sv_res1 = TILED ? p.saved_res + ((size_t)(2 * l) * p.Ntok + tokbase) * FD : p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
+        float* sv_res2 = TILED ? p.saved_res + ((size_t)(2 * l + 1) * p.Ntok + tokbase) * FD : p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
 
+        if (!TILED || !skip_front) {
         STAMP(2);
         EGX_PHASE();
         // Q | K | V (with bias) leave for the backward pass, which loads them instead of recomputing the layer input (LayerNorm +
@@ -378,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     }
                 }
             }
-            store_block(p.xin_out + ((size_t)l * p.B + clip) * S * FD, Xs, S);      // no global load follows before the out-projection
+            store_block(TILED ? p.xin_out + ((size_t)l * p.Ntok + tokbase) * FD : p.xin_out + ((size_t)l * p.B + clip) * S * FD, Xs, S);      // no global load follows before the out-projection
+            if constexpr (TILED) return;        // the attention of the whole clip is another launch (tiled_attn_fwd)
             if (NT < 4) {   // zero the key padding columns SP..63 of V^T
                 for (int i = tid; i < FD * (64 - SP); i += 256) {
                     int c = i / (64 - SP), k = SP + i % (64 - SP);
@@ -391,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         STAMP(3);
         EGX_PHASE();
         // ---- attention: wave = head. S^T = K Q^T (key rows, query columns), softmax over rows, O^T = V^T P^T
-        {
+        if constexpr (!TILED) {
             const int h = wave;
             const float scale = 0.17677669529663687f;   // 1/sqrt(32)
             f32x4 sc[NT][NT];                            // [key tile][query tile]
@@ -477,6 +530,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 }
         }
         __syncthreads();
+        }       // Q | K | V + attention
+        skip_front = false;
 
         STAMP(4);
         EGX_PHASE();
@@ -518,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         float o[4] = {acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w};
                         float4 xr = *reinterpret_cast<const float4*>(Xs + tok * LDX + f0);
                         if (w.res_thresh) {
-                            uint32_t orow = (uint32_t)(clip * S + tok);
+                            uint32_t orow = (uint32_t)(tokbase + tok);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] *= drop_scale(k_res1, orow, (uint32_t)(f0 + e), w.res_thresh, w.drop_inv);
                         }
@@ -683,7 +738,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 #ifdef EGX_DIAG_NOHASH
                             const uint2 h = make_uint2(cq * 0x9E3779B1u + t, cq * 0x85EBCA77U + r);
 #else
-                            const uint2 h = rand_quad(k_ffn, (uint32_t)(clip * 64 + t * 16 + r), cq);
+                            const uint2 h = rand_quad(k_ffn, TILED ? (uint32_t)(tokbase + t * 16 + r) : (uint32_t)(clip * 64 + t * 16 + r), cq);
 #endif
                             // dropped units become negative: the ReLU below zeroes them and their sign bit marks them dead
                             hacc[i][t][0] = keep_lo(h.x, w.ffn_thresh) ? hacc[i][t][0] + bv[i][0] : -1.f;
@@ -780,7 +835,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     float f[4] = {a0.x + a1.x + a2.x + a3.x + b2.x, a0.y + a1.y + a2.y + a3.y + b2.y,
                                   a0.z + a1.z + a2.z + a3.z + b2.z, a0.w + a1.w + a2.w + a3.w + b2.w};
                     if (w.res_thresh) {
-                        uint32_t orow = (uint32_t)(clip * S + row);
+                        uint32_t orow = (uint32_t)(tokbase + row);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) f[e] *= drop_scale(k_res2, orow, (uint32_t)(c0 + 4 * j + e), w.res_thresh, w.drop_inv);
                     }
@@ -792,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         {
             bool last = (l + 1 == p.n_layers);
             ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
-                if (last && p.tokens_out && row < p.out_T) store32(p.tokens_out + ((size_t)clip * p.out_T + row) * FD + c0, y);
+                if (last && p.tokens_out && (TILED || row < p.out_T)) store32(p.tokens_out + (TILED ? tokbase + row : (size_t)clip * p.out_T + row) * FD + c0, y);
                 if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
             }, [&] { store_block(sv_res2, X1, S); });        // (the LayerNorm leaves X1 alone)
         }
@@ -805,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     }
 
     // ---- optional pooled head: logits = Linear(LN(mean_s tokens)); tokens of the last layer are in Xs
-    if (p.head.n_out > 0) {
+    if (!TILED && p.head.n_out > 0) {
         float* pooled = X1;                      // 128 floats of scratch (X1 is dead)
         if (tid < FD) pooled[tid] = colsum_lds(Xs, 0, S, tid) * (1.f / (float)S);
         __syncthreads();
@@ -870,7 +925,7 @@ int timing_read(int which, double* total_ms, int* count) {
 
 size_t fused_lds_bytes(int NT) {
     int SP = NT * 16;
-    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg);
+    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16;
 }
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {
@@ -885,29 +940,19 @@ bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const 
     return true;
 }
 
-template <int CM>
+template <int CM, bool TILED>
 static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     // NT = 2 (S <= 32) is not instantiated: shorter sequences run the 48-row kernel with masked padding.
-    int NT = p.S <= 48 ? 3 : cdiv(p.S, 16);
-    size_t lds = fused_lds_bytes(NT);
-    dim3 grid(p.B), block(256);
-#define EGX_FWD_CASE(N)                                                                                          \
-    case N: {                                                                                                    \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, N>),               \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
-        timing_begin(TIMER_FUSED_FWD, st);                                                                       \
-        hipLaunchKernelGGL((fused_fwd_kernel<CM, N>), grid, block, lds, st, p);                                \
-        timing_end(TIMER_FUSED_FWD, st);                                                                         \
-    } break;
-    switch (NT) {
-        EGX_FWD_CASE(3)
-        default: EGX_CHECK(false, "fused: S=%d unsupported", p.S);
+    EGX_CHECK(p.S <= 48, "fused: S=%d unsupported", p.S);
+    const size_t lds = fused_lds_bytes(3);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
     }
-#undef EGX_FWD_CASE
+    timing_begin(TIMER_FUSED_FWD, st);
+    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED>), dim3(p.B), dim3(256), lds, st, p);
+    timing_end(TIMER_FUSED_FWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
 }
@@ -919,7 +964,11 @@ int ffn_rot_mode() {
 }
 
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {
-    return compute == CM_BF16 ? launch_fwd<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT>(p, st) : launch_fwd<CM_F32>(p, st);
+    if (p.mode != FUSED_MODE_FULL) {        // tiled mode: bf16 and split only (the exact-fp32 mode stays on the generic kernels for S > 48)
+        EGX_CHECK(compute == CM_BF16 || compute == CM_SPLIT, "tiled mode: compute must be bf16 or f32s");
+        return compute == CM_BF16 ? launch_fwd<CM_BF16, true>(p, st) : launch_fwd<CM_SPLIT, true>(p, st);
+    }
+    return compute == CM_BF16 ? launch_fwd<CM_BF16, false>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT, false>(p, st) : launch_fwd<CM_F32, false>(p, st);
 }
 
 }  // namespace egx

@@ -1067,7 +1067,10 @@ int debug_read_bstamps(unsigned long long* out, int n) {
 // One workgroup per clip. Six token-major LDS blocks (48 x 132 fp32 each) are rotated through the roles noted at
 // each phase; small per-head softmax statistics live behind them. Everything that another kernel needs
 // (operands of the weight-gradient GEMMs) is written to HBM exactly once.
-template <int CM>
+// TILED (48 < S <= 512, see FusedBwdParams): the workgroup is one 48-token tile and the kernel is cut at the attention backward
+// (tiled_attn_bwd): a launch runs [P11 - P12 of layer l_front on the dQ | dK | dV rows that kernel left] + [P1 - P7 of layer
+// l_back, leaving d(attention output) and the residual gradient in HBM], or ends with the token-preparation backward.
+template <int CM, bool TILED>
 __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     constexpr int NT = 3;
     constexpr int SP = NT * 16;
@@ -1083,15 +1086,23 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int clip = blockIdx.x;
-    const int S = p.S;
+    const int clip = blockIdx.x;            // TILED: the tile (index of every 48-row grid)
+    int S, c_real, t0;
+    size_t tok0;                            // global index of the first token (row of the dense arrays, dropout row key)
+    if constexpr (TILED) {
+        c_real = clip / p.tpc;
+        t0 = (clip - c_real * p.tpc) * 48;
+        S = min(48, p.S_clip - t0);
+        tok0 = (size_t)c_real * p.S_clip + t0;
+    } else {
+        c_real = clip; t0 = 0; S = p.S; tok0 = (size_t)clip * S;
+    }
     if (p.zero_buf) {       // the caller's flat gradient buffer: every accumulation into it happens in later launches
         const size_t n4 = p.zero_n / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
         for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
     }
 
-    const size_t tok0 = (size_t)clip * S;
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
     // the phases (1 KB of scratch per lane). Re-deriving the lane indices behind an opaque asm at each phase start
@@ -1132,12 +1143,84 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
     };
     f32x4 pf_a[BPF], pf_b[BPF];       // res2 / res1 of the layer about to be processed (pf_a: `pre` for the token preparation)
-    blk_request(pf_a, p.saved_res + ((size_t)(2 * (p.n_layers - 1) + 1) * p.B + clip) * S * FD);
-    blk_request(pf_b, p.saved_res + ((size_t)(2 * (p.n_layers - 1)) * p.B + clip) * S * FD);
+    // dense (S, 128) block of saved residual sums: slot 2 l = res1, 2 l + 1 = res2 of layer l
+    auto res_ptr = [&](int slot) -> const float* {
+        return TILED ? p.saved_res + ((size_t)slot * p.Ntok + tok0) * FD : p.saved_res + ((size_t)slot * p.B + clip) * S * FD;
+    };
+    const int l_first = TILED ? p.l_back : p.n_layers - 1;      // the layer whose P1 - P7 this launch runs first (TILED: < 0 = none)
+    blk_request(pf_a, l_first >= 0 ? res_ptr(2 * l_first + 1) : p.saved_pre + tok0 * FD);
+    blk_request(pf_b, l_first >= 0 ? res_ptr(2 * l_first) : p.saved_pre + tok0 * FD);
     static_assert((6 * BLK) % 4 == 0, "the blocks are zeroed in 16-byte pieces");
     for (int i = tid; i < 6 * BLK / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
     __syncthreads();
+    if constexpr (TILED) {
+        if (p.l_front >= 0) {
+            // dQ | dK | dV rows of this tile (tiled_attn_bwd) -> B4 | B5 | Gs, the residual gradient of layer l_front -> B1; then
+            // P11 - P12 of that layer exactly as below
+            const FusedBwdLayer& w = p.layer[p.l_front];
+            float* pl = part + p.l_front * FUSED_P_LAYER;
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(w.dqkv_out + tok0 * (3 * FD));
+                const f32x4* rsrc = reinterpret_cast<const f32x4*>(p.dres + tok0 * FD);
+                for (int i = tid; i < S * 96; i += 256) {
+                    const int row = i / 96, c = (i - row * 96) * 4;
+                    float* dst = c < FD ? B4 + c : (c < 2 * FD ? B5 + (c - FD) : Gs + (c - 2 * FD));
+                    *reinterpret_cast<f32x4*>(dst + row * LDX) = src[i];
+                }
+                for (int i = tid; i < S * (FD / 4); i += 256) {
+                    const int row = i >> 5, c = (i & 31) << 2;
+                    *reinterpret_cast<f32x4*>(B1 + row * LDX + c) = rsrc[i];
+                }
+            }
+            __syncthreads();
+            PackW<CM, 2, 4> wi_pf;
+            pack_issue(wi_pf, w.in_proj_wtp, wave * 2, 12, 0);
+            if (tid < 128) {
+                pl[768 + tid] = colsum_lds(B4, 0, S, tid);
+                pl[768 + 256 + tid] = colsum_lds(Gs, 0, S, tid);
+            } else {
+                pl[768 + 128 + (tid - 128)] = colsum_lds(B5, 0, S, tid - 128);
+            }
+            EGX_PHASE();
+            {
+                f32x4 acc[2][NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+                PackW<CM, 2, 4> wi2, wi3;
+                pack_issue(wi2, w.in_proj_wtp, wave * 2, 12, 4);
+                gemm_packed<CM, 2, NT, 4>(acc, wi_pf, B4, r, q);
+                pack_issue(wi3, w.in_proj_wtp, wave * 2, 12, 8);
+                gemm_packed<CM, 2, NT, 4>(acc, wi2, B5, r, q);
+                gemm_packed<CM, 2, NT, 4>(acc, wi3, Gs, r, q);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        int tok = t * 16 + r;
+                        int c = (wave * 2 + i) * 16 + 4 * q;
+                        float4 rs = *reinterpret_cast<const float4*>(B1 + tok * LDX + c);
+                        float4 o = make_float4(acc[i][t][0] + rs.x, acc[i][t][1] + rs.y, acc[i][t][2] + rs.z, acc[i][t][3] + rs.w);
+                        if (tok >= S) o = make_float4(0, 0, 0, 0);
+                        *reinterpret_cast<float4*>(B2 + tok * LDX + c) = o;
+                    }
+            }
+            __syncthreads();
+            { float* t = Gs; Gs = B2; B2 = t; }
+        } else {
+            for (int i = tid; i < S * (FD / 4); i += 256) {
+                int row = i >> 5, c = (i & 31) << 2;
+                *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(p.d_tokens + (tok0 + row) * FD + c);
+            }
+        }
+        if (l_first >= 0) {
+            blk_store(pf_a, B1, nullptr);
+            blk_store(pf_b, B5, nullptr);
+        }
+    }
     // res2 -> B1 (LayerNorm2 backward; with the fused head also -> Gs, normalised in place below), res1 -> B5 (P3 / P5)
+    if constexpr (!TILED) {
     blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);
     blk_store(pf_b, B5, nullptr);
     if (p.head.n_out > 0) {
@@ -1191,8 +1274,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(p.d_tokens + ((size_t)clip * p.out_T + row) * FD + c);
         }
     }
+    }       // !TILED
 
-    for (int l = p.n_layers - 1; l >= 0; --l) {
+    for (int l = l_first; l >= 0; --l) {
         const FusedBwdLayer& w = p.layer[l];
         const uint64_t k_attn = dev_seed ? site_key(seed_dev, l, SITE_ATTN) : w.attn_key;
         const uint64_t k_res1 = dev_seed ? site_key(seed_dev, l, SITE_RES1) : w.res1_key;
@@ -1201,7 +1285,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
         BSTAMP(0);
         // P1: res2 -> B1, res1 -> B5: requested during the previous layer's P11 / P12 (the last layer's before the LDS zero fill)
-        if (l != p.n_layers - 1) {
+        if (!TILED && l != p.n_layers - 1) {
             blk_store(pf_a, B1, nullptr);
             blk_store(pf_b, B5, nullptr);
         }
@@ -1213,7 +1297,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(B1 + row * LDX + c0, dx);
                 store32(B3 + row * LDX + c0, dyx);
                 if (w.res_thresh) {
-                    uint32_t orow = (uint32_t)(clip * S + row);
+                    uint32_t orow = (uint32_t)(tok0 + row);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res2, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
@@ -1435,17 +1519,19 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(B1 + row * LDX + c0, dx);      // d_res1 (residual path into the layer input)
                 store32(B4 + row * LDX + c0, dyx);
                 if (w.res_thresh) {
-                    uint32_t orow = (uint32_t)(clip * S + row);
+                    uint32_t orow = (uint32_t)(tok0 + row);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(k_res1, orow, (uint32_t)(c0 + j), w.res_thresh, w.drop_inv);
                 }
                 store32(B2 + row * LDX + c0, dx);      // g1
             },
             [&] {       // behind the request for the LayerNorm weights: the Q | K | V rows (in flight until after P7)
-                int t_ = threadIdx.x;
-                asm volatile("" : "+v"(t_));        // keep the address arithmetic here (see EGX_PHASE)
+                if constexpr (!TILED) {
+                    int t_ = threadIdx.x;
+                    asm volatile("" : "+v"(t_));        // keep the address arithmetic here (see EGX_PHASE)
 #pragma unroll
-                for (int k = 0; k < QKV_PF; ++k) qv[k] = qsrc[t_ + 256 * k];
+                    for (int k = 0; k < QKV_PF; ++k) qv[k] = qsrc[t_ + 256 * k];
+                }
             });
         __syncthreads();
         store_block(w.g1_out + tok0 * FD, B2, S);
@@ -1477,6 +1563,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                         make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]);
         }
         BSTAMP(6);
+        if constexpr (TILED) {
+            // the attention backward of the whole clip is another launch (tiled_attn_bwd): d(attention output) and the residual
+            // gradient leave as dense rows; the next launch of this kernel picks the residual gradient up again (l_front)
+            __syncthreads();
+            store_block(p.datt + tok0 * FD, B3, S);
+            store_block(p.dres + tok0 * FD, B1, S);
+            return;
+        }
         // P8 / P9: Q -> B4, K -> B5, V -> Gs, loaded from what the forward saved (FusedFwdParams::qkv_out). Until round 3 the layer
         // input was recomputed here (LayerNorm + embeddings + dropout hash) and projected again: 13k + 6k of the kernel's 136k
         // cycles in bf16 mode, 22k + 17k of 300k in split mode.
@@ -1696,8 +1790,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         pack_issue(wi_pf, w.in_proj_wtp, wave * 2, 12, 0);
         // what the next stretch loads first, requested now (lands under P11 / P12): the next layer's residual sums, or `pre`
         // (no branch around the requests: after layer 0 the second one re-reads `pre` and is dropped)
-        blk_request(pf_a, l > 0 ? p.saved_res + ((size_t)(2 * (l - 1) + 1) * p.B + clip) * S * FD : p.saved_pre + tok0 * FD);
-        blk_request(pf_b, l > 0 ? p.saved_res + ((size_t)(2 * (l - 1)) * p.B + clip) * S * FD : p.saved_pre + tok0 * FD);
+        blk_request(pf_a, l > 0 ? res_ptr(2 * (l - 1) + 1) : p.saved_pre + tok0 * FD);
+        blk_request(pf_b, l > 0 ? res_ptr(2 * (l - 1)) : p.saved_pre + tok0 * FD);
         // P11: in_proj_b partials
         if (tid < 128) {
             pl[768 + tid] = colsum_lds(B4, 0, S, tid);
@@ -1745,7 +1839,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
                 load32(Gs + row * LDX + c0, dy);
                 if (p.pos_thresh) {
-                    uint32_t orow = (uint32_t)(clip * S + row);
+                    uint32_t orow = (uint32_t)(tok0 + row);
 #pragma unroll
                     for (int j = 0; j < 32; ++j) dy[j] *= drop_scale(pos_key, orow, (uint32_t)(c0 + j), p.pos_thresh, p.pos_inv);
                 }
@@ -1757,14 +1851,15 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 store32(B3 + row * LDX + c0, dyx);
 #pragma unroll
                 for (int si = 0; si < FUSED_MAX_SEG; ++si)
-                    if (si < p.nseg && row >= p.seg[si].off && row < p.seg[si].off + p.seg[si].T)
-                        store32(p.dseg_out[si] + ((size_t)clip * p.seg[si].T + (row - p.seg[si].off)) * FD + c0, dx);
+                    if (si < p.nseg && t0 + row >= p.seg[si].off && t0 + row < p.seg[si].off + p.seg[si].T)
+                        store32(p.dseg_out[si] + ((size_t)c_real * p.seg[si].T + (t0 + row - p.seg[si].off)) * FD + c0, dx);
             });
         __syncthreads();
         if (tid < 128) pg[tid] = colsum_lds(B3, 0, S, tid);
         else pg[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
         for (int si = 0; si < p.nseg; ++si) {
-            int r0 = p.seg[si].off, r1 = r0 + p.seg[si].T;
+            int r0 = p.seg[si].off - t0, r1 = r0 + p.seg[si].T;      // the segment's rows within this tile (empty ranges sum to zero)
+            r0 = max(r0, 0); r1 = min(r1, S);
             if (tid < 128) pg[256 + si * 256 + tid] = colsum_lds(Gs, r0, r1, tid);
             else pg[256 + si * 256 + 128 + (tid - 128)] = colsum_lds(B1, r0, r1, tid - 128);
         }
@@ -1782,17 +1877,17 @@ int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool determi
     return 0;
 }
 
-template <int CM>
+template <int CM, bool TILED>
 static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
     size_t lds = (size_t)(6 * 48 * LDX + FH * 3 * 48) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM>),
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, TILED>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_BWD, st);
-    hipLaunchKernelGGL((fused_bwd_kernel<CM>), dim3(p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED>), dim3(p.B), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -1800,7 +1895,11 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
 
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st) {
     EGX_CHECK(p.S <= 48, "fused backward: S=%d > 48", p.S);
-    return compute == CM_BF16 ? launch_bwd<CM_BF16>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT>(p, st) : launch_bwd<CM_F32>(p, st);
+    if (p.tiled) {
+        EGX_CHECK(compute == CM_BF16 || compute == CM_SPLIT, "tiled mode: compute must be bf16 or f32s");
+        return compute == CM_BF16 ? launch_bwd<CM_BF16, true>(p, st) : launch_bwd<CM_SPLIT, true>(p, st);
+    }
+    return compute == CM_BF16 ? launch_bwd<CM_BF16, false>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT, false>(p, st) : launch_bwd<CM_F32, false>(p, st);
 }
 
 }  // namespace egx

@@ -13,12 +13,12 @@ import torch
 
 from . import _lib
 from ._lib import (Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
-                   EGX_F32, EGX_BF16, EGX_F32_SPLIT, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE)
+                   EGX_F32, EGX_BF16, EGX_F32_SPLIT, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED)
 
 # "f32s": fp32 operands split exactly into three bf16 parts, six bf16 MFMAs per K-block (fp32-grade results, fused d = 128
 # kernels only; elsewhere it computes as "f32")
 COMPUTE = {"f32": EGX_F32, "fp32": EGX_F32, "float32": EGX_F32, "bf16": EGX_BF16, "bfloat16": EGX_BF16, "f32s": EGX_F32_SPLIT}
-IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED, "wide": EGX_IMPL_WIDE}
+IMPL = {"auto": EGX_IMPL_AUTO, "generic": EGX_IMPL_GENERIC, "fused": EGX_IMPL_FUSED, "wide": EGX_IMPL_WIDE, "tiled": EGX_IMPL_TILED}
 
 
 @dataclass
@@ -262,7 +262,7 @@ class EncoderFn(torch.autograd.Function):
                 # learned positional table (HOI `pe`): the fused per-clip backward emits no gradient for it; the wide
                 # bf16 path and the generic kernels do
                 probe = spec.config()
-                if lib.egx_encoder_impl(C.byref(probe), segs, B) == EGX_IMPL_FUSED:
+                if lib.egx_encoder_impl(C.byref(probe), segs, B) in (EGX_IMPL_FUSED, EGX_IMPL_TILED):
                     spec = dataclasses.replace(spec, impl="generic")
         # first-tokens-only output: in-kernel on the fused path; elsewhere the full block is sliced here (and the gradient
         # scattered back in backward)
@@ -302,7 +302,7 @@ class EncoderFn(torch.autograd.Function):
                 tokens = tokens[:, :py_slice].contiguous()
         ctx.py_slice, ctx.S = py_slice, S
         ctx.spec = spec
-        ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
+        ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_TILED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
         _last_impl[0] = ctx.impl
         ctx.fused_path = ctx.impl == EGX_IMPL_FUSED
         ctx.B = B

@@ -48,11 +48,11 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 11
+#define EGX_ABI_VERSION 12
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
-enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2, EGX_IMPL_WIDE = 3 };
+enum { EGX_IMPL_AUTO = 0, EGX_IMPL_GENERIC = 1, EGX_IMPL_FUSED = 2, EGX_IMPL_WIDE = 3, EGX_IMPL_TILED = 4 };
 
 /* One contiguous run of tokens of the packed sequence, produced from one frozen-backbone feature
  * tensor: tokens[b, off + t, :] = LN(feat[b, t, :] @ proj_w^T + proj_b) + add_vec + pos[t * pos_stride + :]
@@ -179,7 +179,9 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
 /* 1 when this configuration runs on the fused per-clip kernels (which leave d_tokens untouched in backward),
  * 0 for the shape-generic kernels (which consume d_tokens). */
 int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B);
-/* Which kernels this configuration runs on: EGX_IMPL_FUSED (per-clip kernels: d = 128, h = 4, S <= 48), EGX_IMPL_WIDE
+/* Which kernels this configuration runs on: EGX_IMPL_FUSED (per-clip kernels: d = 128, h = 4, S <= 48), EGX_IMPL_TILED (the same
+ * kernels over 48-token tiles with the attention of the whole clip between the launches: d = 128, h = 4, 48 < S <= 512, compute bf16
+ * or f32s - the reference's real TTM / ASD batches of 15 .. 150 frames per task, HHI/dataset/ttm/data_loader_2task.py:119,150-162), EGX_IMPL_WIDE
  * (compute = bf16 with d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128: all B*S tokens
  * through bf16-storage MFMA GEMMs and MFMA attention - BASELINE.json configs[3], configs[4]) or EGX_IMPL_GENERIC; -1 on an
  * invalid configuration. */

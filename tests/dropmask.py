@@ -9,8 +9,7 @@ Sites (nn.TransformerEncoderLayer + PositionalEncoding + the HOI feature dropout
 HHI/models/ttm/model_taskspecific.py:149-151,211-215, HOI/models/pnr/video_model_transfer_3task.py:249-252):
     FEAT  key layer = segment index; row = b * T_k + t (row of the segment's projection GEMM); col = feature
     POS   key layer = 0;             row = b * S + s (packed token);  col = feature
-    ATTN  key layer = l;             row = (b * H + h) * RS + query;  col = key        RS = 64 fused, 128 wide, S generic,
-                                                                                        512 tiled
+    ATTN  key layer = l;             row = (b * H + h) * RS + query;  col = key        RS = 64 fused, 128 wide, S generic / tiled
     RES1  key layer = l;             row = b * S + s;                 col = feature
     FFN   key layer = l;             row = b * 64 + s (fused) / b * S + s (others); col = hidden unit
     RES2  key layer = l;             row = b * S + s;                 col = feature
@@ -79,7 +78,7 @@ def keep_scale(key: int, rows: np.ndarray, cols: np.ndarray, p: float) -> torch.
     return torch.from_numpy(np.where(v >= np.uint64(thresh), inv_keep(p), 0.0))
 
 
-ATTN_ROW_STRIDE = {"fused": 64, "wide": 128, "tiled": 512}
+ATTN_ROW_STRIDE = {"fused": 64, "wide": 128}      # others (generic, tiled): S
 
 
 def encoder_masks(seed: int, impl: str, B: int, seg_T, d: int, H: int, d_ff: int, L: int, p_drop: float, p_pos: float = 0.0,

@@ -211,11 +211,19 @@ def _bucket_worker(rank, world, port, q):
     # parameter whose gradient lives outside any announced buffer (a task head computed by torch)
     flat = torch.zeros(48)
     ps = [torch.nn.Parameter(torch.zeros(16)) for _ in range(3)] + [torch.nn.Parameter(torch.zeros(5))]
-    for i in range(3):
-        ps[i].grad = flat[16 * i:16 * (i + 1)]
+    # precondition: a parameter that already holds a .grad would be accumulated into while the collective rewrites it
+    ps[0].grad = torch.zeros(16)
+    try:
+        with ddp.BucketedExchange(ps):
+            raise AssertionError("a stale .grad must be refused")
+    except RuntimeError as e:
+        assert "already hold a .grad" in str(e) and F_egx.bucket_hook is None
+    ps[0].grad = None
     order = []
     with ddp.BucketedExchange(ps) as ex:
         assert F_egx.bucket_hook is not None
+        for i in range(3):                                   # the "backward" creates the gradients as views of its flat buffer
+            ps[i].grad = flat[16 * i:16 * (i + 1)]
         for i in range(3):                                   # slice i becomes final, is announced, then the next one is "computed"
             flat[16 * i:16 * (i + 1)] = (i + 1) * (rank + 1) * torch.arange(16, dtype=torch.float32)
             F_egx.bucket_hook(flat, 16 * i, 16 * (i + 1))

@@ -11,17 +11,20 @@ pytestmark = pytest.mark.gpu
 CE_W = [0.266, 0.734]
 
 
-def test_long_validation_sequence_matches_oracle(egx_lib, cuda):
-    """batch_size = 1, T = 150: S = 450 tokens, far beyond the fused kernels' 48."""
-    from egot2_amd import hhi_ttm
+@pytest.mark.parametrize("compute,impl", [("f32", "generic"), ("f32s", "tiled")])
+def test_long_validation_sequence_matches_oracle(egx_lib, cuda, compute, impl):
+    """batch_size = 1, T = 150: S = 450 tokens, far beyond the per-clip kernels' 48: the shape-generic
+    kernels in exact fp32, and the tiled MFMA path (fp32-grade split arithmetic) held to the same fp32 tolerances."""
+    from egot2_amd import functional as F_egx, hhi_ttm
     m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=1))
     sd = seeded_state_dict(m, 21)
     m.load_state_dict(sd)
-    m = m.to(cuda).train()
+    m = m.to(cuda).set_compute(compute).train()
     m.pos_embed.dropout.p = 0.0
     feats = seeded_feats(22, [(1, 150, 256)] * 3)
     target = torch.tensor([1])
     logits = m.forward_features(*[f.to(cuda) for f in feats])
+    assert F_egx.last_encoder_impl() == impl
     torch.nn.functional.cross_entropy(logits, target.to(cuda), weight=torch.tensor(CE_W, device=cuda)).backward()
     sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
     ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats])

@@ -34,7 +34,9 @@ def _oracle_ttm(sd, n_heads, feats, target):
                                            (3, 1, 1, 1), (3, 1, 16, 4), (2, 3, 7, 3), (3, 257, 3, 1)])
 def test_ttm_translator_vs_oracle(egx_lib, cuda, impl, compute, tol_logit, tol_grad, n_tasks, B, T, L):
     if impl == "fused" and n_tasks * T > 48:
-        pytest.skip("fused kernels cover S <= 48")
+        if compute == "f32":
+            pytest.skip("S > 48 in exact-fp32 MFMA arithmetic runs the generic kernels")
+        impl = "tiled"          # the same kernels over 48-token tiles (tests/test_gpu_tiled.py covers the real batch shapes)
     if impl == "generic" and compute == "f32s":
         pytest.skip("f32s is f32 outside the fused kernels")
     from egot2_amd import hhi_ttm
