@@ -59,14 +59,16 @@ def parse_args(argv=None):
                     help="weak: --batch clips per GPU; strong: --batch clips in total, sharded over the ranks (SURVEY.md 8e)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi"],
                     help="BASELINE.json configuration (default c2 = configs[1], the metric)")
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="clips per GPU (0 = 256; with --frames > 16 on c1 - c3: 3840 // frames, i.e. the headline's 3840 frames per task - "
+                         "the reference's sampler packs B * T ~ 400, HHI/dataset/ttm/sampler.py:41, this is 9.6 such batches)")
     ap.add_argument("--frames", type=int, default=15)
     ap.add_argument("--layers", type=int, default=0, help="0 = the configuration's own depth")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "f32s"],
                     help="default: f32s for c1/c2 (fp32-grade split-bf16 arithmetic; f32 = exact fp32 MFMA), bf16 for c3..c5 (BASELINE.json)")
     ap.add_argument("--graph-collectives", action="store_true", help="N > 1 (or --force-dist): capture the gradient all-reduce(s) inside the step's hipGraph")
     ap.add_argument("--no-native-line", action="store_true", help="f32s runs: skip the reference timing of the exact fp32 MFMA path")
-    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide", "tiled"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
@@ -202,6 +204,8 @@ def run(args) -> int:
     # fp32 accumulation ("f32s": fp32-grade results, tests/test_gpu_translator.py::test_split_bf16_mode_is_fp32_grade);
     # `--dtype f32` is the exact v_mfma_f32_16x16x4_f32 path, reported beside it as `native_f32`
     run_dtype = args.dtype or ("f32s" if args.config in ("c1", "c2") else None)
+    if args.batch <= 0:
+        args.batch = 3840 // args.frames if (args.config in ("c1", "c2", "c3") and args.frames > 16) else 256
     # weak scaling: --batch clips on every GPU. strong scaling ("global B = 256 -> 32 clips / GPU at n = 8"): the
     # --batch clips are sharded over the ranks, the per-GPU work shrinks with N
     if args.scaling == "strong":
@@ -622,6 +626,15 @@ def measure_roofline(torch, lib, step, wl, dtype):
         if lib.egx_timing_read(which, C.byref(tot), C.byref(cnt)) == 0 and cnt.value:
             res[name] = tot.value / cnt.value * 1e-3
             tot_ms[name], counts[name] = tot.value, cnt.value
+    # tiled mode (S > 48): the tile kernels run L + 1 launches per step and the attention is its own kernels: times become
+    # per-STEP sums and the attention FLOPs move to the attention entries
+    from egot2_amd import functional as F_egx
+    tiled = F_egx.last_encoder_impl() == "tiled"
+    if tiled:
+        for k in list(res):
+            res[k] = tot_ms[k] * 1e-3 / reps
+        flops["fused_bwd_kernel"] -= L * 8.0 * B * S * S * d
+        flops["fused_fwd_kernel"] -= L * 4.0 * B * S * S * d
     # split mode: the FFN halves run as their own launches; the per-clip kernels then hold only the attention halves
     if "ffn_fwd_kernel" in res:
         flops["fused_fwd_kernel"] -= ffn
@@ -642,6 +655,9 @@ def measure_roofline(torch, lib, step, wl, dtype):
         if cnt:
             step_traffic = sum(v.get("traffic_bytes", 0.0) * v.get("launches", 0) for k, v in cnt["kernels"].items()
                                if k.startswith("egx::")) / max(cnt.get("steps_profiled", 1), 1)
+        if tiled:
+            extra["tiled"] = (f"S = {S} > 48: the per-clip kernels run over 48-token tiles, {L + 1} launches per step (times and FLOPs are "
+                              "per-step sums over them), attention in tiled_attn kernels (other_kernels: wide_attn_*)")
         return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, **extra, **cf, "traffic_unit": "bytes/launch",
                 "counters_source": cnt_src, "hbm_bytes_per_step": step_traffic,
