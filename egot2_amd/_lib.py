@@ -116,6 +116,8 @@ SIGNATURES = {
                                   C.POINTER(DecLayerGrads), _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_uint64, _fp]),
     "egx_relu_mask": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
     "egx_dropout": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
+    "egx_pool_pack": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                _fp, C.c_int, C.c_longlong, _fp]),
     "egx_weighted_ce": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "egx_linear_ce_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "egx_linear_ce_fwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -175,7 +175,35 @@ class TaskFusionMFTransformerLTA4Task(_LTATranslator):
                                [self.proj_pnr, self.proj_oscc, None, self.proj_lta], pools=[frames_per_clip, frames_per_clip, 1, 1])
 
     def encode_clips_pnr(self, model, x):
-        return torch.stack([model([x[:, i, ...]], middle=True).mean(dim=1) for i in range(x.shape[1])], dim=1)
+        head = getattr(self, "_sink_heads", {}).get(id(model))
+        if head is None:
+            return torch.stack([model([x[:, i, ...]], middle=True).mean(dim=1) for i in range(x.shape[1])], dim=1)
+        # producer side of row F4 (enable_feature_sink): the backbone's head pools, permutes, averages the frames and casts in ONE
+        # pass over its res5 map, straight into token row i of the packed (B, n, 8192) stream the projection GEMM reads in place
+        B, n = x.shape[0], x.shape[1]
+        stream = head._stream_name
+        self._sink.alloc(stream, B, n, self.proj_pnr.in_features)
+        try:
+            for i in range(n):
+                head.token = i
+                model([x[:, i, ...]], middle=True)
+        finally:
+            head.token = None
+        return self._sink.get(stream)
+
+    def enable_feature_sink(self, dtype=torch.bfloat16, head_attrs=("Keyframe_localisation_head", "State_detection_head", "head")):
+        """Route the PNR / OSCC backbones' `middle=True` features through a FeatureSink (egot2_amd/feature_sink.py): their pooling
+        heads are swapped for PooledFeatureHead (same parameters) and `forward()` hands packed `dtype` rows to the translator.
+        bf16 (default) is what the wide path's projection GEMM consumes in place; the action / LTA streams are unchanged."""
+        from .feature_sink import FeatureSink, attach_sink
+        self._sink = FeatureSink(self.pe.device, dtype)
+        self._sink_heads = {}
+        for stream, model in (("pnr", self.pnr_model), ("oscc", self.oscc_model)):
+            attr = next((a for a in head_attrs if hasattr(model, a)), None)
+            if attr is None:
+                raise ValueError(f"enable_feature_sink: the {stream} backbone has none of the head modules {head_attrs}")
+            self._sink_heads[id(model)] = attach_sink(model, attr, self._sink, stream)
+        return self
 
     def forward(self, x_lta, x_pnr):
         # as the reference (:354-363): no no_grad() around the backbone calls; their parameters are frozen

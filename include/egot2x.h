@@ -393,6 +393,16 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
                     float* d_fc_b, void* zero_buf, size_t zero_bytes, int training, uint64_t seed, void* stream);
 /* dy[i] = y[i] > 0 ? dy[i] : 0 in place: backward of the ReLU fused into egx_linear_fwd(relu = 1). */
 int egx_relu_mask(float* dy, const float* y, size_t n, void* stream);
+/* Producer side of the feature hand-off: the `middle=True` head of the frozen PNR / OSCC backbones,
+ * ResNetKeyframeLocalizationHead.forward (HOI/models/pnr/head_helper.py:353-373) = AvgPool3d((kt, kh, kw), stride 1) of the res5
+ * map fmap (N, C, T, H, W) [fp32, or bf16 with fmap_bf16], permute to (N, T', H', W', C), reshape to rows of H' W' C columns
+ * (8192 = 2 * 2 * 2048) - optionally followed by the per-clip temporal mean of encode_clips_pnr
+ * (HOI/models/lta/lta_models_lta_transfer.py:335-345; frames_mean != 0, or kt == T) - written as packed fp32 / bf16 rows:
+ * out[n * out_map_stride + t' * (H' W' C) + (h' W' + w') * C + c]. With out_map_stride = n_clips * H' W' C and `out` offset by
+ * i * H' W' C, call i fills token i of every sample of a (B, n_clips, 8192) translator input in place. kt must be 1 or T. */
+int egx_pool_pack(const void* fmap, int fmap_bf16, int N, int C, int T, int H, int W, int kt, int kh, int kw, int frames_mean,
+                  void* out, int out_bf16, long long out_map_stride, void* stream);
+
 /* x[r, c] *= keep(seed, site, r, c) / (1 - p) in place (inverted dropout); calling it on the gradient with the same
  * (seed, site) is its backward. */
 int egx_dropout(float* x, int rows, int cols, float p_drop, uint64_t seed, uint32_t site, void* stream);

@@ -509,3 +509,30 @@ def test_lossAV_mirror_has_the_reference_interface():
     assert hhi_asd.lossAV().FC.in_features == 256
     with pytest.raises(Exception):          # the HIP path fails loudly on CPU tensors instead of falling back
         m(torch.randn(4, 1, 128), torch.zeros(4, dtype=torch.int64))
+
+
+def test_feature_cache_and_sink_host_logic(tmp_path):
+    """Row F4 producer side, host logic only (no kernels): the on-disk Stage-II cache round-trips packed bf16 / fp32 streams
+    bit-exactly and atomically replaces files; the sink validates block shapes; the drop-in PNR / OSCC head has the reference
+    head's parameter names (HOI/models/pnr/head_helper.py:338: `projection = nn.Linear(8192, num_classes)`)."""
+    from egot2_amd import _lib
+    from egot2_amd.feature_sink import FeatureCache, FeatureSink, PooledFeatureHead
+    cache = FeatureCache(str(tmp_path / "c"))
+    feats = {"pnr": torch.randn(1, 4, 64).bfloat16(), "action": torch.randn(1, 4, 16)}
+    assert not cache.has("uid123:0-8")
+    cache.save("uid123:0-8", feats)
+    cache.save("uid123:0-8", feats)                 # overwrite is atomic (os.replace)
+    got = cache.load("uid123:0-8")
+    assert set(got) == set(feats) and all(torch.equal(got[k], feats[k]) and got[k].dtype == feats[k].dtype for k in feats)
+    sink = FeatureSink("cpu", torch.float32)
+    out = cache.load_batch(["uid123:0-8", "uid123:0-8"], sink)
+    assert tuple(out["pnr"].shape) == (2, 4, 64) and out["pnr"].dtype == torch.bfloat16 and torch.equal(out["pnr"][1], feats["pnr"][0])
+    sink.alloc("x", 2, 6, 8)
+    sink.put("x", torch.ones(2, 3, 8), t0=3)
+    assert sink.get("x")[:, 3:].eq(1).all()
+    with pytest.raises(_lib.EgxError):
+        sink.put("x", torch.ones(2, 4, 8), t0=3)    # runs past the stream
+    with pytest.raises(_lib.EgxError):
+        sink.put_pooled_map("x", torch.zeros(2, 2, 1, 2, 2), (1, 1, 1))     # CPU tensor: no fallback
+    head = PooledFeatureHead([2048], 17, [[1, 7, 7]], act_func="softmax_1")
+    assert set(head.state_dict()) == {"projection.weight", "projection.bias"} and tuple(head.projection.weight.shape) == (17, 8192)
