@@ -84,6 +84,9 @@ def parse_args(argv=None):
     ap.add_argument("--encoder-only", action="store_true", help="c5*: time the task-translation encoder alone (loss = sum of the memory), without the sequence decoder + vocabulary CE")
     ap.add_argument("--deterministic", action="store_true", help="fixed-order reductions in the backward (bit-identical gradients run to run)")
     ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"], help="c4: dtype of the backbone features handed to the translator (row F4)")
+    ap.add_argument("--feat-source", default="tensor", choices=["tensor", "sink"],
+                    help="c4: 'sink' = the PNR / OSCC token rows are produced by egx_pool_pack into a FeatureSink (row F4 producer side) "
+                         "and read by the translator as packed bf16 in place; the producer kernel is timed separately (`producer`)")
     ap.add_argument("--feat-frames", type=int, default=1, help="c4: per-frame PNR / OSCC features, this many frames per clip, temporal mean fused into the hand-off")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
@@ -216,7 +219,7 @@ def run(args) -> int:
         local_batch = args.batch
     wl = synth.make_workload(args.config, dev, batch=local_batch, frames=args.frames, layers=args.layers or None,
                              dtype=run_dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
-                             feat_dtype=args.feat_dtype, feat_frames=args.feat_frames)
+                             feat_dtype=args.feat_dtype, feat_frames=args.feat_frames, feat_source=args.feat_source)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
     if args.deterministic:
@@ -504,6 +507,8 @@ def run(args) -> int:
     if rank == 0 and not args.no_roofline:
         model.egx_defer_small = False
         out["roofline"] = measure_roofline(torch, lib, fwd_bwd, wl, dtype)
+        if wl.get("producer"):
+            out["producer"] = wl["producer"]
     if rank == 0 and not args.no_cpu_baseline and world == 1 and wl["name"] in ("c1", "c2"):
         from oracle.stock_module import time_cpu_baseline
         out["cpu_baseline"] = time_cpu_baseline(B=B, T=args.frames, n_tasks=len(wl["feats"]), dim=128, n_heads=4,

@@ -57,7 +57,7 @@ def _randn(gen, shape, device):
 
 def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, layers: int | None = None,
                   dtype: str | None = None, impl: str = "auto", dropout: float | None = None, seed: int = 1234,
-                  encoder_only: bool = False, feat_dtype: str = "f32", feat_frames: int = 1) -> Dict:
+                  encoder_only: bool = False, feat_dtype: str = "f32", feat_frames: int = 1, feat_source: str = "tensor") -> Dict:
     from . import functional as F_egx
     from .train import CrossEntropyLoss
     name = name.lower()
@@ -115,6 +115,38 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
                  _randn(gen, (B, n, 768), device), _randn(gen, (B, n, 2048), device)]
         if feat_dtype == "bf16":
             feats = [feats[0].bfloat16(), feats[1].bfloat16(), feats[2], feats[3].bfloat16()]
+        producer = None
+        if feat_source == "sink":
+            # producer side of row F4: the PNR / OSCC token rows come out of egx_pool_pack (the backbones' pooling head fused
+            # with the per-clip temporal mean and the bf16 cast) into a FeatureSink; the translator reads the packed bf16
+            # streams in place. The maps of ONE token position stand in for all n (a backbone would produce n different ones).
+            import time
+            from .feature_sink import FeatureSink
+            assert fr == 1, "--feat-source sink pools the frames inside the producer kernel"
+            F_frames = 4
+            sink = FeatureSink(device, torch.bfloat16)
+            fmaps = [torch.randn(B, 2048, F_frames, 8, 8, device=device) for _ in range(2)]
+            for k, nm in enumerate(("pnr", "oscc")):
+                sink.alloc(nm, B, n, 8192)
+
+            def produce():
+                for k, nm in enumerate(("pnr", "oscc")):
+                    for i in range(n):
+                        sink.put_pooled_map(nm, fmaps[k], (1, 7, 7), token=i, frames_mean=True)
+            produce()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            produce()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            nbytes = 2.0 * n * (fmaps[0].numel() * 4 + B * 8192 * 2)
+            producer = {"kernel": "egx::pool_pack_kernel", "launches": 2 * n, "maps_per_launch": B,
+                        "map_shape": [2048, F_frames, 8, 8], "us_per_launch": dt / (2 * n) * 1e6,
+                        "algorithmic_bytes": nbytes, "achieved_GBps": nbytes / dt / 1e9,
+                        "note": "AvgPool3d(1,7,7) + permute + mean over frames + bf16 cast of one res5 map batch per launch, into token "
+                                "row i of the packed (B, n, 8192) stream; run before the timed region (frozen-backbone side)"}
+            feats = [sink.get("pnr"), sink.get("oscc"), feats[2], feats[3].bfloat16()]
+            feat_dtype = "bf16 (FeatureSink)"
         tv = torch.randint(0, 115, (B * 20,), generator=gen).to(device)
         tn = torch.randint(0, 478, (B * 20,), generator=gen).to(device)
 
@@ -167,4 +199,5 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
     params = [q for q in model.parameters() if q.requires_grad] + list(getattr(model, "extra_params", []))
     return {"name": name, "model": model, "feats": feats, "loss_fn": loss_fn, "params": params, "flops": fl,
             "describe": desc, "B": B, "S": S, "d": d, "segs": segs, "L": L, "compute": model.egx_compute,
-            "batch_arg": batch, "frames": frames, "layers_arg": layers or 0, "encoder_only": bool(encoder_only)}
+            "batch_arg": batch, "frames": frames, "layers_arg": layers or 0, "encoder_only": bool(encoder_only),
+            "producer": locals().get("producer")}
