@@ -126,7 +126,6 @@ static bool packed_feats(const egx_segment* segs, int nseg) {
 static bool fused_ok(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     if (pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1) return false;
     if (packed_feats(segs, pl.nseg)) return false;
-    if (cfg->p_feat > 0.f) return false;
     int d_in[EGX_MAX_SEGMENTS], T[EGX_MAX_SEGMENTS];
     bool hp[EGX_MAX_SEGMENTS];
     for (int i = 0; i < pl.nseg; ++i) { d_in[i] = segs[i].d_in; T[i] = segs[i].T; hp[i] = segs[i].proj_w != nullptr; }
@@ -228,7 +227,7 @@ static bool use_tiled(const egx_config* cfg, const egx_segment* segs, const Plan
 struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
-    size_t partials, slabs, slab_bytes, dhid, bytes;
+    size_t partials, slabs, slab_bytes, dhid, bytes, dx0;
     size_t datt, dres, delta, dtok;         // tiled mode only
     size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
     int P;
@@ -256,6 +255,7 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     s.ffn_slab[0] = s.slabs;
     for (int l = 1; l < pl.L && l < FUSED_MAX_LAYERS; ++l) s.ffn_slab[l] = take(cur, ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr));
     s.dhid = take(cur, fused_hid_total(cfg, pl));
+    s.dx0 = take(cur, nd);         // d(token-prep output) behind its dropout mask (learned positional table gradient)
     if (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) {       // tiled mode: d(attention output), the residual gradient, delta, d(tokens) of a translator call
         s.datt = take(cur, nd); s.dres = take(cur, nd);
         s.delta = take(cur, (size_t)pl.B * pl.H * pl.S * 4);
@@ -275,7 +275,7 @@ static bool use_fused(const egx_config* cfg, const egx_segment* segs, const Plan
     *err = false;
     bool ok = fused_ok(cfg, segs, pl);
     if (cfg->impl == EGX_IMPL_FUSED) {
-        if (!ok) { set_error("fused implementation does not support this configuration (needs d=128, h=4, S<=48, d_ff%%128==0, projected segments, <=4 layers)"); *err = true; }
+        if (!ok) { set_error("fused implementation does not support this configuration (needs d=128, h=4 or 8, S<=48, d_ff%%128==0, projected segments, <=%d layers)", FUSED_MAX_LAYERS); *err = true; }
         return ok;
     }
     return cfg->impl == EGX_IMPL_AUTO && ok;   // auto: fused per-clip kernels whenever the shape allows
@@ -504,8 +504,11 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fs.feat = segs[i].feat; fs.proj_wp = add_pack(segs[i].proj_w, PL.proj[i], d, segs[i].d_in, segs[i].d_in, 0); fs.proj_b = segs[i].proj_b;
             fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos;
             fs.T = segs[i].T; fs.d_in = segs[i].d_in; fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride;
-            fs.row0 = 0; fs.Tfull = segs[i].T;
+            fs.row0 = 0; fs.Tfull = segs[i].T; fs.seg_id = i;
+            Drop df = make_drop(training, cfg->p_feat, seed, (uint32_t)i, SITE_FEAT);
+            fp.feat_key[i] = df.key; fp.feat_thresh = df.thresh; fp.feat_inv = df.inv_keep;
         }
+        fp.n_heads = pl.H;
         for (int l = 0; l < pl.L; ++l) {
             FusedLayer& fl = fp.layer[l];
             const egx_layer& w = layers[l];
@@ -687,9 +690,15 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             for (int i = 0; i < pl.nseg; ++i) {
                 FusedSeg& fs = bp.seg[i];
                 fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos; fs.T = segs[i].T; fs.d_in = segs[i].d_in;
-                fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride; fs.row0 = 0; fs.Tfull = segs[i].T;
+                fs.off = pl.seg_off[i]; fs.pos_stride = segs[i].pos_stride; fs.row0 = 0; fs.Tfull = segs[i].T; fs.seg_id = i;
                 bp.dseg_out[i] = fptr(scratch, SC.dseg[i]);
+                Drop df = make_drop(training, cfg->p_feat, seed, (uint32_t)i, SITE_FEAT);
+                bp.feat_key[i] = df.key; bp.feat_thresh = df.thresh; bp.feat_inv = df.inv_keep;
             }
+            bp.n_heads = pl.H;
+            bool want_pos = false;
+            for (int i = 0; i < pl.nseg && seg_grads; ++i) want_pos = want_pos || seg_grads[i].pos;
+            bp.dx0_out = want_pos ? fptr(scratch, SC.dx0) : nullptr;
             for (int l = 0; l < pl.L; ++l) {
                 FusedBwdLayer& fl = bp.layer[l];
                 const egx_layer& w = layers[l];
@@ -784,7 +793,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             add_dst(d_ln_w, og, 128); add_dst(d_ln_b, og + 128, 128);
             for (int i = 0; i < pl.nseg; ++i) {
                 if (!seg_grads) break;
-                EGX_CHECK(!seg_grads[i].pos && !seg_grads[i].feat, "fused backward: positional / feature gradients are not supported (use impl=generic)");
+                EGX_CHECK(!seg_grads[i].feat, "fused backward: feature gradients are not supported (use impl=generic)");
                 add_dst(seg_grads[i].add_vec, og + 256 + i * 256, 128);
                 add_dst(seg_grads[i].proj_b, og + 256 + i * 256 + 128, 128);
             }
@@ -794,6 +803,10 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(head_grads->b, oh + 256, head->n_out);
                 add_dst(head_grads->W, oh + 256 + FUSED_HEAD_MAX_OUT, head->n_out * 128);
             }
+            // learned positional table (the HOI translators' `pe`): sum d(token-prep output) over the clips, per segment
+            if (bp.dx0_out && stage != 2)
+                for (int i = 0; i < pl.nseg; ++i)
+                    if (seg_grads[i].pos && pos_grad_accum(bp.dx0_out, B, S, pl.seg_off[i], segs[i].T, d, seg_grads[i].pos, segs[i].pos_stride, 0, 0, 1.f, st)) return 1;
             // the partial-row reduction rides in the slab-reduction launch of the first FFN weight gradient
             bool rp_pending = stage != 2;
             void* slab = (char*)scratch + SC.slabs;

@@ -5,7 +5,7 @@
 namespace egx {
 
 constexpr int FUSED_MAX_SEG = 4;
-constexpr int FUSED_MAX_LAYERS = 4;
+constexpr int FUSED_MAX_LAYERS = 6;      // the shipped PNR / OSCC recipe stacks 6 (HOI/configs/pnr/ts_pnr.yaml:28-34)
 
 struct FusedSeg {
     const float* feat;      // (B, T, d_in)
@@ -15,6 +15,7 @@ struct FusedSeg {
     const float* pos;       // rows of 128 with stride pos_stride, or null
     int T, d_in, off, pos_stride;
     int row0, Tfull;        // tiled mode (S > 48): this descriptor covers frames [row0, row0 + T) of a segment of Tfull frames (else 0, T)
+    int seg_id, pad_;       // index of the segment in the caller's list (key of its feature dropout)
 };
 
 struct FusedLayer {
@@ -65,6 +66,10 @@ struct FusedFwdParams {
     // ---- tiled mode (d = 128 with 48 < S <= 512, fused_tiled.hip drives it): a workgroup is one 48-token TILE of a clip ("virtual
     // clip" v = clip * tpc + j holds tokens [48 j, 48 j + 48) of the clip); B = number of tiles; the dense (N, .) arrays are
     // addressed by the global token index, the 48-row grids by the tile. Attention runs between the launches (tiled_attn.hip).
+    // feature dropout `self.dp(proj_k(feat_k))` (HOI/models/pnr/video_model_transfer_3task.py:249-252): on the projection output,
+    // before the shared LayerNorm; keyed like the generic kernels (layer = segment index, row = b * T_k + t)
+    uint64_t feat_key[FUSED_MAX_SEG]; uint32_t feat_thresh; float feat_inv;
+    int n_heads;            // 4 (heads of 32) or 8 (heads of 16)
     int tpc, S_clip;        // tiles per clip, tokens per clip (full mode: 1, S)
     size_t Ntok;            // real tokens B_clips * S_clip: the layer stride of the dense saved arrays
     int mode, l0;           // FUSED_MODE_*; POST: the layer whose attention output `attn_in` holds
@@ -78,7 +83,7 @@ struct PackDesc {
     int R, K, ld, transpose, first_block;
     float scale;        // the packed copy holds scale * W (0 = 1): the FFN dropout keep-scale 1 / (1 - p) rides on W1 and W2^T
 };
-constexpr int PACK_MAX = 40;
+constexpr int PACK_MAX = 56;          // 4 projections + 8 per layer (both orientations) x 6 layers
 struct PackParams {
     PackDesc d[PACK_MAX];
     int n, mode;                // CM_F32 / CM_BF16 / CM_SPLIT (fused_dev.h): element format of the packed fragments
@@ -170,6 +175,10 @@ struct FusedBwdParams {
     const uint64_t* seed_ptr;
     // ---- tiled mode (see FusedFwdParams): one launch runs [the in-projection input gradient of layer l_front] + [LayerNorm2 ..
     // out-projection input gradient of layer l_back] or, with l_back < 0, the token-preparation backward
+    uint64_t feat_key[FUSED_MAX_SEG]; uint32_t feat_thresh; float feat_inv;    // feature dropout (see FusedFwdParams)
+    int n_heads;
+    float* dx0_out;                 // optional (Ntok, 128): gradient w.r.t. the token-preparation output BEHIND its dropout mask = the
+                                    // per-token gradient of a learned positional table (summed over the clips by pos_grad_accum)
     int tpc, S_clip; size_t Ntok;
     int tiled, l_front, l_back;     // l_front < 0: the launch starts from d_tokens; l_back < 0: it ends with the token preparation
     float* datt;                    // (Ntok, 128) gradient w.r.t. the attention output of layer l_back (written) 
@@ -196,7 +205,7 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullpt
 int seed_advance(uint64_t* seed, hipStream_t st);
 
 struct PartialDst { float* dst; int off, len; };
-constexpr int PARTIAL_MAX_DST = 48;
+constexpr int PARTIAL_MAX_DST = 64;
 struct ReducePartialsParams {
     PartialDst d[PARTIAL_MAX_DST];
     int n, B, P;
@@ -231,7 +240,7 @@ constexpr int TILED_MAX_S = 512;
 int tiled_attn_fwd(const TiledAttnParams& p, int compute, hipStream_t st);
 int tiled_attn_bwd(const TiledAttnParams& p, int compute, hipStream_t st);
 
-bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);
+bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);      // n_heads 4 or 8
 size_t fused_lds_bytes(int NT);
 int debug_read_stamps(unsigned long long* out, int n);
 int debug_read_bstamps(unsigned long long* out, int n);

@@ -101,8 +101,10 @@ int debug_read_stamps(unsigned long long* out, int n) {
 // FUSED_MODE_PRE = token preparation + Q | K | V of layer 0; FUSED_MODE_POST = out-projection .. LayerNorm2 of layer l0 on the
 // attention output tiled_attn_fwd left in `attn_in`, then Q | K | V of layer l0 + 1 (or the output tokens). The full-clip
 // instantiation (TILED = false) compiles to the code it was before the tiled mode existed.
-template <int CM, int NT, bool TILED>
+template <int CM, int NT, bool TILED, int DH>
 __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
+    constexpr int HPW = FDH / DH;               // heads per wave: 1 (4 heads of 32) or 2 (8 heads of 16)
+    constexpr int NHEAD = FH * HPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SP = NT * 16;                 // padded token count
     float* Xs = lds;                            // [SP][LDX] layer input (later: FFN partial 0)
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             for (int i = 0; i < p.nseg; ++i) {
                 FusedSeg o = p.seg[i];
                 const int lo = max(o.off, t0), hi = min(o.off + o.T, t0 + 48);
-                if (hi > lo) { o.Tfull = o.T; o.row0 = lo - o.off; o.T = hi - lo; o.off = lo - t0; segtab[n++] = o; }
+                if (hi > lo) { o.Tfull = o.T; o.row0 = lo - o.off; o.T = hi - lo; o.off = lo - t0; o.seg_id = i; segtab[n++] = o; }
             }
             *nseg_slot = n;
         }
@@ -268,10 +270,19 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 const int trow = s.t0 + r;
                 if (trow < sg.T) {
                     const int f0 = wave * 32 + 4 * q;
-                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0) =
-                        make_float4(acc[0][0] + bb0.x, acc[0][1] + bb0.y, acc[0][2] + bb0.z, acc[0][3] + bb0.w);
-                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0 + 16) =
-                        make_float4(acc[1][0] + bb1.x, acc[1][1] + bb1.y, acc[1][2] + bb1.z, acc[1][3] + bb1.w);
+                    float4 o0 = make_float4(acc[0][0] + bb0.x, acc[0][1] + bb0.y, acc[0][2] + bb0.z, acc[0][3] + bb0.w);
+                    float4 o1 = make_float4(acc[1][0] + bb1.x, acc[1][1] + bb1.y, acc[1][2] + bb1.z, acc[1][3] + bb1.w);
+                    if (p.feat_thresh) {        // feature dropout on the projection output (wave-uniform branch, no memory operation inside)
+                        const uint64_t fk = dev_seed ? site_key(seed_dev, (uint32_t)sg.seg_id, SITE_FEAT) : p.feat_key[sg.seg_id];
+                        const uint32_t frow = (uint32_t)((size_t)c_real * (TILED ? sg.Tfull : sg.T) + (TILED ? sg.row0 : 0) + trow);
+                        float m0[4], m1[4];
+                        drop_scale4(fk, frow, (uint32_t)f0, p.feat_thresh, p.feat_inv, m0);
+                        drop_scale4(fk, frow, (uint32_t)(f0 + 16), p.feat_thresh, p.feat_inv, m1);
+                        o0 = make_float4(o0.x * m0[0], o0.y * m0[1], o0.z * m0[2], o0.w * m0[3]);
+                        o1 = make_float4(o1.x * m1[0], o1.y * m1[1], o1.z * m1[2], o1.w * m1[3]);
+                    }
+                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0) = o0;
+                    *reinterpret_cast<float4*>(Xs + (sg.off + trow) * LDX + f0 + 16) = o1;
                 }
             }
         };
@@ -445,15 +456,17 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         EGX_PHASE();
         // ---- attention: wave = head. S^T = K Q^T (key rows, query columns), softmax over rows, O^T = V^T P^T
         if constexpr (!TILED) {
-            const int h = wave;
-            const float scale = 0.17677669529663687f;   // 1/sqrt(32)
+#pragma unroll
+          for (int hl = 0; hl < HPW; ++hl) {
+            const int h = wave * HPW + hl, hc = h * DH;
+            const float scale = DH == 32 ? 0.17677669529663687f : 0.25f;   // 1/sqrt(d_h)
             f32x4 sc[NT][NT];                            // [key tile][query tile]
             Frag<CM> kq[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) kq[t] = load_frag<CM>(Qs + (t * 16 + r) * LDX + h * FDH, q);
+            for (int t = 0; t < NT; ++t) kq[t] = load_head_frag<CM, DH>(Qs + (t * 16 + r) * LDX + hc, q);
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
-                Frag<CM> a = load_frag<CM>(Ks + (kt * 16 + r) * LDX + h * FDH, q);
+                Frag<CM> a = load_head_frag<CM, DH>(Ks + (kt * 16 + r) * LDX + hc, q);
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     sc[kt][qt] = f32x4{0, 0, 0, 0};
@@ -495,39 +508,41 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         float pv = sc[kt][qt][e] * inv;
                         if (w.attn_thresh) {
                             int key = kt * 16 + 4 * q + e;
-                            pv *= drop_scale(k_attn, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
+                            pv *= drop_scale(k_attn, (uint32_t)((clip * NHEAD + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv);
                         }
                         sc[kt][qt][e] = pv;
                     }
             }
             // O^T[c][query] = sum_key V^T[c][key] P^T[key][query]; keys in K-blocks of 32 = key-tile pairs
-            f32x4 oc[2][NT];
+            constexpr int NCT = DH / 16;
+            f32x4 oc[NCT][NT];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) oc[ct][qt] = f32x4{0, 0, 0, 0};
 #pragma unroll
             for (int kb = 0; kb < (NT + 1) / 2; ++kb) {
-                Frag<CM> a[2];
+                Frag<CM> a[NCT];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) a[ct] = load_frag<CM>(Vt + (h * FDH + ct * 16 + r) * LDV + kb * 32, q);
+                for (int ct = 0; ct < NCT; ++ct) a[ct] = load_frag<CM>(Vt + (hc + ct * 16 + r) * LDV + kb * 32, q);
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     f32x4 z = f32x4{0, 0, 0, 0};
                     Frag<CM> b = chain_frag<CM>(sc[2 * kb][qt], (2 * kb + 1 < NT) ? sc[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) mma<CM>(oc[ct][qt], a[ct], b);
+                    for (int ct = 0; ct < NCT; ++ct) mma<CM>(oc[ct][qt], a[ct], b);
                 }
             }
             // write O token-major over this head's Q columns (only this wave reads/writes them)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     int tok = qt * 16 + r;
-                    *reinterpret_cast<float4*>(Qs + tok * LDX + h * FDH + ct * 16 + 4 * q) =
+                    *reinterpret_cast<float4*>(Qs + tok * LDX + hc + ct * 16 + 4 * q) =
                         make_float4(oc[ct][qt][0], oc[ct][qt][1], oc[ct][qt][2], oc[ct][qt][3]);
                 }
+          }
         }
         __syncthreads();
         }       // Q | K | V + attention
@@ -929,7 +944,7 @@ size_t fused_lds_bytes(int NT) {
 }
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {
-    if (d_model != FD || n_heads != FH) return false;
+    if (d_model != FD || (n_heads != FH && n_heads != 2 * FH)) return false;
     if (d_ff % 128 != 0 || d_ff < 128) return false;
     if (S < 1 || S > 48) return false;   // NT = 4 would need 170 KB of LDS
     for (int i = 0; i < nseg; ++i) {
@@ -940,18 +955,18 @@ bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const 
     return true;
 }
 
-template <int CM, bool TILED>
+template <int CM, bool TILED, int DH>
 static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     // NT = 2 (S <= 32) is not instantiated: shorter sequences run the 48-row kernel with masked padding.
     EGX_CHECK(p.S <= 48, "fused: S=%d unsupported", p.S);
     const size_t lds = fused_lds_bytes(3);
     static bool attr_set = false;
     if (!attr_set) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, TILED, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_FWD, st);
-    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED>), dim3(p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_FWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -966,9 +981,12 @@ int ffn_rot_mode() {
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {
     if (p.mode != FUSED_MODE_FULL) {        // tiled mode: bf16 and split only (the exact-fp32 mode stays on the generic kernels for S > 48)
         EGX_CHECK(compute == CM_BF16 || compute == CM_SPLIT, "tiled mode: compute must be bf16 or f32s");
-        return compute == CM_BF16 ? launch_fwd<CM_BF16, true>(p, st) : launch_fwd<CM_SPLIT, true>(p, st);
+        EGX_CHECK(p.n_heads == FH, "tiled mode: 4 heads of 32");
+        return compute == CM_BF16 ? launch_fwd<CM_BF16, true, 32>(p, st) : launch_fwd<CM_SPLIT, true, 32>(p, st);
     }
-    return compute == CM_BF16 ? launch_fwd<CM_BF16, false>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT, false>(p, st) : launch_fwd<CM_F32, false>(p, st);
+    if (p.n_heads == 2 * FH)        // 8 heads of 16 (the HOI PNR / OSCC and action-recognition translators)
+        return compute == CM_BF16 ? launch_fwd<CM_BF16, false, 16>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT, false, 16>(p, st) : launch_fwd<CM_F32, false, 16>(p, st);
+    return compute == CM_BF16 ? launch_fwd<CM_BF16, false, 32>(p, st) : compute == CM_SPLIT ? launch_fwd<CM_SPLIT, false, 32>(p, st) : launch_fwd<CM_F32, false, 32>(p, st);
 }
 
 }  // namespace egx

@@ -1070,8 +1070,9 @@ int debug_read_bstamps(unsigned long long* out, int n) {
 // TILED (48 < S <= 512, see FusedBwdParams): the workgroup is one 48-token tile and the kernel is cut at the attention backward
 // (tiled_attn_bwd): a launch runs [P11 - P12 of layer l_front on the dQ | dK | dV rows that kernel left] + [P1 - P7 of layer
 // l_back, leaving d(attention output) and the residual gradient in HBM], or ends with the token-preparation backward.
-template <int CM, bool TILED>
+template <int CM, bool TILED, int DH>
 __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
+    constexpr int HPW = FDH / DH, NHEAD = FH * HPW, NCT = DH / 16;      // heads per wave, heads, 16-channel tiles per head
     constexpr int NT = 3;
     constexpr int SP = NT * 16;
     constexpr int BLK = SP * LDX;
@@ -1590,11 +1591,13 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         EGX_PHASE();
         BSTAMP(8);
         EGX_PHASE();
-        // P10: attention forward recompute + backward, wave = head. Q = B4, K = B5, V = Gs, dO = B3.
-        {
-            const int h = wave;
-            const int hc = h * FDH;
-            const float scale = 0.17677669529663687f;
+        // P10: attention forward recompute + backward, wave = head (8 heads of 16: two heads per wave, one after the other).
+        // Q = B4, K = B5, V = Gs, dO = B3.
+#pragma unroll
+        for (int hl = 0; hl < HPW; ++hl) {
+            const int h = wave * HPW + hl;
+            const int hc = h * DH;
+            const float scale = DH == 32 ? 0.17677669529663687f : 0.25f;
             float* st_m = stat + (h * 3 + 0) * SP;
             float* st_i = stat + (h * 3 + 1) * SP;
             float* st_d = stat + (h * 3 + 2) * SP;
@@ -1603,10 +1606,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             Frag<CM> fq[NT], fk[NT], fv[NT], fdo[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                fq[t] = load_frag<CM>(B4 + (t * 16 + r) * LDX + hc, q);
-                fk[t] = load_frag<CM>(B5 + (t * 16 + r) * LDX + hc, q);
-                fv[t] = load_frag<CM>(Gs + (t * 16 + r) * LDX + hc, q);
-                fdo[t] = load_frag<CM>(B3 + (t * 16 + r) * LDX + hc, q);
+                fq[t] = load_head_frag<CM, DH>(B4 + (t * 16 + r) * LDX + hc, q);
+                fk[t] = load_head_frag<CM, DH>(B5 + (t * 16 + r) * LDX + hc, q);
+                fv[t] = load_head_frag<CM, DH>(Gs + (t * 16 + r) * LDX + hc, q);
+                fdo[t] = load_head_frag<CM, DH>(B3 + (t * 16 + r) * LDX + hc, q);
             }
             auto ldq = [&](int t) -> const Frag<CM>& { return fq[t]; };
             auto ldk = [&](int t) -> const Frag<CM>& { return fk[t]; };
@@ -1626,7 +1629,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
             }
             auto keep = [&](int query, int key) -> float {   // attention-dropout keep-scale (regenerated, never stored)
-                return w.attn_thresh ? drop_scale(k_attn, (uint32_t)((clip * FH + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv) : 1.f;
+                return w.attn_thresh ? drop_scale(k_attn, (uint32_t)((clip * NHEAD + h) * 64 + query), (uint32_t)key, w.attn_thresh, w.drop_inv) : 1.f;
             };
 #pragma unroll
             for (int qt = 0; qt < NT; ++qt) {
@@ -1677,16 +1680,16 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     }
             }
             // O^T = V^T (P^T .* mask) -> attn_o (HBM);  dQ^T = K^T dS^T
-            f32x4 oq[2][NT], dqa[2][NT];
+            f32x4 oq[NCT][NT], dqa[NCT][NT];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) { oq[ct][qt] = f32x4{0, 0, 0, 0}; dqa[ct][qt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag<CM> av[2], ak[2];
+                Frag<CM> av[NCT], ak[NCT];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     av[ct] = gather_frag<CM>(Gs, hc + ct * 16 + r, kb * 32, q, SP - 1);
                     ak[ct] = gather_frag<CM>(B5, hc + ct * 16 + r, kb * 32, q, SP - 1);
                 }
@@ -1696,14 +1699,14 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     Frag<CM> bp = chain_frag<CM>(pt[2 * kb][qt], (2 * kb + 1 < NT) ? pt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
                     Frag<CM> bs = chain_frag<CM>(dpt[2 * kb][qt], (2 * kb + 1 < NT) ? dpt[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][qt] : z);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         mma<CM>(oq[ct][qt], av[ct], bp);
                         mma<CM>(dqa[ct][qt], ak[ct], bs);
                     }
                 }
             }
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int qt = 0; qt < NT; ++qt) {
                     int tok = qt * 16 + r;
@@ -1737,16 +1740,16 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 }
             }
             // dV^T = dO^T P ; dK^T = Q^T dS   (A gathered from token-major dO / Q; K dimension = query)
-            f32x4 dva[2][NT], dka[2][NT];
+            f32x4 dva[NCT][NT], dka[NCT][NT];
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt) { dva[ct][kt] = f32x4{0, 0, 0, 0}; dka[ct][kt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                Frag<CM> ad[2], aq[2];
+                Frag<CM> ad[NCT], aq[NCT];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
+                for (int ct = 0; ct < NCT; ++ct) {
                     ad[ct] = gather_frag<CM>(B3, hc + ct * 16 + r, kb * 32, q, SP - 1);
                     aq[ct] = gather_frag<CM>(B4, hc + ct * 16 + r, kb * 32, q, SP - 1);
                 }
@@ -1756,7 +1759,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     Frag<CM> bp = chain_frag<CM>(pn[2 * kb][kt], (2 * kb + 1 < NT) ? pn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
                     Frag<CM> bs = chain_frag<CM>(dsn[2 * kb][kt], (2 * kb + 1 < NT) ? dsn[(2 * kb + 1 < NT) ? 2 * kb + 1 : 0][kt] : z);
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
+                    for (int ct = 0; ct < NCT; ++ct) {
                         mma<CM>(dva[ct][kt], ad[ct], bp);
                         mma<CM>(dka[ct][kt], aq[ct], bs);
                     }
@@ -1764,7 +1767,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             }
             // all operands of this head are consumed: overwrite Q/K/V columns with dQ/dK/dV and emit dqkv
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     int tok = t * 16 + r;
@@ -1847,14 +1850,22 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             },
             [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
                 store32(Gs + row * LDX + c0, dy);
-                store32(B1 + row * LDX + c0, dx);
                 store32(B3 + row * LDX + c0, dyx);
 #pragma unroll
                 for (int si = 0; si < FUSED_MAX_SEG; ++si)
-                    if (si < p.nseg && t0 + row >= p.seg[si].off && t0 + row < p.seg[si].off + p.seg[si].T)
-                        store32(p.dseg_out[si] + ((size_t)c_real * p.seg[si].T + (t0 + row - p.seg[si].off)) * FD + c0, dx);
+                    if (si < p.nseg && t0 + row >= p.seg[si].off && t0 + row < p.seg[si].off + p.seg[si].T) {
+                        const size_t frow = (size_t)c_real * p.seg[si].T + (t0 + row - p.seg[si].off);
+                        if (p.feat_thresh) {    // d(projection output) = d(LayerNorm input) .* feature-dropout mask (the forward's keying)
+                            const uint64_t fk = dev_seed ? site_key(seed_dev, (uint32_t)si, SITE_FEAT) : p.feat_key[si];
+#pragma unroll
+                            for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(fk, (uint32_t)frow, (uint32_t)(c0 + j), p.feat_thresh, p.feat_inv);
+                        }
+                        store32(p.dseg_out[si] + frow * FD + c0, dx);
+                    }
+                store32(B1 + row * LDX + c0, dx);       // (masked) gradient of the projection output: proj_b partials below
             });
         __syncthreads();
+        if (p.dx0_out) store_block(p.dx0_out + tok0 * FD, Gs, S);      // d(token-prep output) behind its dropout mask: learned-position gradient
         if (tid < 128) pg[tid] = colsum_lds(B3, 0, S, tid);
         else pg[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
         for (int si = 0; si < p.nseg; ++si) {
@@ -1877,17 +1888,17 @@ int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool determi
     return 0;
 }
 
-template <int CM, bool TILED>
+template <int CM, bool TILED, int DH>
 static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
-    size_t lds = (size_t)(6 * 48 * LDX + FH * 3 * 48) * sizeof(float);
+    size_t lds = (size_t)(6 * 48 * LDX + (FH * FDH / DH) * 3 * 48) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, TILED>),
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, TILED, DH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_BWD, st);
-    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED>), dim3(p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -1897,9 +1908,11 @@ int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st) {
     EGX_CHECK(p.S <= 48, "fused backward: S=%d > 48", p.S);
     if (p.tiled) {
         EGX_CHECK(compute == CM_BF16 || compute == CM_SPLIT, "tiled mode: compute must be bf16 or f32s");
-        return compute == CM_BF16 ? launch_bwd<CM_BF16, true>(p, st) : launch_bwd<CM_SPLIT, true>(p, st);
+        return compute == CM_BF16 ? launch_bwd<CM_BF16, true, 32>(p, st) : launch_bwd<CM_SPLIT, true, 32>(p, st);
     }
-    return compute == CM_BF16 ? launch_bwd<CM_BF16, false>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT, false>(p, st) : launch_bwd<CM_F32, false>(p, st);
+    if (p.n_heads == 2 * FH)
+        return compute == CM_BF16 ? launch_bwd<CM_BF16, false, 16>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT, false, 16>(p, st) : launch_bwd<CM_F32, false, 16>(p, st);
+    return compute == CM_BF16 ? launch_bwd<CM_BF16, false, 32>(p, st) : compute == CM_SPLIT ? launch_bwd<CM_SPLIT, false, 32>(p, st) : launch_bwd<CM_F32, false, 32>(p, st);
 }
 
 }  // namespace egx

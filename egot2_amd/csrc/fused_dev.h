@@ -72,6 +72,14 @@ __device__ __forceinline__ Frag<CM> load_frag(const float* p, int q) {
     return make_frag<CM>(a, b);
 }
 
+// fragment over a head dimension of DH (32: a full K-block; 16: the K-block's second half is zero — the shipped PNR / OSCC
+// translators run 8 heads of 16, HOI/models/pnr/video_model_transfer_3task.py:231)
+template <int CM, int DH>
+__device__ __forceinline__ Frag<CM> load_head_frag(const float* p, int q) {
+    if constexpr (DH == 32) return load_frag<CM>(p, q);
+    else return make_frag<CM>(*reinterpret_cast<const float4*>(p + 4 * q), make_float4(0, 0, 0, 0));
+}
+
 template <int CM>
 __device__ __forceinline__ Frag<CM> zero_frag() {
     return make_frag<CM>(make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));

@@ -258,12 +258,7 @@ class EncoderFn(torch.autograd.Function):
                 spec = dataclasses.replace(spec, impl="generic")
             elif any(feat_grad):
                 pass
-            else:
-                # learned positional table (HOI `pe`): the fused per-clip backward emits no gradient for it; the wide
-                # bf16 path and the generic kernels do
-                probe = spec.config()
-                if lib.egx_encoder_impl(C.byref(probe), segs, B) in (EGX_IMPL_FUSED, EGX_IMPL_TILED):
-                    spec = dataclasses.replace(spec, impl="generic")
+            # (a learned positional table - the HOI translators' `pe` - gets its gradient from every implementation)
         # first-tokens-only output: in-kernel on the fused path; elsewhere the full block is sliced here (and the gradient
         # scattered back in backward)
         py_slice = 0
