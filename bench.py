@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-seconds", type=float, default=3.6, help="auto trials: total timed GPU work to aim for")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch clips per GPU; strong: --batch clips in total, sharded over the ranks (SURVEY.md 8e)")
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi"],
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5hhi", "c5hoi", "pnr"],
                     help="BASELINE.json configuration (default c2 = configs[1], the metric)")
     ap.add_argument("--batch", type=int, default=0,
                     help="clips per GPU (0 = 256; with --frames > 16 on c1 - c3: 3840 // frames, i.e. the headline's 3840 frames per task - "
@@ -294,7 +294,7 @@ def run(args) -> int:
             n = int(t.item())
         return n
 
-    fused_graph_ok = wl["name"] in ("c1", "c2", "c3")        # device-resident dropout seed: fused kernels only
+    fused_graph_ok = wl["name"] in ("c1", "c2", "c3", "pnr")        # device-resident dropout seed: fused kernels only
     use_graph = not args.no_graph and fused_graph_ok
     if use_graph:
         model.enable_device_seed()
@@ -605,7 +605,7 @@ def measure_roofline(torch, lib, step, wl, dtype):
     (forward, dX and dW: 3 x forward GEMM FLOPs minus the feature-projection dX) summed over its launches."""
     import ctypes as C
     B, S, d, L, segs = wl["B"], wl["S"], wl["d"], wl["L"], wl["segs"]
-    dff = 2048
+    dff = wl.get("dff", 2048)
     N = B * S
     ffn = L * 4.0 * N * d * dff
     proj = sum(2.0 * B * t * k * d for t, k, pj in segs if pj)
@@ -621,7 +621,7 @@ def measure_roofline(torch, lib, step, wl, dtype):
         "wide_attn_bwd_kernel": L * 8.0 * B * S * S * d,
     }
     lib.egx_timing_enable(1)
-    reps = 16 if wl["name"] in ("c1", "c2", "c3") else 4
+    reps = 16 if wl["name"] in ("c1", "c2", "c3", "pnr") else 4
     for _ in range(reps):
         step()
     torch.cuda.synchronize()

@@ -101,6 +101,24 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
                 f"output (B*T, d) + lossAV (FC + weighted CE + scores, one launch each way), dropout={p}")
         d, S = 128, 3 * T
         model.extra_params = list(head.FC.parameters())
+    elif name == "pnr":
+        # the shipped PNR / OSCC EgoT2-s recipe (HOI/configs/pnr/ts_pnr.yaml:28-34; video_model_transfer_3task.py:212-258):
+        # 16 + 16 + 8 + 8 = 48 tokens, d = 128, 8 heads of 16, d_ff = 256, 6 layers, feature dropout, learned positions
+        from . import hoi_pnr
+        L = layers or 6
+        p = 0.1 if dropout is None else dropout
+        cfg = NS(DATA=NS(TASK="state_change_detection"),
+                 MODEL=NS(TRANSLATION_INPUT_FEATURES=128, TRANSLATION_LAYERS=L, FEAT_DROPOUT_RATE=p, TRANSFORMER_DROPOUT_RATE=p))
+        model = hoi_pnr.TaskFusionMFTransformer3TaskDropout(cfg).to(device).set_compute(dtype or "f32s", impl).train()
+        feats = [torch.randn(B, 16, 8192, device=device), torch.randn(B, 16, 8192, device=device),
+                 _randn(gen, (B, 8, 2048), device), _randn(gen, (B, 8, 256), device)]
+        target = torch.randint(0, 2, (B,), generator=gen).to(device)
+        loss_fn = lambda: torch.nn.functional.cross_entropy(model.forward_features(*feats).squeeze(2), target)   # noqa: E731
+        segs = [(16, 8192, True), (16, 8192, True), (8, 2048, True), (8, 256, True)]
+        fl = encoder_flops(B, segs, 128, 256, L, extra_fwd=2.0 * B * 128 * 2)
+        desc = (f"HOI PNR / OSCC EgoT2-s translator (ts_pnr.yaml recipe): S=48 (16+16+8+8), d=128 h=8 d_ff=256, {L} layers, B={B}/GPU, "
+                f"8192-wide PNR / OSCC features, feature + encoder dropout {p}, learned positions, CE")
+        d, S = 128, 48
     elif name == "c4":
         from . import hoi_lta
         L = layers or 4
@@ -200,4 +218,4 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
     return {"name": name, "model": model, "feats": feats, "loss_fn": loss_fn, "params": params, "flops": fl,
             "describe": desc, "B": B, "S": S, "d": d, "segs": segs, "L": L, "compute": model.egx_compute,
             "batch_arg": batch, "frames": frames, "layers_arg": layers or 0, "encoder_only": bool(encoder_only),
-            "producer": locals().get("producer")}
+            "producer": locals().get("producer"), "dff": 256 if name == "pnr" else 2048}

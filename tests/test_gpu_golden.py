@@ -70,8 +70,8 @@ def hip_run(c, model, feats):
 @pytest.mark.parametrize("name", FIXTURES)
 def test_hip_matches_reference_fixture(egx_lib, cuda, name, compute, tol_out, tol_grad):
     c, z = load_fixture(name)
-    if compute == "f32s" and c["kind"] not in ("ttm", "asd"):
-        pytest.skip("f32s differs from f32 only on the fused d = 128 kernels")
+    if compute == "f32s" and c["kind"] not in ("ttm", "asd", "pnr3", "ar3", "ar2"):
+        pytest.skip("f32s differs from f32 only on the per-clip d = 128 kernels (HHI TTM / ASD, HOI PNR / OSCC and action recognition)")
     model = build_ours(c)
     model.load_state_dict(seeded_state_dict(model, c["wseed"]))
     model = model.to(cuda).set_compute(compute).train()
