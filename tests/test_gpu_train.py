@@ -297,8 +297,9 @@ def _hip_ddp_worker(rank, world, port, q, overlapped):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("overlapped", [False, True])
-def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, overlapped):
+def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, overlapped, world):
     """the N-rank leg on the HIP backward itself (not the stock module): rank-sharded clips, ONE flat
     gradient buffer per rank straight out of the fused backward, one all-reduce (or the overlapped early / late pair),
     result == the single-process gradient on the concatenated batch."""
@@ -306,8 +307,8 @@ def test_two_rank_hip_backward_allreduce_equals_single_process(egx_lib, cuda, ov
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000 + (7 if overlapped else 0)
-    procs = [ctx.Process(target=_hip_ddp_worker, args=(r, 2, port, q, overlapped)) for r in range(2)]
+    port = 39500 + os.getpid() % 2000 + (7 if overlapped else 0) + 13 * world
+    procs = [ctx.Process(target=_hip_ddp_worker, args=(r, world, port, q, overlapped)) for r in range(world)]
     for p in procs:
         p.start()
     n, one_storage, grads = q.get(timeout=300)
@@ -380,7 +381,8 @@ def _wide_bucket_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_wide_bucketed_exchange_equals_single_process(egx_lib, cuda):
+@pytest.mark.parametrize("world", [2, 4])
+def test_two_rank_wide_bucketed_exchange_equals_single_process(egx_lib, cuda, world):
     """VERDICT r2 missing #1: gradient exchange overlapped with the backward on the WIDE path (configs[3] / [4]): the encoder's
     backward announces one slice of the flat buffer per layer, last layer first (egx_config.bucket_cb), every slice is
     all-reduced as it is announced, the head's torch gradients follow, and the result equals the single-process gradient on the
@@ -389,8 +391,8 @@ def test_two_rank_wide_bucketed_exchange_equals_single_process(egx_lib, cuda):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 41500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_wide_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 41500 + os.getpid() % 2000 + 13 * world
+    procs = [ctx.Process(target=_wide_bucket_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     ncoll, nseen, lay_ok, grads = q.get(timeout=300)
