@@ -62,7 +62,7 @@ BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 class DecConfig(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("d_ff", C.c_int), ("n_layers", C.c_int), ("vocab", C.c_int),
                 ("sy", C.c_int), ("S", C.c_int), ("ln_eps", C.c_float), ("compute", C.c_int), ("p_drop", C.c_float),
-                ("p_pos", C.c_float)]
+                ("p_pos", C.c_float), ("seed_ptr", C.c_void_p)]
 
 
 _DEC_LAYER_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "norm1_w", "norm1_b", "ca_in_w", "ca_in_b", "ca_out_w",

@@ -104,6 +104,12 @@ static inline uint32_t drop_threshold(float p) {
     uint32_t u = (uint32_t)(t + 0.5);
     return u ? u : 1u;
 }
+// A dropout key handed to a kernel is either the key itself (site_key() results are ODD) or the device address (8-byte aligned:
+// EVEN) of a key that a kernel ahead of it on the stream derives from a device-resident seed (derive_keys: hipGraph replays then
+// draw fresh masks). Resolved once per kernel, under the `thresh != 0` test.
+__device__ __forceinline__ uint64_t resolve_key(uint64_t k) {
+    return (k & 1ull) ? k : *reinterpret_cast<const uint64_t*>(k);
+}
 __host__ __device__ static inline uint64_t site_key(uint64_t seed, uint32_t layer, uint32_t site) {
     uint64_t k = seed * 0x9E3779B97F4A7C15ull + ((uint64_t)layer << 8 | site) * 0xD1B54A32D192ED03ull;
     k ^= k >> 29;

@@ -817,6 +817,20 @@ int ffn_dw_reduce(const SlabReduce& a, const ReducePartialsParams* rp, bool dete
 }
 
 __global__ void seed_advance_kernel(uint64_t* seed) { *seed = *seed * 6364136223846793005ull + 1442695040888963407ull; }
+__global__ void derive_keys_kernel(uint64_t* seed, uint64_t* table, uint32_t layer0, int n, int advance) {
+    uint64_t s = *seed;
+    __syncthreads();        // every thread has read the old value before thread 0 replaces it
+    if (advance) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        if (threadIdx.x == 0) *seed = s;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) table[i] = site_key(s, layer0 + (uint32_t)(i / 8), (uint32_t)(i % 8));
+}
+int derive_keys(uint64_t* seed, uint64_t* table, uint32_t layer0, int nlayer, int advance, hipStream_t st) {
+    hipLaunchKernelGGL(derive_keys_kernel, dim3(1), dim3(256), 0, st, seed, table, layer0, nlayer * 8, advance);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
 int seed_advance(uint64_t* seed, hipStream_t st) {
     hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed);
     EGX_LAUNCH_CHECK();

@@ -134,4 +134,13 @@ int relu_mask(float* dy, const float* y, size_t n, hipStream_t st);
 int gelu_fwd(const float* z, float* h, size_t n, hipStream_t st);
 int gelu_bwd(const float* z, const float* dh, float* dz, size_t n, hipStream_t st);
 
+// Device-resident dropout seed outside the per-clip kernels: table[(layer - layer0) * 8 + site] = site_key(*seed, layer, site) for
+// `nlayer` layers, computed on the stream by one small launch (advance != 0: *seed = lcg(*seed) first - the training forward).
+// Kernels then receive the ADDRESS of their key (common.h resolve_key), so a captured hipGraph draws fresh masks per replay.
+constexpr int DROP_KEY_SLOTS = 8;
+int derive_keys(uint64_t* seed, uint64_t* table, uint32_t layer0, int nlayer, int advance, hipStream_t st);
+static inline uint64_t key_slot(const uint64_t* table, uint32_t layer_rel, uint32_t site) {
+    return (uint64_t)(uintptr_t)(table + (size_t)layer_rel * DROP_KEY_SLOTS + site);
+}
+
 }  // namespace egx

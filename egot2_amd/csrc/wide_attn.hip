@@ -72,6 +72,7 @@ __device__ __forceinline__ void image_store(const ImageRegs<DH, SP, NTH>& R, uns
 // ---- forward ----------------------------------------------------------------------------------------------------
 template <int DH, int NKT>
 __global__ __launch_bounds__(256) void wide_attn_fwd_kernel(WideAttnParams p) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
     constexpr int RS = DH * 2 + 32, SP = NKT * 16, NKB = DH / 32, NCT = DH / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kimg = smem;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void wide_attn_fwd_kernel(WideAttnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pv = sc[kt][e] * inv;
-                if (p.drop_thresh) pv *= drop_scale(p.drop_key, (uint32_t)(bh * 128 + query), (uint32_t)(kt * 16 + 4 * g + e), p.drop_thresh, p.drop_inv);
+                if (p.drop_thresh) pv *= drop_scale(dkey, (uint32_t)(bh * 128 + query), (uint32_t)(kt * 16 + 4 * g + e), p.drop_thresh, p.drop_inv);
                 sc[kt][e] = pv;
             }
         f32x4 oc[NCT];
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void wide_attn_fwd_kernel(WideAttnParams p) {
 // NKT = 8 (S <= 128): 512 threads, one query tile (pass T) and one key tile (pass N) per wave, two waves per SIMD.
 template <int DH, int NKT>
 __global__ __launch_bounds__(NKT * 64) void wide_attn_bwd_kernel(WideAttnParams p) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
     constexpr int RS = DH * 2 + 32, SP = NKT * 16, NKB = DH / 32, NCT = DH / 16, NW = NKT, NTH = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Qimg = smem;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NKT * 64) void wide_attn_bwd_kernel(WideAttnParams 
             for (int e = 0; e < 4; ++e) {
                 int key = kt * 16 + 4 * g + e;
                 float pv = (key < S && query < S) ? __expf(a[e] * scale - lq) : 0.f;
-                float ks = p.drop_thresh ? drop_scale(p.drop_key, (uint32_t)(bh * 128 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
+                float ks = p.drop_thresh ? drop_scale(dkey, (uint32_t)(bh * 128 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
                 float dm = c[e] * ks;
                 dl += pv * dm;
                 a[e] = pv; c[e] = dm;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(NKT * 64) void wide_attn_bwd_kernel(WideAttnParams 
             for (int e = 0; e < 4; ++e) {
                 int query = qt * 16 + 4 * g + e;
                 float pv = (key < S && query < S) ? __expf(a[e] * scale - lq[e]) : 0.f;
-                float ks = p.drop_thresh ? drop_scale(p.drop_key, (uint32_t)(bh * 128 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
+                float ks = p.drop_thresh ? drop_scale(dkey, (uint32_t)(bh * 128 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
                 a[e] = pv * ks;                                   // dropped P
                 c[e] = pv * (ks * c[e] - dq4[e]) * scale;         // dS
             }

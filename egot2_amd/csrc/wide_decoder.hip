@@ -87,6 +87,7 @@ __device__ __forceinline__ void store8(void* base, size_t idx, const float (&a)[
 
 template <int DH, bool BWD, bool F32>
 __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
     __shared__ float sQ[4][DA_MAXQ][DH];        // query rows (fp32)
     __shared__ float sG[4][DA_MAXQ][DH];        // dO rows (backward)
     __shared__ float sP[4][DA_MAXQ][64];        // probabilities after dropout
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
         const float e = live ? __expf(s - m) : 0.f;
         const float prob = e / wsum64d(e);
         float mask = 1.f;
-        if (p.drop_thresh) mask = drop_scale(p.drop_key, (uint32_t)(bh * DA_MAXQ + i), (uint32_t)lane, p.drop_thresh, p.drop_inv);
+        if (p.drop_thresh) mask = drop_scale(dkey, (uint32_t)(bh * DA_MAXQ + i), (uint32_t)lane, p.drop_thresh, p.drop_inv);
         sP[wave][i][lane] = prob * mask;
         if constexpr (BWD) {
             float dp = 0.f;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int64_t* __restric
     float o[4] = {e.x * scale + pp.x, e.y * scale + pp.y, e.z * scale + pp.z, e.w * scale + pp.w};
     if (thresh) {
         float ds[4];
-        drop_scale4(key, (uint32_t)row, (uint32_t)c, thresh, inv, ds);
+        drop_scale4(resolve_key(key), (uint32_t)row, (uint32_t)c, thresh, inv, ds);
         o[0] *= ds[0]; o[1] *= ds[1]; o[2] *= ds[2]; o[3] *= ds[3];
     }
     *reinterpret_cast<float4*>(x32 + (size_t)row * d + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void dec_embed_grad_kernel(const int64_t* __re
         for (int row = grp; row < rows; row += 4) {
             if (tok[row] != v) continue;                                 // wave-uniform
             float g = dy[(size_t)row * d + c];
-            if (thresh) g *= drop_scale(key, (uint32_t)row, (uint32_t)c, thresh, inv);
+            if (thresh) g *= drop_scale(resolve_key(key), (uint32_t)row, (uint32_t)c, thresh, inv);
             acc += g;
         }
     }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(1024) void dec_embed_grad_small_kernel(const int64_
         for (int u = 0; u < 8; ++u) {
             if (row + u >= r1) break;
             float gv = g[u];
-            if (thresh) gv *= drop_scale(key, (uint32_t)(row + u), (uint32_t)cc, thresh, inv);
+            if (thresh) gv *= drop_scale(resolve_key(key), (uint32_t)(row + u), (uint32_t)cc, thresh, inv);
             if (t[u] >= 0 && t[u] < V) mine[t[u] * 64 + lane] += gv;      // lane-private column: no conflict, row order kept
         }
     }
@@ -319,7 +320,7 @@ struct DLayer {
 struct DPlan {
     int B, sy, S, d, H, dff, L, V;
     size_t Md, Nm;
-    size_t zero, mem16, xL32, qkv32;
+    size_t zero, mem16, xL32, qkv32, keys;
     DLayer layer[16];
     size_t saved_bytes;
     size_t gA, gB, dres, dattn16, dqkv32, slab_all, slab_all_bytes, lnpart, cspart, cspart_side, fcslab, fcslab_bytes, scratch_bytes;
@@ -348,6 +349,7 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
     const size_t d = pl.d, dff = pl.dff, Md = pl.Md, Nm = pl.Nm;
     size_t cur = 0;
     pl.zero = dtake(cur, 1024);
+    pl.keys = dtake(cur, (size_t)16 * DROP_KEY_SLOTS * sizeof(uint64_t));
     pl.mem16 = dtake(cur, Nm * d * 2);
     for (int l = 0; l < pl.L; ++l) {
         DLayer& o = pl.layer[l];
@@ -400,11 +402,19 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
 }
 
 struct DDrop { uint64_t key = 0; uint32_t thresh = 0; float inv = 1.f; };
+thread_local const uint64_t* g_dkeys = nullptr;     // device-resident seed: table of this call's keys (layers 0x40 + l), see derive_keys
 DDrop ddrop(int training, float p, uint64_t seed, uint32_t layer, uint32_t site) {
     DDrop dr;
-    if (training && p > 0.f) { dr.key = site_key(seed, 0x40u + layer, site); dr.thresh = drop_threshold(p); dr.inv = p < 1.f ? 1.f / (1.f - p) : 0.f; }
+    if (training && p > 0.f) {
+        dr.key = g_dkeys ? key_slot(g_dkeys, layer, site) : site_key(seed, 0x40u + layer, site);
+        dr.thresh = drop_threshold(p); dr.inv = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    }
     return dr;
 }
+struct DKeyScope {
+    DKeyScope(const uint64_t* t) { g_dkeys = t; }
+    ~DKeyScope() { g_dkeys = nullptr; }
+};
 enum { DS_SELF = 1, DS_SA_OUT = 2, DS_CROSS = 3, DS_CA_OUT = 4, DS_FFN = 5, DS_FFN_OUT = 6, DS_EMBED = 7 };
 
 // The decoder's weight gradients (small TN GEMMs over B * sy target rows, bias column sums) are off the critical path of its
@@ -459,11 +469,11 @@ struct SideJoin {
 // a host seed is baked into a captured graph: every replay would redraw the SAME masks. The encoder's fused kernels have the
 // device-resident seed (egx_config.seed_ptr) for that; the decoder has not, so training-mode dropout under capture is refused.
 int refuse_captured_dropout(const egx_dec_config* cfg, int training, hipStream_t st) {
-    if (!training || !(cfg->p_drop > 0.f || cfg->p_pos > 0.f)) return 0;
+    if (!training || !(cfg->p_drop > 0.f || cfg->p_pos > 0.f) || cfg->seed_ptr) return 0;      // with seed_ptr every replay draws fresh masks
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
     EGX_CHECK(cs == hipStreamCaptureStatusNone, "egx_decoder: training-mode dropout (p > 0) cannot be captured in a hipGraph: the host seed "
-              "would be baked in and every replay would repeat the same masks; launch eagerly or capture with p = 0");
+              "would be baked in and every replay would repeat the same masks; launch eagerly, capture with p = 0, or pass egx_dec_config.seed_ptr");
     return 0;
 }
 
@@ -492,6 +502,10 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
     hipStream_t st = (hipStream_t)stream;
     if (refuse_captured_dropout(cfg, training, st)) return 1;
     const int d = pl.d, dff = pl.dff, Md = (int)pl.Md, Nm = (int)pl.Nm, dh = d / pl.H;
+    // device-resident seed (the encoder's forward of this step has advanced it): this call's keys, derived on the stream
+    const bool dev_keys = cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f);
+    if (dev_keys && derive_keys(const_cast<uint64_t*>(cfg->seed_ptr), at<uint64_t>(saved, pl.keys), 0x40u, 16, 0, st)) return 1;
+    DKeyScope key_scope(dev_keys ? cat<uint64_t>(saved, pl.keys) : nullptr);
     EGX_HIP(hipMemsetAsync(at<char>(saved, pl.zero), 0, 1024, st));
     const void* zero = at<char>(saved, pl.zero);
     bf16_t* mem16 = at<bf16_t>(saved, pl.mem16);
@@ -618,6 +632,8 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     hipStream_t st = (hipStream_t)stream;
     if (refuse_captured_dropout(cfg, training, st)) return 1;
     const int d = pl.d, dff = pl.dff, Md = (int)pl.Md, Nm = (int)pl.Nm, dh = d / pl.H;
+    const bool dev_keys = cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f);
+    DKeyScope key_scope(dev_keys ? cat<uint64_t>(saved, pl.keys) : nullptr);
     const void* zero = cat<char>(saved, pl.zero);
     if (zero_buf && zero_bytes) EGX_HIP(hipMemsetAsync(zero_buf, 0, zero_bytes, st));
     float* gA = at<float>(scratch, pl.gA);

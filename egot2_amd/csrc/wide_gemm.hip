@@ -73,6 +73,7 @@ template <int TJ>
 __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc)[4][TJ], int mb, int nb, int prow0, int r, int g) {
     constexpr int JG = TJ >= 4 ? TJ / 4 : 1;         // 64-row groups of a wave: one column-sum partial row each (TJ < 4: no column sums, see wide_gemm_nt)
     float cs_part[JG][4][4];
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
 #pragma unroll
     for (int jg = 0; jg < JG; ++jg)
 #pragma unroll
@@ -98,7 +99,7 @@ __device__ __forceinline__ void nt_epilogue(const WideGemmParams& p, f32x4 (&acc
             }
             if (p.drop_thresh) {
                 float ds[4];
-                drop_scale4(p.drop_key, (uint32_t)m, (uint32_t)n, p.drop_thresh, p.drop_inv, ds);
+                drop_scale4(dkey, (uint32_t)m, (uint32_t)n, p.drop_thresh, p.drop_inv, ds);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= ds[e];
             }
@@ -169,6 +170,7 @@ template <int TJ, int NI = 4, bool R16 = false>
 __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (&acc)[NI][TJ], int mb, int nb, int prow0, int r, int g, int lane, unsigned char* region) {
     constexpr int EPI_LDB = epi_ldb<NI>(), EPI_LDF = epi_ldf<NI>();
     // phase A (accumulator layout): bias, ReLU, dropout
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
     float4 bb[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const WideGemmParams& p, f32x4 (
         }
         if (p.drop_thresh) {
             float ds[4];
-            drop_scale4(p.drop_key, (uint32_t)(mb + j * 16 + r), (uint32_t)(nb + i * 16 + 4 * g), p.drop_thresh, p.drop_inv, ds);
+            drop_scale4(dkey, (uint32_t)(mb + j * 16 + r), (uint32_t)(nb + i * 16 + 4 * g), p.drop_thresh, p.drop_inv, ds);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= ds[e];
         }

@@ -23,6 +23,7 @@ struct WPlan {
     int B, S, d, H, dff, L, nseg;
     size_t N;
     int seg_off[EGX_MAX_SEGMENTS];
+    size_t keys;        // dropout keys derived from a device-resident seed (derive_keys): (max(L, nseg) layers) x 8 slots
     size_t zero, seg_w[EGX_MAX_SEGMENTS], seg_feat16[EGX_MAX_SEGMENTS], seg_pre[EGX_MAX_SEGMENTS], seg_stats[EGX_MAX_SEGMENTS];
     WLayer layer[64];
     size_t saved_bytes;
@@ -42,6 +43,7 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
     const size_t d = pl.d, N = pl.N, dff = pl.dff;
     size_t cur = 0;
     pl.zero = take(cur, 1024);
+    pl.keys = take(cur, (size_t)64 * DROP_KEY_SLOTS * sizeof(uint64_t));
     for (int i = 0; i < pl.nseg; ++i) {
         size_t rows = (size_t)B * segs[i].T;
         if (segs[i].proj_w) {
@@ -110,11 +112,20 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
 }
 
 struct Drop { uint64_t key = 0; uint32_t thresh = 0; float inv = 1.f; };
+// g_keys != null (device-resident seed): the key is the ADDRESS of its slot in the table derive_keys() filled on the stream
+thread_local const uint64_t* g_keys = nullptr;
 Drop mkdrop(int training, float p, uint64_t seed, uint32_t layer, uint32_t site) {
     Drop dr;
-    if (training && p > 0.f) { dr.key = site_key(seed, layer, site); dr.thresh = drop_threshold(p); dr.inv = p < 1.f ? 1.f / (1.f - p) : 0.f; }
+    if (training && p > 0.f) {
+        dr.key = g_keys ? key_slot(g_keys, layer, site) : site_key(seed, layer, site);
+        dr.thresh = drop_threshold(p); dr.inv = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    }
     return dr;
 }
+struct KeyScope {       // sets the table for the mkdrop calls of one forward / backward
+    KeyScope(const uint64_t* t) { g_keys = t; }
+    ~KeyScope() { g_keys = nullptr; }
+};
 
 template <class T> T* at(void* base, size_t off) { return reinterpret_cast<T*>((char*)base + off); }
 template <class T> const T* cat(const void* base, size_t off) { return reinterpret_cast<const T*>((const char*)base + off); }
@@ -149,8 +160,11 @@ int wide_encoder_fwd(const egx_config* cfg, const egx_segment* segs, const float
     WPlan pl;
     make_wplan(cfg, segs, B, pl);
     const int d = pl.d, S = pl.S, dff = pl.dff, N = (int)pl.N;
-    EGX_CHECK(!(cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)),
-              "device-resident dropout seed (seed_ptr) is only supported by the fused kernels");
+    // device-resident seed: one small launch advances it (training forward with advance_seed) and derives every key of this
+    // call into `saved`; the kernels below read their keys from there, and so does the backward
+    const bool dev_keys = cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f);
+    if (dev_keys && derive_keys(const_cast<uint64_t*>(cfg->seed_ptr), at<uint64_t>(saved, pl.keys), 0, 64, cfg->advance_seed, st)) return 1;
+    KeyScope key_scope(dev_keys ? cat<uint64_t>(saved, pl.keys) : nullptr);
     EGX_HIP(hipMemsetAsync(at<char>(saved, pl.zero), 0, 1024, st));
     const void* zero = at<char>(saved, pl.zero);
 
@@ -272,6 +286,9 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
     make_wplan(cfg, segs, B, pl);
     const int d = pl.d, S = pl.S, dff = pl.dff, N = (int)pl.N;
     const void* zero = cat<char>(saved, pl.zero);
+    // device-resident seed: the forward left this step's keys in `saved`
+    const bool dev_keys = cfg->seed_ptr && training && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f);
+    KeyScope key_scope(dev_keys ? cat<uint64_t>(saved, pl.keys) : nullptr);
     if (cfg->zero_buf && cfg->zero_bytes) EGX_HIP(hipMemsetAsync(cfg->zero_buf, 0, cfg->zero_bytes, st));
     float* gA = at<float>(scratch, pl.gA);
     float* gB = at<float>(scratch, pl.gB);

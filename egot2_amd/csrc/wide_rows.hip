@@ -27,6 +27,7 @@ constexpr int LN_MAXV = 4;      // float4 per lane: d <= 1024
 }  // namespace
 
 __global__ __launch_bounds__(256) void wide_ln_fwd_kernel(WideLnFwdParams p) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = p.d, nv = (d + 255) / 256;
     const float inv_d = 1.f / (float)d;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void wide_ln_fwd_kernel(WideLnFwdParams p) {
                 if (pos) { float4 a = *reinterpret_cast<const float4*>(pos + c); o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; }
                 if (p.drop_thresh) {
                     float ds[4];
-                    drop_scale4(p.drop_key, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv, ds);
+                    drop_scale4(dkey, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv, ds);
                     o[0] *= ds[0]; o[1] *= ds[1]; o[2] *= ds[2]; o[3] *= ds[3];
                 }
                 if (p.y32) *reinterpret_cast<float4*>(p.y32 + (size_t)orow * d + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -90,6 +91,7 @@ int wide_ln_fwd(const WideLnFwdParams& p, hipStream_t st) {
 // Each block owns a CONTIGUOUS range of rows; its four waves interleave over it and keep per-column partial sums in
 // registers, combined through LDS at the end: partials[block][k][d], k = 0 d(gamma), 1 d(beta), 2 column sums of dx16.
 __global__ __launch_bounds__(256) void wide_ln_bwd_kernel(WideLnBwdParams p, int rows_per_block) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull, okey = p.out_thresh ? resolve_key(p.out_key) : 0ull;
     __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = p.d, nv = (d + 255) / 256;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void wide_ln_bwd_kernel(WideLnBwdParams p, int
                 float4 g = *reinterpret_cast<const float4*>(dy + c);
                 if (p.drop_thresh) {
                     float ds[4];
-                    drop_scale4(p.drop_key, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv, ds);
+                    drop_scale4(dkey, (uint32_t)orow, (uint32_t)c, p.drop_thresh, p.drop_inv, ds);
                     g.x *= ds[0]; g.y *= ds[1]; g.z *= ds[2]; g.w *= ds[3];
                 }
                 float4 x = *reinterpret_cast<const float4*>(pre + c);
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void wide_ln_bwd_kernel(WideLnBwdParams p, int
                 float m[4] = {o[0], o[1], o[2], o[3]};
                 if (p.out_thresh) {
                     float ds[4];
-                    drop_scale4(p.out_key, (uint32_t)row, (uint32_t)c, p.out_thresh, p.out_inv, ds);
+                    drop_scale4(okey, (uint32_t)row, (uint32_t)c, p.out_thresh, p.out_inv, ds);
                     m[0] *= ds[0]; m[1] *= ds[1]; m[2] *= ds[2]; m[3] *= ds[3];
                 }
                 if (p.dx32) {
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void wide_pos_grad_kernel(const float* __restr
         float4 v = *reinterpret_cast<const float4*>(dtok + (size_t)orow * d + c);
         if (thresh) {
             float ds[4];
-            drop_scale4(key, (uint32_t)orow, (uint32_t)c, thresh, inv, ds);
+            drop_scale4(resolve_key(key), (uint32_t)orow, (uint32_t)c, thresh, inv, ds);
             v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
         }
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;

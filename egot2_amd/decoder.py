@@ -33,7 +33,8 @@ class DecoderMixin:
             train = bool(self.training)
             meta = dict(n_layers=len(decoder.layers), n_heads=n_heads, d_ff=d_ff, ln_eps=decoder.layers[0].norm1.eps,
                         p_drop=p_drop if train else 0.0, p_pos=pos_embed.dropout.p if train else 0.0, training=train,
-                        seed=self._egx_seed() if train else 0)
+                        seed=self._egx_seed() if train else 0,
+                        seed_ptr=(self._egx_seed_dev.data_ptr() if train and getattr(self, "_egx_seed_dev", None) is not None else 0))
             params = []
             for layer in decoder.layers:
                 sa, ca = layer.self_attn, layer.multihead_attn

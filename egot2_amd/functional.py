@@ -735,7 +735,7 @@ class DecoderFn(torch.autograd.Function):
         d = emb.shape[1]
         S = memory.shape[0] // B
         cfg = _lib.DecConfig(d, meta["n_heads"], meta["d_ff"], n_layers, emb.shape[0], sy, S, meta["ln_eps"], EGX_BF16,
-                             meta["p_drop"], meta["p_pos"])
+                             meta["p_drop"], meta["p_pos"], meta.get("seed_ptr") or None)
         sv, sc = C.c_size_t(0), C.c_size_t(0)
         check(lib.egx_decoder_workspace(C.byref(cfg), B, C.byref(sv), C.byref(sc)))
         need_grad = any(ctx.needs_input_grad)
@@ -778,7 +778,7 @@ class DecoderFn(torch.autograd.Function):
 
         d_memory = torch.empty_like(memory) if need[2] else None
         cfg = _lib.DecConfig(d, meta["n_heads"], meta["d_ff"], n_layers, emb.shape[0], sy, S, meta["ln_eps"], EGX_BF16,
-                             meta["p_drop"], meta["p_pos"])
+                             meta["p_drop"], meta["p_pos"], meta.get("seed_ptr") or None)
         layers = (_lib.DecLayer * n_layers)()
         lgr = (_lib.DecLayerGrads * n_layers)()
         for l in range(n_layers):

@@ -130,7 +130,7 @@ typedef struct egx_config {
     float p_drop;     /* encoder-layer dropout (attention probs, dropout1, FFN hidden, dropout2) */
     float p_pos;      /* dropout on the token-prep output (PositionalEncoding.dropout, fixed 0.1 in HHI) */
     float p_feat;     /* dropout on projected features before LN (HOI `dp`) */
-    const uint64_t* seed_ptr; /* optional DEVICE pointer: when non-NULL the fused kernels derive their dropout keys
+    const uint64_t* seed_ptr; /* optional DEVICE pointer: when non-NULL the per-clip, tiled and wide bf16 kernels derive their dropout keys
                                  from *seed_ptr instead of the host `seed` argument, so a captured hipGraph draws fresh
                                  masks on every replay (advance it with egx_seed_advance inside the graph, or set
                                  advance_seed). */
@@ -367,6 +367,8 @@ typedef struct egx_dec_config {
     int compute;        /* EGX_BF16 */
     float p_drop;       /* dropout of the decoder layers (attention probabilities, the three residual branches, FFN hidden) */
     float p_pos;        /* dropout of the positional encoding */
+    const uint64_t* seed_ptr;   /* optional DEVICE pointer (the translator's egx_config.seed_ptr): dropout keys are derived on the stream
+                                   from *seed_ptr instead of the host `seed`, so a captured hipGraph draws fresh masks per replay */
 } egx_dec_config;
 typedef struct egx_dec_layer {
     const float* sa_in_w; const float* sa_in_b; const float* sa_out_w; const float* sa_out_b; const float* norm1_w; const float* norm1_b;

@@ -195,3 +195,53 @@ def test_fused_decoder_under_graph_capture_matches_eager(egx_lib, cuda):
     assert torch.allclose(out, ref_out, rtol=0, atol=1e-5 * ref_out.abs().max().item() + 1e-6)
     for a, r in zip(static, ref):
         assert torch.allclose(a, r, rtol=0, atol=2e-3 * r.abs().max().item() + 1e-6), (a - r).abs().max().item()
+
+
+def test_fused_decoder_training_dropout_under_capture_needs_the_device_seed(egx_lib, cuda):
+    """a host seed baked into a captured graph would repeat the same masks on every replay, so training-mode
+    dropout under capture is refused - unless the model keeps its seed in device memory (enable_device_seed): then the
+    decoder derives its keys on the stream and every replay draws fresh masks."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import hhi_multitask, _lib
+    from tests.util import seeded_state_dict
+    vocab = {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+    args = NS(hidden_dim=256, num_heads=4, num_layers=2, dropout=0.3, lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None)
+    m = hhi_multitask.TaskTranslationPromptTransformer(args, vocab)
+    m.load_state_dict(seeded_state_dict(m, 9))
+    m = m.to(cuda).train()
+    m.set_compute("bf16")
+    mem = torch.randn(45, 6, 256, device=cuda)
+    y = torch.randint(0, 7, (6, 2), device=cuda)
+
+    def fwd():
+        return m.decode(y, mem)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception, match="hipGraph|captur"):
+        with torch.cuda.graph(g):
+            fwd()
+    torch.cuda.synchronize()
+    m.enable_device_seed()
+    with torch.cuda.stream(side):
+        fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+    m._egx_seed_dev.fill_(5)
+    g.replay()
+    torch.cuda.synchronize()
+    a = out.detach().clone()
+    m._egx_seed_dev.fill_(6)            # (the encoder's forward advances the seed in a real step)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and (a - out).abs().max().item() > 0
+    m._egx_seed_dev.fill_(5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, out)

@@ -134,8 +134,9 @@ def _lta_cfg(n, d, heads, layers, p):
                        NUM_CLASSES=[5, 7], DROPOUT_RATE=0.0, HEAD_ACT="softmax"), TEST=NS(NO_ACT=False))
 
 
-@pytest.mark.parametrize("impl,compute,n,d", [("wide", "bf16", 8, 256), ("wide", "bf16", 32, 768), ("generic", "f32", 4, 256)])
-def test_lta4_train_mode_matches_oracle_under_the_same_masks(egx_lib, cuda, impl, compute, n, d):
+@pytest.mark.parametrize("impl,compute,n,d,device_seed", [("wide", "bf16", 8, 256, False), ("wide", "bf16", 32, 768, False),
+                                                          ("generic", "f32", 4, 256, False), ("wide", "bf16", 8, 256, True)])
+def test_lta4_train_mode_matches_oracle_under_the_same_masks(egx_lib, cuda, impl, compute, n, d, device_seed):
     """The wide bf16 path (configs[3] flavour: 4 x n tokens, 8 heads, learned positions, identity action segment) and the
     generic kernels at p = 0.3 on all four encoder-layer sites."""
     from egot2_amd import hoi_lta
@@ -144,6 +145,10 @@ def test_lta4_train_mode_matches_oracle_under_the_same_masks(egx_lib, cuda, impl
     sd = seeded_state_dict(m, 9 + n)
     m.load_state_dict(sd)
     m = _pin_seed(m.to(cuda).set_compute(compute, impl).train(), seed)
+    if device_seed:         # the wide path reads its keys from a table derived on the stream from the device-resident seed
+        m.enable_device_seed()
+        m._egx_seed_dev.fill_(seed)
+        seed = dm.lcg(seed)
     feats = seeded_feats(10 + n, [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
     outs = m.forward_features(*[f.to(cuda) for f in feats])
     lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
