@@ -324,7 +324,10 @@ def run(args) -> int:
         return ok
 
     overlap = multi and not args.no_overlap and staged_backward_ok()
-    bucketed = multi and not args.no_overlap and not use_graph
+    # wide / generic configurations: per-layer buckets exchanged under the backward (eager launches: the bucket announcements are
+    # host callbacks) - or, with --graph-collectives, the same exchange CAPTURED with the step (announcements happen once, at
+    # capture time; the collectives replay from RCCL's stream as a parallel branch of the graph)
+    bucketed = multi and not args.no_overlap and not overlap and (wl["name"] in ("c4", "c5", "c5hhi", "c5hoi") or not use_graph)
     exch = {"collectives": None}
 
     def place_optimizer(with_opt):
@@ -354,11 +357,18 @@ def run(args) -> int:
             model.egx_defer_small = bool(overlap)
 
             def body():
-                fwd_bwd()
-                if overlap:
-                    ddp.allreduce_gradients_overlapped(F_egx.run_deferred, params, force=args.force_dist)
+                if bucketed:
+                    for p in params:
+                        p.grad = None
+                    with ddp.BucketedExchange(params, force=args.force_dist) as ex:
+                        fwd_bwd()
+                    exch["collectives"] = ex.collectives
                 else:
-                    ddp.allreduce_gradients(params, force=args.force_dist)
+                    fwd_bwd()
+                    if overlap:
+                        ddp.allreduce_gradients_overlapped(F_egx.run_deferred, params, force=args.force_dist)
+                    else:
+                        ddp.allreduce_gradients(params, force=args.force_dist)
                 if with_opt:
                     with_opt.step()
             gr = capture(body)
@@ -476,7 +486,7 @@ def run(args) -> int:
                                + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else
                                                                  " in per-layer buckets overlapped with the backward" if bucketed else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
-                   "launch": "one hipGraph replay per step" if use_graph else "eager",
+                   "launch": "one hipGraph replay per step" if (use_graph and not (bucketed and not args.graph_collectives)) else "eager",
                    "deterministic": bool(args.deterministic)},
         "library_launches_per_step": launches_per_step,
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,

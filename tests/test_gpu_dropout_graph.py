@@ -135,24 +135,29 @@ def test_wide_path_step_graph_replay_draws_fresh_masks(egx_lib, cuda):
         loss.backward()
         return loss
 
-    m._egx_seed_dev.fill_(777)
-    eager = step()
-    torch.cuda.synchronize()
-    g_eager = m.transformer.layers[0].linear1.weight.grad.clone()
+    # (warm-up, eager reference and capture all run on ONE side stream: an autograd graph kept alive from the default stream
+    # would leave AccumulateGrad nodes bound to it and break the capture)
     s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m._egx_seed_dev.fill_(777)
+        eager = step().item()
+        g_eager = m.transformer.layers[0].linear1.weight.grad.clone()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(2):
             step()
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         loss = step()
     m._egx_seed_dev.fill_(777)
     g.replay()
     torch.cuda.synchronize()
     l1, g1 = loss.item(), m.transformer.layers[0].linear1.weight.grad.clone()
-    assert abs(l1 - eager.item()) < 1e-6 * max(1.0, abs(l1)) and torch.equal(g1, g_eager)      # deterministic path: same seed, same step
+    assert abs(l1 - eager) < 1e-6 * max(1.0, abs(l1)) and torch.equal(g1, g_eager)      # deterministic path: same seed, same step
     g.replay()
     torch.cuda.synchronize()
     g2 = m.transformer.layers[0].linear1.weight.grad.clone()

@@ -576,7 +576,9 @@ def test_lossAV_mirror_matches_the_stock_modules(egx_lib, cuda):
 
 
 @pytest.mark.parametrize("extra", [["--force-dist"], ["--force-dist", "--graph-collectives"], ["--force-dist", "--no-overlap"],
-                                   ["--config", "c5hhi", "--batch", "32", "--force-dist"]])
+                                   ["--config", "c5hhi", "--batch", "32", "--force-dist"],
+                                   # round 4: the bucketed exchange CAPTURED with the step (device-resident dropout seed on the wide path)
+                                   ["--config", "c5hhi", "--batch", "32", "--force-dist", "--graph-collectives"]])
 def test_bench_distributed_code_paths_on_one_rank(cuda, extra):
     """The RCCL code paths of bench.py (staged-backward overlap, collectives captured inside the step's hipGraph, single
     collective, per-layer buckets on the wide path) with a one-rank process group: the JSON line must carry the exchange fields.
@@ -596,6 +598,7 @@ def test_bench_distributed_code_paths_on_one_rank(cuda, extra):
     assert out["value"] > 0 and out["allreduce_us"] > 0
     if "c5hhi" in extra:
         assert out["overlap"] == "bucketed" and out["collectives_per_step"] >= 4      # 3 encoder layers + remainder + the decoder's buffer
+        assert out["config"]["launch"] == ("one hipGraph replay per step" if "--graph-collectives" in extra else "eager")
     elif "--no-overlap" in extra:
         assert out["overlap"] == "none"
     else:
