@@ -71,6 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide", "tiled"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")
+    ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph also where eager launches are the default (c5hoi)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-line", action="store_true", help="skip the separate fwd+bwd+Adam measurement")
@@ -296,7 +297,9 @@ def run(args) -> int:
 
     # device-resident dropout seed: the per-clip / tiled kernels derive their keys in-kernel, the wide bf16 path and the fused
     # decoder from a key table computed on the stream (round 4) - every configuration replays as one hipGraph
-    fused_graph_ok = True
+    # (c5hoi - 225 launches with many side-stream forks in the decoder's backward - measures 7-10 % SLOWER as one graph than with
+    # eager launches, c5hhi 11 % faster, c4 equal: profiles/r04_wide_graph.txt; eager stays its default, --graph forces the capture)
+    fused_graph_ok = wl["name"] != "c5hoi" or args.graph
     use_graph = not args.no_graph and fused_graph_ok
     if use_graph:
         model.enable_device_seed()
