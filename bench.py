@@ -163,6 +163,13 @@ def launch_selftest(args):
     return 0
 
 
+def resolve_batch(args) -> int:
+    """--batch 0 = the configuration's default: 256 clips, or 3840 frames per task for the long-sequence workloads."""
+    if args.batch > 0:
+        return args.batch
+    return 3840 // args.frames if (args.config in ("c1", "c2", "c3") and args.frames > 16) else 256
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -208,8 +215,7 @@ def run(args) -> int:
     # fp32 accumulation ("f32s": fp32-grade results, tests/test_gpu_translator.py::test_split_bf16_mode_is_fp32_grade);
     # `--dtype f32` is the exact v_mfma_f32_16x16x4_f32 path, reported beside it as `native_f32`
     run_dtype = args.dtype or ("f32s" if args.config in ("c1", "c2") else None)
-    if args.batch <= 0:
-        args.batch = 3840 // args.frames if (args.config in ("c1", "c2", "c3") and args.frames > 16) else 256
+    args.batch = resolve_batch(args)
     # weak scaling: --batch clips on every GPU. strong scaling ("global B = 256 -> 32 clips / GPU at n = 8"): the
     # --batch clips are sharded over the ranks, the per-GPU work shrinks with N
     if args.scaling == "strong":

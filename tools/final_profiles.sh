@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/final_profiles.sh [round-tag, default r03]
+# usage (GPU box, repo root): tools/final_profiles.sh [round-tag, default r04]
 # Bench lines, rocprofv3 kernel stats and PMC counters of every BASELINE configuration -> gpurun_out/final/ (copy what is to
 # be kept into profiles/). Every step checks its exit code: a failed bench never leaves a half-written JSON behind.
 set -euo pipefail
-R=${1:-r03}
+R=${1:-r04}
 STAGES=${2:-bench,prof,trace,pmc}      # which parts to run (run pmc first and copy its files into profiles/ when the bench lines are to carry the counters)
 OUT=gpurun_out/final
 mkdir -p $OUT
@@ -27,6 +27,13 @@ bench f32 --dtype f32 --no-cpu-baseline
 bench bf16 --dtype bf16 --no-cpu-baseline
 bench c3 --config c3 --no-cpu-baseline
 bench c4 --config c4 --no-cpu-baseline --steps 5 --warmup 2
+bench c4_sink --config c4 --feat-source sink --feat-dtype bf16 --no-cpu-baseline --steps 5 --warmup 2
+bench pnr --config pnr --no-cpu-baseline --no-native-line
+bench c2_t30 --frames 30 --no-cpu-baseline --no-native-line
+bench c2_t60 --frames 60 --no-cpu-baseline --no-native-line
+bench c2_t150 --frames 150 --no-cpu-baseline --no-native-line
+bench c2_t150_bf16 --frames 150 --dtype bf16 --no-cpu-baseline
+bench c3_t60 --config c3 --frames 60 --no-cpu-baseline
 bench c5hoi --config c5hoi --no-cpu-baseline --steps 5 --warmup 2
 bench c5hoi_enc --config c5hoi --encoder-only --no-cpu-baseline --steps 5 --warmup 2
 bench c5hhi --config c5hhi --no-cpu-baseline --steps 5 --warmup 2
@@ -35,6 +42,9 @@ bench f32s_deterministic --deterministic --no-cpu-baseline --no-roofline --no-na
 bench f32s_forcedist --force-dist --no-cpu-baseline --no-roofline --no-native-line
 bench c4_forcedist --config c4 --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_forcedist --config c5hoi --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_graph --config c5hoi --graph --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_graph_forcedist --config c5hoi --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c4_graph_forcedist --config c4 --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 fi
 if [[ $STAGES == *prof* ]]; then
 prof c2 f32s
@@ -44,11 +54,14 @@ prof c3 c3
 prof c4 c4 --steps 5 --warmup 2
 prof c5hoi c5hoi --steps 5 --warmup 2
 prof c5hhi c5hhi --steps 5 --warmup 2
+prof c2 c2_t150 --frames 150
+prof pnr pnr
 fi
 if [[ $STAGES == *trace* ]]; then      # one step's kernels in launch order (eager launches)
 for c in c2 c3 c4 c5hoi c5hhi; do
   python3 tools/step_trace.py $c -- --config $c > /dev/null 2>&1 && cp gpurun_out/steptrace_$c.txt $OUT/${R}_steptrace_$c.txt
 done
+python3 tools/step_trace.py c2_t150 -- --config c2 --frames 150 > /dev/null 2>&1 && cp gpurun_out/steptrace_c2_t150.txt $OUT/${R}_steptrace_c2_t150.txt
 fi
 if [[ $STAGES == *pmc* ]]; then
 python3 tools/pmc_collect.py f32s > $OUT/pmc_f32s.txt 2>&1 && cp gpurun_out/pmc_f32s.json $OUT/${R}_pmc_c2_f32s.json
@@ -56,6 +69,7 @@ python3 tools/pmc_collect.py bf16 -- --dtype bf16 > $OUT/pmc_bf16.txt 2>&1 && cp
 python3 tools/pmc_collect.py c3 -- --config c3 > $OUT/pmc_c3.txt 2>&1 && cp gpurun_out/pmc_c3.json $OUT/${R}_pmc_c3_bf16.json
 python3 tools/pmc_collect.py c4 -- --config c4 > $OUT/pmc_c4.txt 2>&1 && cp gpurun_out/pmc_c4.json $OUT/${R}_pmc_c4_bf16.json
 python3 tools/pmc_collect.py c5hoi -- --config c5hoi > $OUT/pmc_c5hoi.txt 2>&1 && cp gpurun_out/pmc_c5hoi.json $OUT/${R}_pmc_c5hoi_bf16.json
+python3 tools/pmc_collect.py c2_t150 -- --frames 150 > $OUT/pmc_c2_t150.txt 2>&1 && cp gpurun_out/pmc_c2_t150.json $OUT/${R}_pmc_c2_t150_f32s.json
 python tools/gemm_bench.py 20 > $OUT/${R}_gemm_bench.txt 2>&1
 tail -n 4 $OUT/pmc_*.txt
 fi

@@ -93,7 +93,7 @@ def main():
             o["traffic_bytes"] = o["read_bytes"] + o["write_bytes"]
         kernels[name] = o
     res = {"csrc_sha": bench.csrc_sha(),
-           "workload": {"config": a.config, "batch": a.batch, "frames": a.frames, "layers": a.layers, "dtype": a.dtype,
+           "workload": {"config": a.config, "batch": bench.resolve_batch(a), "frames": a.frames, "layers": a.layers, "dtype": a.dtype,
                         "encoder_only": bool(a.encoder_only), "bench_args": bench_args},
            "steps_profiled": steps + warmup + 1,      # + the eager step bench.py runs to count the library's launches
            "correction": "read_bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950 half count); write_bytes = WRITE_SIZE KiB x 1024; all values per launch",
