@@ -139,13 +139,18 @@ def time_cpu_baseline(B=256, T=15, n_tasks=3, dim=128, n_heads=4, num_layers=1, 
         crit(m(*feats), y).backward()
 
     sweep = {}
-    per_count = budget_s * 0.6 / len(counts)
     try:
+        # sweep: one warm-up + up to 5 steps per thread count (<= 3 s each); then the protocol run (3 warm-up + up to 20 steps) at the
+        # best count. (At all 128 logical CPUs of the GPU host a step takes seconds: a full protocol per count would eat the budget.)
         for c in counts:
             torch.set_num_threads(c)
-            steps = one_thread_steps if c == 1 else max_steps
-            med, n, dt = _time_steps(step, steps, per_count, warmup=1 if c == 1 else 3)
+            med, n, dt = _time_steps(step, one_thread_steps if c == 1 else 5, 3.0, warmup=1)
             sweep[c] = {"value": B / med, "ms_per_step": med * 1e3, "steps": n, "seconds": dt}
+        best = max(sweep, key=lambda c: sweep[c]["value"])
+        if best != 1:
+            torch.set_num_threads(best)
+            med, n, dt = _time_steps(step, max_steps, budget_s * 0.3, warmup=3)
+            sweep[best] = {"value": B / med, "ms_per_step": med * 1e3, "steps": n, "seconds": dt}
         best = max(sweep, key=lambda c: sweep[c]["value"])
         torch.set_num_threads(best)
         desc = (f"stock torch.nn translator, B={B}, T={T}, K={n_tasks}, d={dim}, L={num_layers}, dropout={dropout} (+0.1 PE), fp32")
