@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 12
+EGX_ABI_VERSION = 13
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED = 0, 1, 2, 3, 4
@@ -89,7 +89,7 @@ SIGNATURES = {
     "egx_wide_gemm_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "egx_wide_gemm": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "egx_wide_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
-    "egx_wide_attention_bwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_wide_attention_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
     "egx_encoder_fwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,
                                   _fp, _fp, _fp, C.c_int, C.c_uint64, _fp]),
     "egx_encoder_bwd": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), _fp, _fp, C.POINTER(Layer), C.c_int,

@@ -286,7 +286,7 @@ static bool use_wide(const egx_config* cfg, const egx_segment* segs, const Plan&
     *err = false;
     const bool ok = wide_ok(cfg, segs, pl.B);
     if (cfg->impl == EGX_IMPL_WIDE) {
-        if (!ok) { set_error("wide implementation does not support this configuration (needs compute = bf16, d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128)"); *err = true; }
+        if (!ok) { set_error("wide implementation does not support this configuration (needs compute = bf16, d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128 with head dim 32 / 64 / 96 / 128 or S <= 480 with head dim 32 / 64)"); *err = true; }
         return ok;
     }
     return cfg->impl == EGX_IMPL_AUTO && ok && !fused_ok(cfg, segs, pl);
@@ -405,20 +405,20 @@ int egx_wide_gemm(int layout, const void* A, const void* B, float* Cf, void* Cb,
     g.lda = M; g.ldb = N;
     return wide_gemm_tn(g, (char*)scratch + 1024, st);
 }
-static int wide_attn_hook(const void* qkv, void* out, float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
+static int wide_attn_hook(const void* qkv, void* out, float* lse, const void* d_out, void* d_qkv, float* delta, int B, int S, int H, int d,
                           float p_drop, uint64_t seed, void* stream, bool bwd) {
     WideAttnParams a;
-    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.lse = lse; a.d_out = (const bf16_t*)d_out; a.d_qkv = (bf16_t*)d_qkv;
+    a.qkv = (const bf16_t*)qkv; a.out = (bf16_t*)out; a.lse = lse; a.d_out = (const bf16_t*)d_out; a.d_qkv = (bf16_t*)d_qkv; a.delta = delta;
     a.B = B; a.S = S; a.H = H; a.d = d;
     if (p_drop > 0.f) { a.drop_key = site_key(seed, 0, SITE_ATTN); a.drop_thresh = drop_threshold(p_drop); a.drop_inv = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f; }
     return bwd ? wide_attn_bwd(a, (hipStream_t)stream) : wide_attn_fwd(a, (hipStream_t)stream);
 }
 int egx_wide_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int d, float p_drop, uint64_t seed, void* stream) {
-    return wide_attn_hook(qkv, out, lse, nullptr, nullptr, B, S, H, d, p_drop, seed, stream, false);
+    return wide_attn_hook(qkv, out, lse, nullptr, nullptr, nullptr, B, S, H, d, p_drop, seed, stream, false);
 }
-int egx_wide_attention_bwd(const void* qkv, const float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
-                           float p_drop, uint64_t seed, void* stream) {
-    return wide_attn_hook(qkv, nullptr, const_cast<float*>(lse), d_out, d_qkv, B, S, H, d, p_drop, seed, stream, true);
+int egx_wide_attention_bwd(const void* qkv, const void* out, const float* lse, const void* d_out, void* d_qkv, float* delta, int B, int S,
+                           int H, int d, float p_drop, uint64_t seed, void* stream) {
+    return wide_attn_hook(qkv, const_cast<void*>(out), const_cast<float*>(lse), d_out, d_qkv, delta, B, S, H, d, p_drop, seed, stream, true);
 }
 
 int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B, size_t* saved_bytes, size_t* scratch_bytes) {

@@ -99,8 +99,10 @@ struct WideAttnParams {
     const bf16_t* d_out = nullptr; bf16_t* d_qkv = nullptr;
     int B = 0, S = 0, H = 0, d = 0;
     uint64_t drop_key = 0; uint32_t drop_thresh = 0; float drop_inv = 1.f;
+    float* delta = nullptr;       // S > 128 backward: (B, H, S) scratch, delta = rowsum(dO . O); `out` must then hold the forward's output
 };
-bool wide_attn_supported(int S, int dh);
+bool wide_attn_supported(int S, int dh);      // S <= 128: head dim 32 / 64 / 96 / 128; 128 < S <= ~480: head dim 32 / 64 (wide_attn_long_*)
+size_t wide_attn_delta_bytes(int B, int H, int S);
 int wide_attn_fwd(const WideAttnParams& p, hipStream_t st);
 int wide_attn_bwd(const WideAttnParams& p, hipStream_t st);
 

@@ -28,7 +28,7 @@ struct WPlan {
     WLayer layer[64];
     size_t saved_bytes;
     // scratch
-    size_t gA, gB, dres, dy16, dhid16, dattn16, dqkv16, dseg16, slabs, slab_all, slab_all_bytes, lnpart, cspart, scratch_bytes;
+    size_t gA, gB, dres, dy16, dhid16, dattn16, dqkv16, adelta, dseg16, slabs, slab_all, slab_all_bytes, lnpart, cspart, scratch_bytes;
 };
 
 size_t take(size_t& cur, size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
@@ -84,6 +84,7 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
     pl.dhid16 = take(sc, N * dff * 2);
     pl.dattn16 = take(sc, N * d * 2);
     pl.dqkv16 = take(sc, N * 3 * d * 2);
+    pl.adelta = take(sc, wide_attn_delta_bytes(B, pl.H, S));
     size_t segrows = 0;
     for (int i = 0; i < pl.nseg; ++i) segrows = smax(segrows, (size_t)B * segs[i].T);
     pl.dseg16 = take(sc, segrows * d * 2);
@@ -371,6 +372,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
         {
             WideAttnParams a;
             a.qkv = cat<bf16_t>(saved, o.qkv); a.lse = const_cast<float*>(cat<float>(saved, o.lse));
+            a.out = const_cast<bf16_t*>(cat<bf16_t>(saved, o.attn)); a.delta = at<float>(scratch, pl.adelta);
             a.d_out = dattn16; a.d_qkv = dqkv16; a.B = B; a.S = S; a.H = pl.H; a.d = d;
             Drop da = mkdrop(training, cfg->p_drop, seed, (uint32_t)l, SITE_ATTN);
             a.drop_key = da.key; a.drop_thresh = da.thresh; a.drop_inv = da.inv;

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 12
+#define EGX_ABI_VERSION 13
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -277,12 +277,14 @@ int egx_attention_bwd(const float* qkv, const float* out, const float* lse, cons
 size_t egx_wide_gemm_scratch(int layout, int M, int N, int K);
 int egx_wide_gemm(int layout, const void* A, const void* B, float* Cf, void* Cb, int M, int N, int K, const float* bias,
                   int relu, const float* residual, void* scratch, void* stream);
-/* qkv: (B*S, 3d) packed bf16 in-projection rows; out: (B*S, d) bf16; lse: (B, H, S) fp32. S <= 128, head dim 32/64/96/128.
- * Backward: d_out (B*S, d) bf16 -> d_qkv (B*S, 3d) bf16 (probabilities recomputed from lse; every element written once). */
+/* qkv: (B*S, 3d) packed bf16 in-projection rows; out: (B*S, d) bf16; lse: (B, H, S) fp32. S <= 128 with head dim 32/64/96/128,
+ * or 128 < S <= 480 with head dim 32/64 (the EgoT2-g encoders on sequences of up to 3 x 150 tokens: online softmax).
+ * Backward: d_out (B*S, d) bf16 -> d_qkv (B*S, 3d) bf16 (probabilities recomputed from lse; every element written once).
+ * S > 128 also reads `out` (the forward's output) and uses `delta` ((B, H, S) fp32 scratch); both may be NULL for S <= 128. */
 int egx_wide_attention_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int d, float p_drop, uint64_t seed,
                            void* stream);
-int egx_wide_attention_bwd(const void* qkv, const float* lse, const void* d_out, void* d_qkv, int B, int S, int H, int d,
-                           float p_drop, uint64_t seed, void* stream);
+int egx_wide_attention_bwd(const void* qkv, const void* out, const float* lse, const void* d_out, void* d_qkv, float* delta,
+                           int B, int S, int H, int d, float p_drop, uint64_t seed, void* stream);
 
 /* Fused FFN weight gradients (d_model = 128): dW1 += dH^T x1, db1 += colsum(dH), dW2 += g^T H where
  * H = dropout(relu(x1 W1^T + b1)) and dH = (g W2) .* mask are recomputed on chip. x1, g: (N, 128); S = tokens per

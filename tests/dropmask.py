@@ -78,7 +78,7 @@ def keep_scale(key: int, rows: np.ndarray, cols: np.ndarray, p: float) -> torch.
     return torch.from_numpy(np.where(v >= np.uint64(thresh), inv_keep(p), 0.0))
 
 
-ATTN_ROW_STRIDE = {"fused": 64, "wide": 128}      # others (generic, tiled): S
+ATTN_ROW_STRIDE = {"fused": 64, "wide": 128}      # others (generic, tiled): S; wide with S > 128: 512
 
 
 def encoder_masks(seed: int, impl: str, B: int, seg_T, d: int, H: int, d_ff: int, L: int, p_drop: float, p_pos: float = 0.0,
@@ -102,7 +102,7 @@ def encoder_masks(seed: int, impl: str, B: int, seg_T, d: int, H: int, d_ff: int
                 continue
             rows = b[:, None] * T + np.arange(T)[None, :]
             masks["feat"].append(keep_scale(site_key(seed, k, SITE_FEAT), rows, cols_d, p_feat))
-    rs = ATTN_ROW_STRIDE.get(impl, S)
+    rs = 512 if (impl == "wide" and S > 128) else ATTN_ROW_STRIDE.get(impl, S)
     ffn_rows = b[:, None] * 64 + s[None, :] if impl == "fused" else tok_rows
     h = np.arange(H, dtype=np.int64)
     attn_rows = (b[:, None, None] * H + h[None, :, None]) * rs + s[None, None, :]   # (B, H, S)

@@ -135,10 +135,12 @@ def _lta_cfg(n, d, heads, layers, p):
 
 
 @pytest.mark.parametrize("impl,compute,n,d,device_seed", [("wide", "bf16", 8, 256, False), ("wide", "bf16", 32, 768, False),
-                                                          ("generic", "f32", 4, 256, False), ("wide", "bf16", 8, 256, True)])
+                                                          ("generic", "f32", 4, 256, False), ("wide", "bf16", 8, 256, True),
+                                                          ("wide", "bf16", 40, 256, False), ("wide", "bf16", 36, 512, True)])
 def test_lta4_train_mode_matches_oracle_under_the_same_masks(egx_lib, cuda, impl, compute, n, d, device_seed):
     """The wide bf16 path (configs[3] flavour: 4 x n tokens, 8 heads, learned positions, identity action segment) and the
-    generic kernels at p = 0.3 on all four encoder-layer sites."""
+    generic kernels at p = 0.3 on all four encoder-layer sites. n = 40 / 36: S = 160 / 144 > 128, the wide path's online-softmax
+    attention kernels (head dim 32 / 64), whose dropout rows are keyed bh * 512 + query."""
     from egot2_amd import hoi_lta
     B, L, p, seed = 3, 2, 0.3, 0x17A4 + n
     m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(n, d, 8, L, p))

@@ -86,18 +86,21 @@ def _attn_ref(qkv, d_out, B, S, H, d):
 
 
 @pytest.mark.parametrize("B,S,H,d", [(3, 128, 8, 768), (2, 45, 4, 256), (5, 48, 8, 512), (2, 17, 4, 128), (1, 1, 2, 256),
-                                     (2, 100, 2, 256), (2, 64, 8, 256), (3, 65, 4, 384)])
+                                     (2, 100, 2, 256), (2, 64, 8, 256), (3, 65, 4, 384),
+                                     (2, 129, 4, 256), (3, 450, 4, 256), (2, 300, 8, 256), (1, 480, 8, 512), (2, 225, 8, 512), (40, 150, 4, 256)])
 def test_wide_attention_fwd_bwd(egx_lib, cuda, B, S, H, d):
     """S^T = K Q^T orientation, softmax, O^T = V^T P^T and both backward passes against fp64 autograd. Covers head dims
-    32 / 64 / 96 / 128, both tile counts (S <= 64 and S <= 128), ragged last tiles and a single token."""
+    32 / 64 / 96 / 128, both tile counts (S <= 64 and S <= 128), ragged last tiles and a single token; S > 128: the online-softmax
+    kernels (head dim 32 / 64, split and unsplit grids)."""
     g = torch.Generator().manual_seed(S * 7 + d)
     qkv = torch.randn(B * S, 3 * d, generator=g).to(cuda).bfloat16()
     d_out = torch.randn(B * S, d, generator=g).to(cuda).bfloat16()
     out = torch.empty(B * S, d, device=cuda, dtype=torch.bfloat16)
     lse = torch.empty(B, H, S, device=cuda)
     dqkv = torch.full((B * S, 3 * d), float("nan"), device=cuda, dtype=torch.bfloat16)
+    delta = torch.empty(B, H, S, device=cuda)
     assert egx_lib.egx_wide_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, S, H, d, 0.0, 0, _stream()) == 0, egx_lib.egx_last_error()
-    assert egx_lib.egx_wide_attention_bwd(_ptr(qkv), _ptr(lse), _ptr(d_out), _ptr(dqkv), B, S, H, d, 0.0, 0, _stream()) == 0, egx_lib.egx_last_error()
+    assert egx_lib.egx_wide_attention_bwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(d_out), _ptr(dqkv), _ptr(delta), B, S, H, d, 0.0, 0, _stream()) == 0, egx_lib.egx_last_error()
     ro, rl, rg = _attn_ref(qkv, d_out, B, S, H, d)
     assert (lse.double() - rl).abs().max().item() < 2e-3 * max(1.0, rl.abs().max().item())
     assert (out.double() - ro).abs().max().item() < 1.5e-2 * ro.abs().max().item()       # P and O rounded to bf16
@@ -106,11 +109,13 @@ def test_wide_attention_fwd_bwd(egx_lib, cuda, B, S, H, d):
     assert err < 1.5e-2, err
 
 
-def test_wide_attention_dropout_is_consistent(egx_lib, cuda):
+@pytest.mark.parametrize("S", [64, 200])
+def test_wide_attention_dropout_is_consistent(egx_lib, cuda, S):
     """p > 0: the backward regenerates the forward's mask. Checked by linearity: d/d(eps) out(v + eps * dv) == out_dv exactly
     matches the backward's dV contraction when the same mask is used (V enters linearly), and the keep rate is 1 - p."""
-    B, S, H, d, p = 2, 64, 4, 256, 0.25
+    B, H, d, p = 2, 4, 256, 0.25
     g = torch.Generator().manual_seed(11)
+    delta = torch.empty(B, H, S, device=cuda)
     qkv = torch.randn(B * S, 3 * d, generator=g).to(cuda).bfloat16()
     out = torch.empty(B * S, d, device=cuda, dtype=torch.bfloat16)
     lse = torch.empty(B, H, S, device=cuda)
@@ -124,7 +129,7 @@ def test_wide_attention_dropout_is_consistent(egx_lib, cuda):
     # backward with dO := 1 and V := 1: dV[k] = sum_q P_drop[q, k]; summed over keys it equals sum_q rowsum[q] exactly-ish
     d_out = torch.ones(B * S, d, device=cuda, dtype=torch.bfloat16)
     dqkv = torch.empty(B * S, 3 * d, device=cuda, dtype=torch.bfloat16)
-    egx_lib.egx_wide_attention_bwd(_ptr(q1), _ptr(lse), _ptr(d_out), _ptr(dqkv), B, S, H, d, p, 1234, _stream())
+    egx_lib.egx_wide_attention_bwd(_ptr(q1), _ptr(out), _ptr(lse), _ptr(d_out), _ptr(dqkv), _ptr(delta), B, S, H, d, p, 1234, _stream())
     dv = dqkv.float()[:, 2 * d::d // H].view(B, S, H)
     rs = rowsum.view(B, S, H)
     assert torch.allclose(dv.sum(1), rs.sum(1), rtol=2e-2, atol=2e-2)
@@ -184,23 +189,28 @@ def test_wide_path_is_selected_and_generic_agrees(egx_lib, cuda):
     cfg.compute = 0
     assert egx_lib.egx_encoder_impl(C.byref(cfg), segs, 4) == _lib.EGX_IMPL_GENERIC       # fp32 stays on the exact kernels
     cfg.compute, cfg.impl = 1, _lib.EGX_IMPL_WIDE
-    segs[0].T = 200                                                                       # S = 200 > 128
+    segs[0].T = 200                                                                       # 128 < S <= 480: the online-softmax kernels
+    assert egx_lib.egx_encoder_impl(C.byref(cfg), segs, 4) == _lib.EGX_IMPL_WIDE
+    segs[0].T = 600
     assert egx_lib.egx_encoder_impl(C.byref(cfg), segs, 4) == -1 and b"wide" in egx_lib.egx_last_error()
 
-    res = {}
-    for impl in ("wide", "generic"):
-        m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(4, 256, 8, 2))
-        m.load_state_dict(seeded_state_dict(m, 5))
-        m = m.to(cuda).set_compute("bf16", impl).train()
-        feats = [f.to(cuda) for f in seeded_feats(6, [(3, 4, 8192), (3, 4, 8192), (3, 4, 256), (3, 4, 2048)])]
-        o = m.forward_features(*feats)
-        (o[0].sum() + (o[1] * o[1]).sum()).backward()
-        res[impl] = (torch.cat([t.detach().flatten() for t in o]), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-    ow, og = res["wide"][0], res["generic"][0]
-    assert (ow - og).abs().max().item() < 2e-2 * max(1.0, og.abs().max().item())
-    for k, gg in res["generic"][1].items():
-        gw = res["wide"][1][k]
-        assert (gw - gg).norm().item() <= 8e-2 * gg.norm().item() + 1e-6, k
+    from egot2_amd import functional as F_egx
+    for n in (4, 40):                                   # S = 16 and S = 160 (online-softmax attention)
+        res = {}
+        for impl in ("wide", "generic"):
+            m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(n, 256, 8, 2))
+            m.load_state_dict(seeded_state_dict(m, 5))
+            m = m.to(cuda).set_compute("bf16", impl).train()
+            feats = [f.to(cuda) for f in seeded_feats(6, [(3, n, 8192), (3, n, 8192), (3, n, 256), (3, n, 2048)])]
+            o = m.forward_features(*feats)
+            assert F_egx.last_encoder_impl() == impl
+            (o[0].sum() + (o[1] * o[1]).sum()).backward()
+            res[impl] = (torch.cat([t.detach().flatten() for t in o]), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        ow, og = res["wide"][0], res["generic"][0]
+        assert (ow - og).abs().max().item() < 2e-2 * max(1.0, og.abs().max().item())
+        for k, gg in res["generic"][1].items():
+            gw = res["wide"][1][k]
+            assert (gw - gg).norm().item() <= 8e-2 * gg.norm().item() + 1e-6, (n, k)
 
 
 def test_wide_path_feeds_gradients_into_identity_segments(egx_lib, cuda):
