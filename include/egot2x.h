@@ -335,7 +335,7 @@ int egx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * FFN reuse egx_linear_* / egx_layernorm_*; the entry points below are the decoder-specific pieces.
  *
  * Attention of a few queries against a short key set, one (batch element, head) per wave: rows are tokens (row index
- * b * S + s, row stride ld* floats), head h owns columns [h * dh, (h + 1) * dh). Sq <= 8, Sk <= 64, dh <= 128.
+ * b * S + s, row stride ld* floats), head h owns columns [h * dh, (h + 1) * dh). Sq <= 8, Sk <= 1024 (one wave per (b, h) up to 64 keys, four waves and chunked K / V beyond), dh <= 128.
  * causal != 0 (needs Sq == Sk) applies the reference's lower-triangular target mask. Self-attention passes the packed
  * qkv rows three times (q, q + d, q + 2d with ld = 3d), cross-attention q and the packed kv rows of the memory.
  * p_drop > 0: dropout on the probabilities, keyed by (seed, site); the backward regenerates the same mask and

@@ -40,7 +40,8 @@ def test_self_attention_small_matches_torch(egx_lib, cuda, B, sy, H, dh):
     assert (x.grad.cpu().double() - r.grad).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize("B,sy,S,H,dh", [(4, 2, 45, 4, 64), (6, 4, 12, 8, 64), (30, 2, 3, 4, 64), (2, 1, 64, 8, 32), (3, 8, 48, 4, 128)])
+@pytest.mark.parametrize("B,sy,S,H,dh", [(4, 2, 45, 4, 64), (6, 4, 12, 8, 64), (30, 2, 3, 4, 64), (2, 1, 64, 8, 32), (3, 8, 48, 4, 128),
+                                         (3, 2, 65, 4, 64), (5, 2, 450, 4, 64), (2, 8, 180, 8, 32), (2, 5, 1000, 2, 128), (9, 3, 128, 4, 64)])
 def test_cross_attention_small_matches_torch(egx_lib, cuda, B, sy, S, H, dh):
     from egot2_amd import functional as F_egx
     d = H * dh
@@ -60,11 +61,12 @@ def test_cross_attention_small_matches_torch(egx_lib, cuda, B, sy, S, H, dh):
     assert (kvd.grad.cpu().double() - kvr.grad).abs().max().item() < 1e-5
 
 
-def test_attention_dropout_masks_match_between_forward_and_backward(egx_lib, cuda):
+@pytest.mark.parametrize("S", [20, 200])
+def test_attention_dropout_masks_match_between_forward_and_backward(egx_lib, cuda, S):
     """With a fixed (seed, site) the output is a deterministic, piecewise-smooth function of q: central differences must
     reproduce the analytic gradient, which they only do if the backward regenerates the forward's mask."""
     from egot2_amd import functional as F_egx
-    B, sy, S, H, dh = 3, 2, 20, 4, 32
+    B, sy, H, dh = 3, 2, 4, 32
     d = H * dh
     g = torch.Generator().manual_seed(5)
     q = torch.randn(B * sy, d, generator=g).to(cuda)
@@ -147,6 +149,45 @@ def test_decoder_trains_with_dropout(egx_lib, cuda):
     with torch.no_grad():
         a, b = m.decode(y, mem), m.decode(y, mem)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("task,T", [("ttm", 60), ("ttm", 150), ("asd", 50)])
+def test_egot2g_hhi_long_sequences_encode_and_decode_match_the_oracle(egx_lib, cuda, task, T):
+    """EgoT2-g HHI on real-length TTM / ASD inputs (3 x T tokens of memory, up to 450): the encoder runs the wide path's
+    online-softmax attention (S > 128), the decoder's cross-attention the chunked long-memory kernel (S > 64; the fused decoder
+    stops at 64 memory tokens). bf16 model against the fp64 oracle: memory, vocabulary logits and parameter gradients."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import functional as F_egx, hhi_multitask
+    from oracle import translator_ref as tr
+    from tests.util import seeded_feats, seeded_state_dict
+    vocab = {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+    args = NS(hidden_dim=256, num_heads=4, num_layers=2, dropout=0.0, lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None)
+    m = hhi_multitask.TaskTranslationPromptTransformer(args, vocab)
+    sd = seeded_state_dict(m, 14)
+    m.load_state_dict(sd)
+    m.pos_embed.dropout.p = 0.0          # (the reference's PositionalEncoding keeps its default p = 0.1 whatever --dropout says)
+    m = m.to(cuda).set_compute("bf16").train()
+    B = 3
+    feats = seeded_feats(15 + T, [(B, T, 256)] * 3)
+    mem = m.encode_features(task, *[f.to(cuda) for f in feats])
+    assert F_egx.last_encoder_impl() == "wide"
+    nb = mem.shape[1]
+    y = torch.stack([torch.full((nb,), vocab[task]), torch.randint(5, 7, (nb,), generator=torch.Generator().manual_seed(T))], dim=1)
+    logits = m.decode(y.to(cuda), mem)
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    lin(logits).backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    rmem = tr.hhi_g_encode(sd64, 4, task, *[f.double() for f in feats])
+    rlog = tr.g_decode(sd64, 4, y, rmem)
+    lin(rlog).backward()
+    assert (mem.detach().cpu().double() - rmem.detach()).abs().max().item() < 4e-2 * max(1.0, rmem.detach().abs().max().item())
+    assert (logits.detach().cpu().double() - rlog.detach()).abs().max().item() < 4e-2 * max(1.0, rlog.detach().abs().max().item())
+    named = dict(m.named_parameters())
+    errs = {k: ((named[k].grad.cpu().double() - v.grad).norm() / (v.grad.norm() + 1e-12)).item() for k, v in sd64.items()
+            if v.grad is not None and k in named and v.grad.norm() > 0}
+    bad = {k: e for k, e in errs.items() if not e < 8e-2}
+    assert len(errs) > 20 and not bad, bad
 
 
 def test_fused_decoder_under_graph_capture_matches_eager(egx_lib, cuda):
