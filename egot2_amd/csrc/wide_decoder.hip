@@ -1,7 +1,7 @@
 // The EgoT2-g sequence decoder + vocabulary head as ONE call per direction:
 // decode() of HHI/models/multitask/task_prompt_model.py:260-269 and HOI/models/multitask/video_model_builder.py:150-159 —
 // `embedding(y) * sqrt(d)` + positional encoding -> nn.TransformerDecoder of CustomDecoderLayer (post-LN: causal
-// self-attention over the 2..8 target tokens, cross-attention onto the S <= 64 memory tokens of the clip, ReLU FFN) -> `fc`.
+// self-attention over the 2..8 target tokens, cross-attention onto the S <= 1024 memory tokens of the clip, ReLU FFN) -> `fc`.
 //
 // Round 2 composed it from ~40 autograd functions per layer (60 small fp32 GEMMs, 75 zero-fills and 41 copies per step:
 // launch-bound, 60 % of the EgoT2-g step). Here the whole stack is orchestrated in C++ like the wide encoder
@@ -9,7 +9,7 @@
 // residual, column sums), LayerNorms through the row kernels with bf16 side outputs, the two tiny attentions through a
 // register-resident kernel (one wave per (clip, head)), every gradient accumulates into ONE caller-provided flat buffer
 // that the first memset zeroes, and the split-K slabs of all weight gradients are summed by one launch at the end.
-// Supported: compute = bf16, d_model a multiple of 128 in [256, 1024], head dim 32 or 64, sy <= 8, S <= 64; anything else
+// Supported: compute = bf16, d_model a multiple of 128 in [256, 1024], head dim 32 or 64, sy <= 8, S <= 1024 (one wave per (clip, head) up to 64 memory tokens, a chunked four-wave kernel beyond); anything else
 // stays on the composed path (egot2_amd/decoder.py).
 #include <string.h>
 #include <mutex>
@@ -219,9 +219,166 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnParams p) {
     }
 }
 
+// Cross-attention onto a memory of more than 64 tokens (EgoT2-g HHI on real-length TTM / ASD sequences: up to 3 x 150): one
+// workgroup of four waves per (clip, head); K and V stream through ONE 64-row LDS buffer (fp32, padded rows) chunk by chunk,
+// all Sq x Sk probabilities stay in LDS. bf16 operands and gradients; same dropout keying as dec_attn_kernel.
+constexpr int DAL_MAXK = 1024;
+template <int DH, bool BWD>
+__global__ __launch_bounds__(256) void dec_attn_long_kernel(DecAttnParams p) {
+    const uint64_t dkey = p.drop_thresh ? resolve_key(p.drop_key) : 0ull;
+    constexpr int LDK = DH + 1;
+    extern __shared__ float dal_sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int Sq = p.Sq, Sk = p.Sk, SKP = (Sk + 63) & ~63;
+    float* Cs = dal_sm;                     // K or V chunk [64][DH + 1]
+    float* Qs = Cs + 64 * LDK;
+    float* Gs = Qs + DA_MAXQ * DH;
+    float* Ps = Gs + DA_MAXQ * DH;          // [Sq][SKP]
+    float* Ds = Ps + DA_MAXQ * SKP;         // backward only
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(p.k) + (size_t)b * Sk * p.ldk + h * DH;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(p.v) + (size_t)b * Sk * p.ldv + h * DH;
+    auto stage = [&](const bf16_t* src, int ld, int j0) {
+        __syncthreads();
+        for (int i = tid; i < 64 * (DH / 8); i += 256) {
+            const int j = i / (DH / 8), c = (i - j * (DH / 8)) * 8;
+            float t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (j0 + j < Sk) load8<false>(src, (size_t)(j0 + j) * ld + c, t8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Cs[j * LDK + c + e] = t8[e];
+        }
+        __syncthreads();
+    };
+    for (int i = tid; i < Sq * DH; i += 256) {
+        const int r = i / DH, c = i - r * DH;
+        Qs[i] = load1<false>(p.q, ((size_t)b * Sq + r) * p.ldq + h * DH + c);
+        if constexpr (BWD) Gs[i] = bf1(p.d_o[((size_t)b * Sq + r) * p.ldo + h * DH + c]);
+    }
+    for (int j0 = 0; j0 < Sk; j0 += 64) {          // scores: wave w owns queries w, w + 4; lane = key within the chunk
+        stage(kb, p.ldk, j0);
+        for (int i = wave; i < Sq; i += 4) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) sc += Qs[i * DH + c] * Cs[lane * LDK + c];
+            Ps[i * SKP + j0 + lane] = j0 + lane < Sk ? sc * p.scale : -INFINITY;
+        }
+    }
+    __syncthreads();
+    for (int i = wave; i < Sq; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < SKP; j += 64) m = fmaxf(m, Ps[i * SKP + j]);
+        m = wmax64(m);
+        float sum = 0.f;
+        for (int j = lane; j < SKP; j += 64) { const float e = __expf(Ps[i * SKP + j] - m); Ps[i * SKP + j] = e; sum += e; }
+        sum = 1.f / wsum64d(sum);
+        for (int j = lane; j < SKP; j += 64) Ps[i * SKP + j] *= sum;
+    }
+    auto keep = [&](int i, int j) { return p.drop_thresh ? drop_scale(dkey, (uint32_t)(bh * DA_MAXQ + i), (uint32_t)j, p.drop_thresh, p.drop_inv) : 1.f; };
+    constexpr int NE = DA_MAXQ * DH / 256;          // (query, column) accumulators per thread: 1 (DH = 32) or 2 (DH = 64)
+    float acc[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) acc[u] = 0.f;
+    if constexpr (BWD) {
+        for (int j0 = 0; j0 < Sk; j0 += 64) {      // dP = dO V^T
+            stage(vb, p.ldv, j0);
+            for (int i = wave; i < Sq; i += 4) {
+                float dp = 0.f;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) dp += Gs[i * DH + c] * Cs[lane * LDK + c];
+                Ds[i * SKP + j0 + lane] = dp;
+            }
+        }
+        __syncthreads();
+        for (int i = wave; i < Sq; i += 4) {
+            float delta = 0.f;
+            for (int j = lane; j < SKP; j += 64) {
+                const float dp = Ds[i * SKP + j] * keep(i, j);
+                Ds[i * SKP + j] = dp;
+                delta += Ps[i * SKP + j] * dp;
+            }
+            delta = wsum64d(delta);
+            for (int j = lane; j < SKP; j += 64) {
+                const float pr = Ps[i * SKP + j];
+                Ds[i * SKP + j] = pr * (Ds[i * SKP + j] - delta) * p.scale;
+                Ps[i * SKP + j] = pr * keep(i, j);
+            }
+        }
+        bf16_t* dkb = reinterpret_cast<bf16_t*>(p.dk) + (size_t)b * Sk * p.ldk + h * DH;
+        bf16_t* dvb = reinterpret_cast<bf16_t*>(p.dv) + (size_t)b * Sk * p.ldv + h * DH;
+        for (int j0 = 0; j0 < Sk; j0 += 64) {      // dQ += dS K; dK = dS^T Q, dV = P^T dO for the chunk's keys
+            stage(kb, p.ldk, j0);
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = tid + u * 256, i = e / DH, c = e - i * DH;
+                if (i < Sq) {
+                    float a = 0.f;
+                    for (int j = 0; j < 64; ++j) a += Ds[i * SKP + j0 + j] * Cs[j * LDK + c];
+                    acc[u] += a;
+                }
+            }
+            for (int e = tid; e < 64 * (DH / 8); e += 256) {
+                const int j = e / (DH / 8), c = (e - j * (DH / 8)) * 8;
+                if (j0 + j < Sk) {
+                    float ak[8] = {0, 0, 0, 0, 0, 0, 0, 0}, av[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int i = 0; i < Sq; ++i) {
+                        const float dsv = Ds[i * SKP + j0 + j], pv = Ps[i * SKP + j0 + j];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) { ak[x] += dsv * Qs[i * DH + c + x]; av[x] += pv * Gs[i * DH + c + x]; }
+                    }
+                    store8<false>(dkb, (size_t)(j0 + j) * p.ldk + c, ak);
+                    store8<false>(dvb, (size_t)(j0 + j) * p.ldv + c, av);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + u * 256, i = e / DH, c = e - i * DH;
+            if (i < Sq) store1<false>(p.dq, ((size_t)b * Sq + i) * p.ldq + h * DH + c, acc[u]);
+        }
+    } else {
+        if (p.drop_thresh) {
+            for (int i = wave; i < Sq; i += 4)
+                for (int j = lane; j < SKP; j += 64) Ps[i * SKP + j] *= keep(i, j);
+        }
+        for (int j0 = 0; j0 < Sk; j0 += 64) {
+            stage(vb, p.ldv, j0);
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = tid + u * 256, i = e / DH, c = e - i * DH;
+                if (i < Sq) {
+                    float a = 0.f;
+                    for (int j = 0; j < 64; ++j) a += Ps[i * SKP + j0 + j] * Cs[j * LDK + c];
+                    acc[u] += a;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + u * 256, i = e / DH, c = e - i * DH;
+            if (i < Sq) p.o[((size_t)b * Sq + i) * p.ldo + h * DH + c] = f2bf(acc[u]);
+        }
+    }
+}
+template <int DH, bool BWD>
+int dec_attn_long(const DecAttnParams& p, hipStream_t st) {
+    auto lds = [](int Sk) { return ((size_t)64 * (DH + 1) + (size_t)2 * DA_MAXQ * DH + (size_t)2 * DA_MAXQ * ((Sk + 63) & ~63)) * sizeof(float); };
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_attn_long_kernel<DH, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds(DAL_MAXK)));
+        attr = true;
+    }
+    hipLaunchKernelGGL((dec_attn_long_kernel<DH, BWD>), dim3(p.B * p.H), dim3(256), lds(p.Sk), st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool BWD>
 int dec_attn(DecAttnParams p, int dh, bool f32, hipStream_t st) {
     p.scale = 1.f / sqrtf((float)dh);
+    if (p.Sk > DA_MAXK) {
+        EGX_CHECK(!f32 && !p.causal && (dh == 32 || dh == 64), "decoder attention: a memory of %d tokens needs bf16 operands and head dim 32 / 64", p.Sk);
+        return dh == 64 ? dec_attn_long<64, BWD>(p, st) : dec_attn_long<32, BWD>(p, st);
+    }
     const dim3 grid(cdiv(p.B * p.H, 4)), block(256);
     if (dh == 64 && !f32) hipLaunchKernelGGL((dec_attn_kernel<64, BWD, false>), grid, block, 0, st, p);
     else if (dh == 32 && !f32) hipLaunchKernelGGL((dec_attn_kernel<32, BWD, false>), grid, block, 0, st, p);
@@ -341,7 +498,7 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
               "fused decoder: head dim %d (32 or 64)", c->n_heads > 0 ? c->d_model / c->n_heads : 0);
     EGX_CHECK(c->d_ff >= 128 && c->d_ff % 128 == 0, "fused decoder: d_ff = %d (multiples of 128)", c->d_ff);
     EGX_CHECK(c->n_layers >= 1 && c->n_layers <= 16, "fused decoder: %d layers (1..16)", c->n_layers);
-    EGX_CHECK(c->sy >= 1 && c->sy <= DA_MAXQ && c->S >= 1 && c->S <= DA_MAXK, "fused decoder: sy = %d (1..%d), S = %d (1..%d)", c->sy, DA_MAXQ, c->S, DA_MAXK);
+    EGX_CHECK(c->sy >= 1 && c->sy <= DA_MAXQ && c->S >= 1 && c->S <= DAL_MAXK, "fused decoder: sy = %d (1..%d), S = %d (1..%d)", c->sy, DA_MAXQ, c->S, DAL_MAXK);
     EGX_CHECK(c->vocab >= 1 && B >= 1, "fused decoder: vocab = %d, B = %d", c->vocab, B);
     memset(&pl, 0, sizeof(pl));
     pl.B = B; pl.sy = c->sy; pl.S = c->S; pl.d = c->d_model; pl.H = c->n_heads; pl.dff = c->d_ff; pl.L = c->n_layers; pl.V = c->vocab;

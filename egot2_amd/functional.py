@@ -799,7 +799,7 @@ class DecoderFn(torch.autograd.Function):
 def decoder_supported(compute: str, d: int, n_heads: int, d_ff: int, sy: int, S: int, n_layers: int) -> bool:
     """Shapes egx_decoder_fwd / egx_decoder_bwd serve (include/egot2x.h); everything else stays on the composed decoder."""
     return (compute == "bf16" and 256 <= d <= 1024 and d % 128 == 0 and n_heads > 0 and d % n_heads == 0 and d // n_heads in (32, 64)
-            and d_ff >= 128 and d_ff % 128 == 0 and 1 <= sy <= 8 and 1 <= S <= 64 and 1 <= n_layers <= 16)
+            and d_ff >= 128 and d_ff % 128 == 0 and 1 <= sy <= 8 and 1 <= S <= 1024 and 1 <= n_layers <= 16)
 
 
 def weighted_cross_entropy(logits, target, weight=None):

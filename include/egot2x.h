@@ -358,7 +358,7 @@ int egx_embed_pos_bwd(const int64_t* tokens, const float* dy, float* d_emb, floa
  * task_prompt_model.py:163-172). compute = EGX_BF16 only: the B * sy target rows and the B * S memory rows run through the
  * bf16 MFMA GEMMs of the wide path with fused epilogues, the LayerNorms through its row kernels, the two attentions through
  * a register-resident kernel (one wave per (clip, head)). d_model a multiple of 128 in [256, 1024], head dim 32 or 64,
- * sy <= 8 target tokens, S <= 64 memory tokens per clip; other configurations return an error (the caller composes the
+ * sy <= 8 target tokens, S <= 1024 memory tokens per clip; other configurations return an error (the caller composes the
  * decoder from the entry points above instead). Parameters are torch-layout fp32 ([out, in] row-major); `ca_in_w` /
  * `ca_in_b` are the packed in-projection of the cross-attention (rows [0, d): query, rows [d, 3d): key / value). */
 typedef struct egx_dec_config {

@@ -190,6 +190,42 @@ def test_egot2g_hhi_long_sequences_encode_and_decode_match_the_oracle(egx_lib, c
     assert len(errs) > 20 and not bad, bad
 
 
+@pytest.mark.parametrize("S,sy,heads", [(45, 2, 4), (180, 2, 4), (450, 3, 4), (200, 5, 8), (1024, 2, 4)])
+def test_fused_decoder_matches_the_composed_decoder(egx_lib, cuda, S, sy, heads):
+    """egx_decoder_fwd / _bwd (one call per direction, bf16 GEMMs; memories beyond 64 tokens: dec_attn_long_kernel) against the
+    decoder composed from the unit operators (fp32 target-side GEMMs, egx_small_attention_*) at p = 0: logits, d(memory) and
+    every parameter gradient."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import hhi_multitask
+    from tests.util import seeded_state_dict
+    vocab = {'</s>': 0, '<unk>': 1, 'ttm': 2, 'lam': 3, 'asd': 4, '0': 5, '1': 6}
+    args = NS(hidden_dim=256, num_heads=heads, num_layers=2, dropout=0.0, lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None)
+    B = 4
+    g = torch.Generator().manual_seed(S + sy)
+    mem0 = torch.randn(S, B, 256, generator=g)
+    y = torch.randint(0, 7, (B, sy), generator=g).to(cuda)
+    w = torch.randn(sy, B, 7, generator=g).to(cuda)
+    res = {}
+    for mode in ("fused", "composed"):
+        m = hhi_multitask.TaskTranslationPromptTransformer(args, vocab)
+        m.load_state_dict(seeded_state_dict(m, 4))
+        m.pos_embed.dropout.p = 0.0
+        m = m.to(cuda).set_compute("bf16").train()
+        m.egx_composed_decoder = mode == "composed"
+        mem = mem0.to(cuda).requires_grad_(True)
+        out = m.decode(y, mem)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        res[mode] = (out.detach().double(), mem.grad.double(), {k: p.grad.double() for k, p in m.named_parameters() if p.grad is not None})
+    (of, gf, pf), (oc, gc, pc) = res["fused"], res["composed"]
+    assert (of - oc).abs().max().item() < 3e-2 * max(1.0, oc.abs().max().item())
+    assert (gf - gc).norm().item() < 6e-2 * gc.norm().item()          # d(memory) passes through bf16 d(kv) rows on the fused path
+    assert set(pf) == set(pc) and len(pf) > 30
+    bad = {k: ((pf[k] - pc[k]).norm() / (pc[k].norm() + 1e-12)).item() for k in pc if pc[k].norm() > 0}
+    bad = {k: e for k, e in bad.items() if not e < 8e-2}
+    assert not bad, bad
+
+
 def test_fused_decoder_under_graph_capture_matches_eager(egx_lib, cuda):
     """The fused decoder forks its K | V projections and weight gradients onto a library-owned side stream and joins them
     back by events; captured into a hipGraph (what bench.py replays) the side stream becomes a parallel branch. Replays must
