@@ -86,6 +86,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "egx_encoder_uses_fused": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_encoder_impl": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
+    "egx_encoder_slices": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_wide_gemm_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "egx_wide_gemm": (C.c_int, [C.c_int, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, _fp, _fp]),
     "egx_wide_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),

@@ -187,9 +187,44 @@ static size_t fused_xin_offset(const egx_config* cfg, const egx_segment* segs, c
 static size_t fused_qkv_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_xin_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.N * pl.d * 4, 256);
 }
-static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+static size_t fused_core_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_qkv_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.vB * FUSED_TOK_PAD * 3 * pl.d * 4, 256);
 }
+static int fused_slices(const Plan& pl, int compute);
+static size_t sliced_xchg_bytes(const Plan& pl, int n);
+static size_t sliced_flag_bytes(const Plan& pl, int n);
+static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    const int n = (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) ? 1 : fused_slices(pl, cfg->compute);
+    return fused_core_bytes(cfg, segs, pl) + sliced_xchg_bytes(pl, n) + sliced_flag_bytes(pl, n);
+}
+// ---- sliced mode (small batches): n workgroups per clip, each 1 / n of the FFN hidden blocks (FusedFwdParams::n_slices). Only when
+// every workgroup of the launch is resident at once (the slices of a clip wait for each other): round_up(B, 8) * n <= CUs.
+// EGX_FFN_SLICES=1 turns it off, =2 / 4 / 8 caps n.
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+static int fused_slices(const Plan& pl, int compute) {
+    const char* e = getenv("EGX_FFN_SLICES");      // (read per call: the tests compare both modes in one process)
+    // measured at B = 32 (profiles/r04_sliced.txt): the exchange costs ~10 us per kernel; with bf16's short FFN loop eight slices lose to four
+    int cap = e ? atoi(e) : (compute == EGX_BF16 ? 4 : 8);
+    if (cap < 1) cap = 1;
+    const int cus = device_cus(), nit = pl.dff / 128, bq = (pl.B + 7) / 8 * 8;
+    int n = 1;
+    while (n * 2 <= cap && n * 2 <= 8 && nit % (n * 2) == 0 && bq * n * 2 <= cus) n *= 2;
+    return n;
+}
+// behind the fused layout: the forward's exchange buffer (L, B, n, 48, d) and the arrival counters of forward and backward (2, L, B)
+static size_t sliced_xchg_bytes(const Plan& pl, int n) { return n > 1 ? align_up((size_t)pl.L * pl.B * n * FUSED_TOK_PAD * pl.d * 4, 256) : 0; }
+static size_t sliced_flag_bytes(const Plan& pl, int n) { return n > 1 ? align_up((size_t)2 * pl.L * pl.B * 4, 256) : 0; }
+
 // ---- tiled mode (d = 128, 48 < S <= 512): the same kernels over 48-token tiles, attention between the launches. Behind the fused
 // layout of the tile grid: every layer's attention output (L, N, d) and log-sum-exp (L, B, H, S), then room for the output tokens
 // and the pooled vector of a translator call
@@ -228,6 +263,7 @@ struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes, dx0;
+    size_t xchg;                            // sliced mode only
     size_t datt, dres, delta, dtok;         // tiled mode only
     size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
     int P;
@@ -260,6 +296,8 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
         s.datt = take(cur, nd); s.dres = take(cur, nd);
         s.delta = take(cur, (size_t)pl.B * pl.H * pl.S * 4);
         s.dtok = take(cur, nd);
+    } else {
+        s.xchg = take(cur, sliced_xchg_bytes(pl, fused_slices(pl, cfg->compute)));
     }
     s.bytes = cur;
     return s;
@@ -445,6 +483,13 @@ int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B
     return use_fused(cfg, segs, pl, &ferr) ? 1 : 0;
 }
 
+int egx_encoder_slices(const egx_config* cfg, const egx_segment* segs, int B) {
+    Plan pl;
+    if (make_plan(cfg, segs, B, pl)) return -1;
+    bool ferr;
+    return use_fused(cfg, segs, pl, &ferr) ? fused_slices(pl, cfg->compute) : 1;
+}
+
 int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return -1;
@@ -550,6 +595,12 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
         fp.rot_mode = ffn_rot_mode();
+        fp.n_slices = tiled ? 1 : fused_slices(pl, comp);
+        if (fp.n_slices > 1) {
+            fp.xchg = (float*)((char*)saved + fused_core_bytes(cfg, segs, vp));
+            fp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, fp.n_slices));
+            pk.zero_words = fp.xflags; pk.n_zero = pl.L * pl.B;        // the packing launch (always in front) zeroes the arrival counters
+        }
         if (pack_weights(pk, st)) return 1;
         if (!tiled) return fused_forward(fp, comp, st);
         // tiled mode: token preparation + Q | K | V of layer 0, then per layer [attention of every clip] [out-projection .. LayerNorm2
@@ -744,6 +795,12 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             const int stage = cfg->bwd_stage;
             EGX_CHECK(stage >= 0 && stage <= 2, "bwd_stage=%d", stage);
             if (stage == 2) bp.zero_buf = nullptr;
+            bp.n_slices = tiled ? 1 : fused_slices(pl, comp);
+            if (bp.n_slices > 1 && stage != 2) {
+                bp.xchg = fptr(scratch, SC.xchg);
+                bp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, bp.n_slices)) + (size_t)pl.L * pl.B;
+                EGX_HIP(hipMemsetAsync(bp.xflags, 0, (size_t)pl.L * pl.B * 4, st));
+            }
             if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
             if (stage != 2 && tiled) {
                 // L + 1 launches of the tile kernel with the attention backward of every clip between them

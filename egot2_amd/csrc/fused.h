@@ -74,6 +74,13 @@ struct FusedFwdParams {
     size_t Ntok;            // real tokens B_clips * S_clip: the layer stride of the dense saved arrays
     int mode, l0;           // FUSED_MODE_*; POST: the layer whose attention output `attn_in` holds
     const float* attn_in;   // (L, Ntok, 128) attention outputs (before the out-projection), written by tiled_attn_fwd
+    // ---- sliced mode (small batches: B * n_slices <= CUs): n_slices workgroups per clip. Each runs the whole clip (identical
+    // arithmetic, identical stores) except the FFN, of which it walks 1 / n_slices of the hidden blocks; the partial FFN outputs
+    // are exchanged through `xchg` behind a per-(layer, clip) arrival counter in `xflags` (zeroed before the launch) and summed by
+    // every slice in slice order. See slice_exchange() in fused_dev.h for the residency requirement.
+    int n_slices;           // 1 = one workgroup per clip
+    float* xchg;            // (L, B, n_slices, 48, 128) fp32
+    unsigned* xflags;       // (L, B)
 };
 enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2 };
 
@@ -88,6 +95,7 @@ struct PackParams {
     PackDesc d[PACK_MAX];
     int n, mode;                // CM_F32 / CM_BF16 / CM_SPLIT (fused_dev.h): element format of the packed fragments
     uint64_t* seed_advance;     // optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed)
+    unsigned* zero_words; int n_zero;   // optional: words to zero (the arrival counters of the sliced mode)
 };
 int pack_weights(PackParams& pp, hipStream_t st);
 static inline size_t packed_bytes(int R, int K, int mode) { return (size_t)R * K * (mode == 1 ? 2 : mode == 2 ? 6 : 4); }
@@ -183,6 +191,7 @@ struct FusedBwdParams {
     int tiled, l_front, l_back;     // l_front < 0: the launch starts from d_tokens; l_back < 0: it ends with the token preparation
     float* datt;                    // (Ntok, 128) gradient w.r.t. the attention output of layer l_back (written) 
     float* dres;                    // (Ntok, 128) gradient reaching the layer input through the residual (written for l_back, read for l_front)
+    int n_slices; float* xchg; unsigned* xflags;     // sliced mode (see FusedFwdParams): the partial FFN input gradients are exchanged
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 

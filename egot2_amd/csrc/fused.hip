@@ -28,6 +28,8 @@ __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
     int blk = blockIdx.x;
     if (pp.seed_advance && blk == 0 && threadIdx.x == 0)      // same LCG as seed_advance_kernel
         *pp.seed_advance = *pp.seed_advance * 6364136223846793005ull + 1442695040888963407ull;
+    if (pp.zero_words)
+        for (int i = blk * 64 + threadIdx.x; i < pp.n_zero; i += gridDim.x * 64) pp.zero_words[i] = 0u;
     int di = 0;
     while (di + 1 < pp.n && blk >= pp.d[di + 1].first_block) ++di;
     const PackDesc& d = pp.d[di];
@@ -120,7 +122,15 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int clip = blockIdx.x;            // TILED: the tile ("virtual clip"): index of every 48-row grid
+    int clip_ = blockIdx.x, slice_ = 0;     // TILED: the tile ("virtual clip"): index of every 48-row grid
+    if constexpr (!TILED) {
+        if (p.n_slices > 1) {
+            slice_map(p.n_slices, clip_, slice_);
+            if (clip_ >= p.B) return;
+        }
+    }
+    const int clip = clip_, slice = slice_;
+    const int n_slices = TILED ? 1 : p.n_slices;
     int S, c_real, t0;                      // tokens of this workgroup, the clip they belong to, their first token within it
     size_t tokbase;                         // global index of the first token: row of the dense (Ntok, .) arrays, dropout row key
     if constexpr (TILED) {
@@ -673,7 +683,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             WRaw<CM> w1r[2][FD / 32];   // W1 rows of the current hidden block
             WRaw<CM> w2r[8];            // W2 columns of the current hidden block
             float4 b1r[2];
-            const int nit = nhb / 4;
+            const int nit = nhb / 4 / n_slices;           // sliced mode: blocks [slice * nit, (slice + 1) * nit) of every wave's walk
+            const int j0 = slice * nit;
             // Every CU walks the same weights. All in step (rot_mode 1) they hammer the same few L2 lines at once (+2.5 % step
             // time); every clip at its own starting block (rot_mode 0, round 2) the XCD's instantaneous working set is the whole
             // 3-7.5 MB of packed weights and the 4 MB L2 thrashes (+150 MB of re-fetches per step). Default (rot_mode 4): the
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                           : p.rot_mode == 3 ? (int)(((unsigned)(clip >> 3) & 1u) * (unsigned)nit / 2u)
                           : p.rot_mode == 4 ? (int)(((unsigned)(clip >> 3) & 3u) % (unsigned)nit)
                           : p.rot_mode == 5 ? (int)(((unsigned)(clip >> 3) & 7u) % (unsigned)nit) : 0;
-            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * (j0 + j); };
             // the dropout keep-scale 1 / (1 - p) is folded into the packed W1 (encoder.hip) and, here, into b1:
             // relu(s (W1 x + b1)) = s relu(W1 x + b1) for s > 0, so the epilogue has no multiply
             const float bscale = w.ffn_thresh ? w.drop_inv : 1.f;
@@ -837,14 +848,23 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         // ---- sum partials + bias + residual -> res2 (in X1), then LayerNorm2 -> next layer input / tokens_out
         {
             const int row = tid >> 2, c0 = (tid & 3) * 32;
+            if (n_slices > 1)       // sliced mode: the sum over the waves AND the slices of the clip comes back in Xs
+                slice_allreduce(Xs, Part, Part + SP * LDX, Part + 2 * SP * LDX, LDX, S, p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD),
+                                slice, n_slices, p.xflags + (size_t)l * p.B + clip);
             if (row < S) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     int o = row * LDX + c0 + 4 * j;
-                    float4 a0 = *reinterpret_cast<const float4*>(Xs + o);
-                    float4 a1 = *reinterpret_cast<const float4*>(Part + o);
-                    float4 a2 = *reinterpret_cast<const float4*>(Part + SP * LDX + o);
-                    float4 a3 = *reinterpret_cast<const float4*>(Part + 2 * SP * LDX + o);
+                    float4 a0, a1, a2, a3;
+                    if (n_slices > 1) {
+                        a0 = *reinterpret_cast<const float4*>(Xs + o);
+                        a1 = make_float4(0, 0, 0, 0); a2 = a1; a3 = a1;
+                    } else {
+                        a0 = *reinterpret_cast<const float4*>(Xs + o);
+                        a1 = *reinterpret_cast<const float4*>(Part + o);
+                        a2 = *reinterpret_cast<const float4*>(Part + SP * LDX + o);
+                        a3 = *reinterpret_cast<const float4*>(Part + 2 * SP * LDX + o);
+                    }
                     float4 x1 = *reinterpret_cast<const float4*>(X1 + o);
                     float4 b2 = *reinterpret_cast<const float4*>(w.lin2_b + c0 + 4 * j);
                     float f[4] = {a0.x + a1.x + a2.x + a3.x + b2.x, a0.y + a1.y + a2.y + a3.y + b2.y,
@@ -966,7 +986,8 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_FWD, st);
-    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
+    const int grid = (!TILED && p.n_slices > 1) ? (p.B + 7) / 8 * 8 * p.n_slices : p.B;
+    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED, DH>), dim3(grid), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_FWD, st);
     EGX_LAUNCH_CHECK();
     return 0;

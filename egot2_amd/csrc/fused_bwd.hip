@@ -1101,7 +1101,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
-    const int clip = blockIdx.x;            // TILED: the tile (index of every 48-row grid)
+    int clip_ = blockIdx.x, slice_ = 0;     // TILED: the tile (index of every 48-row grid)
+    if constexpr (!TILED) {
+        if (p.n_slices > 1) slice_map(p.n_slices, clip_, slice_);      // sliced mode (FusedFwdParams): n workgroups per clip
+    }
+    const int clip = clip_, slice = slice_;
+    const int n_slices = TILED ? 1 : p.n_slices;
     int S, c_real, t0;
     size_t tok0;                            // global index of the first token (row of the dense arrays, dropout row key)
     if constexpr (TILED) {
@@ -1117,6 +1122,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
         for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
     }
+    if (clip >= p.B) return;        // (sliced mode: the grid is round_up(B, 8) * n_slices)
 
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
@@ -1389,14 +1395,15 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dxa[i][t] = f32x4{0, 0, 0, 0};
             const int nhb = p.d_ff / 32;
-            const int nit = nhb / 4;
+            const int nit = nhb / 4 / n_slices;           // sliced mode: blocks [slice * nit, (slice + 1) * nit) of every wave's walk
+            const int j0 = slice * nit;
             const int wave_s = __builtin_amdgcn_readfirstlane(wave);
             const int rot = p.rot_mode == 0 ? (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit)
                           : p.rot_mode == 2 ? (int)(((unsigned)(clip >> 3) & 3u) * (unsigned)nit / 4u)
                           : p.rot_mode == 3 ? (int)(((unsigned)(clip >> 3) & 1u) * (unsigned)nit / 2u)
                           : p.rot_mode == 4 ? (int)(((unsigned)(clip >> 3) & 3u) % (unsigned)nit)
                           : p.rot_mode == 5 ? (int)(((unsigned)(clip >> 3) & 7u) % (unsigned)nit) : 0;
-            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * j; };
+            auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return wave_s + 4 * (j0 + j); };
             WRaw<CM> w2r[2][FD / 32], w3r[8];
             uint32_t relu_word;
             const uint32_t* relu_bits = p.relu_bits + ((size_t)l * p.B + clip) * (size_t)(p.d_ff / 32) * 64 + lane;
@@ -1509,6 +1516,19 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         // (f32x4 values, not float4 structs: a struct copy is an llvm.memcpy global -> private -> LDS that pins qv[] in scratch memory)
         const f32x4* qsrc = reinterpret_cast<const f32x4*>(p.saved_qkv + ((size_t)l * p.B + clip) * SP * (3 * FD));   // (L, B, 48, 384)
         f32x4 qv[QKV_PF];
+        if (n_slices > 1) {
+            // sliced mode: the sum over the waves and over the slices of the clip comes back in Gs (B2, B3, B4 cleared): identical
+            // results in every slice
+            __syncthreads();
+            slice_allreduce(Gs, B2, B3, B4, LDX, S, p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD), slice, n_slices,
+                            p.xflags + (size_t)l * p.B + clip);
+            for (int e = tid; e < S * (FD / 4); e += 256) {
+                const int o = (e >> 5) * LDX + (e & 31) * 4;
+                *reinterpret_cast<float4*>(B2 + o) = make_float4(0, 0, 0, 0);
+                *reinterpret_cast<float4*>(B3 + o) = make_float4(0, 0, 0, 0);
+                *reinterpret_cast<float4*>(B4 + o) = make_float4(0, 0, 0, 0);
+            }
+        }
         // P5: LayerNorm1 backward with dy = dX1 (four wave partials in Gs, B2, B3, B4) + d_res2 (B1); x = res1 (B5, from P3).
         __syncthreads();
         ln_bwd_rows(S, w.norm1_w, p.eps,
@@ -1912,7 +1932,8 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_BWD, st);
-    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
+    const int grid = (!TILED && p.n_slices > 1) ? (p.B + 7) / 8 * 8 * p.n_slices : p.B;
+    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED, DH>), dim3(grid), dim3(256), lds, st, p);
     timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;

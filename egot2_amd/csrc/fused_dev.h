@@ -561,4 +561,70 @@ __device__ __forceinline__ Frag<CM> gather_frag(const float* buf, int c, int k0,
     return make_frag<CM>(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
 }
 
+// ---- sliced mode: n workgroups share one clip and meet at the end of the FFN loop -----------------------------------------------
+// blockIdx -> (clip, slice): the slices of a clip get block ids with the same residue mod 8 (under round-robin dispatch: one XCD, so
+// that the clip's features and saved rows are fetched into one L2; nothing depends on it — the linear mapping measured the same).
+// Grid = round_up(B, 8) * n; workgroups whose clip is >= B leave at once.
+__device__ __forceinline__ void slice_map(int n, int& clip, int& slice) {
+    const int b = blockIdx.x, x = b & 7, m = b >> 3;
+    slice = m % n;
+    clip = (m / n) * 8 + x;
+}
+// Arrival barrier of the n slices of a clip: `flag` counts arrivals (zeroed before the launch). ALL n workgroups must be resident
+// at the same time — the host only slices when round_up(B, 8) * n <= number of CUs (encoder.hip: fused_slices) — otherwise the
+// spin never ends; a bounded spin (a few seconds) turns that into a trap (the queue aborts with a hardware exception) instead of
+// a hung GPU. Other work on the device only delays the arrival; two sliced launches racing for the same CUs (two processes
+// training on one GPU) are the one case that can starve each other: run those with EGX_FFN_SLICES=1.
+// No fences: an agent-scope release / acquire pair on gfx950 is a write-back plus an invalidate of the XCD's whole L2 (the eight
+// L2s are not coherent with each other), which throws away the packed weights every clip of the XCD streams from it. The
+// exchanged values instead travel as agent-scope relaxed atomics (xchg_store / xchg_load: write-through / coherent reads of just
+// those words), ordered by the s_waitcnt before the barrier in front of the counter update.
+// (one word per lane, consecutive lanes = consecutive words: these accesses are not merged into wider ones)
+__device__ __forceinline__ void xchg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xchg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void slice_exchange(unsigned* flag, unsigned n) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's xchg_store()s have been written through
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) __builtin_trap();
+        }
+    }
+    __syncthreads();
+}
+// The exchange of one (48, 128) fp32 block held as four per-wave partial blocks in LDS (row stride ld): the sum over the waves goes
+// to this slice's block of `xc`, and behind the arrival barrier the sum over all n slices (in slice order: identical in every
+// slice) comes back into p0.
+__device__ __forceinline__ void slice_allreduce(float* p0, const float* p1, const float* p2, const float* p3, int ld, int S, float* xc, int slice, int n,
+                                                unsigned* flag) {
+    constexpr int BLK = 48 * 128;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < S * 128; e += 256) {
+        const int o = (e >> 7) * ld + (e & 127);
+        xchg_store(xc + (size_t)slice * BLK + e, (p0[o] + p1[o]) + (p2[o] + p3[o]));
+    }
+    slice_exchange(flag, (unsigned)n);
+    // one slice's block per round, its 24 words per thread in flight together (rows >= S: never written, read and dropped)
+    constexpr int PER = BLK / 256;
+    float acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+    for (int s = 0; s < n; ++s) {
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = xchg_load(xc + (size_t)s * BLK + tid + 256 * i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int e = tid + 256 * i;
+        if (e < S * 128) p0[(e >> 7) * ld + (e & 127)] = acc[i];
+    }
+    __syncthreads();
+}
+
 }  // namespace egx

@@ -182,10 +182,16 @@ int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B
 /* Which kernels this configuration runs on: EGX_IMPL_FUSED (per-clip kernels: d = 128, h = 4, S <= 48), EGX_IMPL_TILED (the same
  * kernels over 48-token tiles with the attention of the whole clip between the launches: d = 128, h = 4, 48 < S <= 512, compute bf16
  * or f32s - the reference's real TTM / ASD batches of 15 .. 150 frames per task, HHI/dataset/ttm/data_loader_2task.py:119,150-162), EGX_IMPL_WIDE
- * (compute = bf16 with d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128, head dim 32 / 64 / 96 / 128: all B*S tokens
+ * (compute = bf16 with d_model >= 256, d_model / d_ff / projected d_in multiples of 128, S <= 128 with head dim 32 / 64 / 96 / 128 or S <= 512 with head dim 32 / 64: all B*S tokens
  * through bf16-storage MFMA GEMMs and MFMA attention - BASELINE.json configs[3], configs[4]) or EGX_IMPL_GENERIC; -1 on an
  * invalid configuration. */
 int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B);
+/* Workgroups per clip of the per-clip kernels (EGX_IMPL_FUSED) for this batch on the current device: 1, or 2 / 4 / 8 for small
+ * batches (round_up(B, 8) * n <= compute units; the reference's own TTM batches are ~26 clips, HHI/dataset/ttm/sampler.py:41, and
+ * strong scaling leaves 32 clips per GPU): every workgroup of a clip runs the clip except the FFN, of which it walks 1 / n of the
+ * hidden blocks; the partial sums are exchanged behind an arrival counter, which needs all workgroups of the launch resident at
+ * once (they are, one per compute unit). EGX_FFN_SLICES=1 in the environment turns it off, =2 / 4 / 8 caps n. -1: invalid configuration. */
+int egx_encoder_slices(const egx_config* cfg, const egx_segment* segs, int B);
 
 /* tokens_out: (B, S, d). `saved` is written in forward and read in backward.
  * training != 0 applies dropout with masks derived from (seed, site, element). */

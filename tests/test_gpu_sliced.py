@@ -1,0 +1,119 @@
+"""-m gpu: sliced mode of the per-clip kernels (small batches: the reference's own TTM batches are B * T ~ 400 frames, i.e. ~26
+clips of 15 frames, HHI/dataset/ttm/sampler.py:41; strong scaling leaves 32 clips per GPU). n workgroups share a clip, each walks
+1 / n of the FFN hidden blocks, the partial sums are exchanged behind an arrival counter. Compared with the one-workgroup-per-clip
+launch of the same library (EGX_FFN_SLICES=1) and with the fp64 oracle."""
+import os
+
+import pytest
+import torch
+
+from oracle import translator_ref as tr
+from tests import dropmask as dm
+from tests.util import hhi_args, rel_err, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+CE_W = [0.266, 0.734]
+
+
+def _run(cuda, compute, B, T, L, p, slices, seed=0x51CE):
+    from egot2_amd import hhi_ttm
+    old = os.environ.get("EGX_FFN_SLICES")
+    os.environ["EGX_FFN_SLICES"] = str(slices)
+    try:
+        m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=p, num_layers=L))
+        sd = seeded_state_dict(m, 21)
+        m.load_state_dict(sd)
+        m.pos_embed.dropout.p = 0.1 if p > 0 else 0.0
+        m = m.to(cuda).set_compute(compute, "fused").train()
+        m._egx_seed = lambda: seed
+        feats = seeded_feats(22 + B, [(B, T, 256)] * 3)
+        target = torch.arange(B, device=cuda) % 2
+        logits = m.forward_features(*[f.to(cuda) for f in feats])
+        loss = torch.nn.functional.cross_entropy(logits, target, weight=torch.tensor(CE_W, device=cuda))
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().double().cpu(), {k: q.grad.double().cpu() for k, q in m.named_parameters() if q.grad is not None}, sd, feats, target.cpu()
+    finally:
+        if old is None:
+            os.environ.pop("EGX_FFN_SLICES", None)
+        else:
+            os.environ["EGX_FFN_SLICES"] = old
+
+
+@pytest.mark.parametrize("compute", ["f32", "f32s", "bf16"])
+@pytest.mark.parametrize("B,T,L,p", [(26, 15, 1, 0.5), (32, 15, 1, 0.0), (5, 16, 2, 0.5), (100, 11, 1, 0.5), (64, 15, 3, 0.3), (1, 7, 1, 0.5)])
+def test_sliced_launch_equals_the_one_workgroup_per_clip_launch(egx_lib, cuda, compute, B, T, L, p):
+    """Same library, same masks (the dropout keys do not depend on the slicing): the only difference is the order in which the
+    FFN hidden blocks are summed, so fp32-grade modes agree to rounding and bf16 to a few bf16 ulps of the FFN output."""
+    lo, go, *_ = _run(cuda, compute, B, T, L, p, 1)
+    ls, gs, *_ = _run(cuda, compute, B, T, L, p, 8)
+    tol_l, tol_g = (1e-5, 1e-3 if L > 1 else 1e-4) if compute != "bf16" else (2e-2, 5e-2)     # (L = 3: the reordered sums pass through three LayerNorm backward stages)
+    assert (ls - lo).abs().max().item() < tol_l * max(1.0, lo.abs().max().item())
+    assert set(gs) == set(go)
+    bad = {k: rel_err(gs[k], go[k]) for k in go if not rel_err(gs[k], go[k]) < tol_g}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("compute,tol_l,tol_g", [("f32", 1e-3, 1e-2), ("f32s", 1e-3, 1e-2), ("bf16", 2e-2, 1.2e-1)])
+def test_sliced_launch_matches_the_oracle_under_the_same_masks(egx_lib, cuda, compute, tol_l, tol_g):
+    """The reference's batch (26 clips of 15 frames), train mode p = 0.5 / 0.1, eight slices per clip, against the fp64 oracle fed the
+    masks of the counter-based generator."""
+    B, T, L, p, seed = 26, 15, 1, 0.5, 0x51CE
+    logits, grads, sd, feats, target = _run(cuda, compute, B, T, L, p, 8, seed)
+    masks = dm.encoder_masks(seed, "fused", B, [T] * 3, 128, 4, 2048, L, p, 0.1)
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats], masks=masks)
+    torch.nn.functional.cross_entropy(ref, target, weight=torch.tensor(CE_W, dtype=torch.float64)).backward()
+    assert (logits - ref.detach()).abs().max().item() < tol_l * max(1.0, ref.detach().abs().max().item())
+    bad = {k: rel_err(grads[k], v.grad) for k, v in sd64.items() if v.grad is not None and k in grads and not rel_err(grads[k], v.grad) < tol_g}
+    assert not bad, bad
+
+
+def test_slice_count_policy(egx_lib, cuda):
+    """round_up(B, 8) * n <= compute units, n <= 8 (bf16: 4), n divides the d_ff / 128 hidden blocks of a wave; off by environment."""
+    import ctypes as C
+    from egot2_amd import _lib
+    from egot2_amd._lib import Config, Segment
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    segs = (Segment * 3)()
+    for i in range(3):
+        segs[i].T, segs[i].d_in, segs[i].proj_w = 15, 256, 1
+    def n(B, compute, d_ff=2048):
+        cfg = Config(128, 4, d_ff, 1, 3, 1e-5, compute, 0, 0.0, 0.0, 0.0)
+        return egx_lib.egx_encoder_slices(C.byref(cfg), segs, B)
+    f32s = _lib.EGX_F32_SPLIT
+    want = lambda B, cap: max(k for k in (1, 2, 4, 8) if k <= cap and (B + 7) // 8 * 8 * k <= cus)  # noqa: E731
+    for B in (1, 26, 32, 33, 64, 100, 128, 129, 256):
+        assert n(B, f32s) == want(B, 8), B
+        assert n(B, 1) == want(B, 4), B
+    assert n(32, f32s, d_ff=256) == 2            # d_ff = 256: two hidden blocks per wave
+    os.environ["EGX_FFN_SLICES"] = "1"
+    try:
+        assert n(32, f32s) == 1
+    finally:
+        os.environ.pop("EGX_FFN_SLICES")
+
+
+@pytest.mark.parametrize("compute", ["f32s", "bf16"])
+def test_sliced_asd_translator_tokens_out(egx_lib, cuda, compute):
+    """The ASD translator (first-T token slice leaves the kernel, no pooled head) in sliced mode against the unsliced launch."""
+    from egot2_amd import hhi_asd
+    res = {}
+    for slices in (1, 8):
+        os.environ["EGX_FFN_SLICES"] = str(slices)
+        try:
+            m = hhi_asd.TaskFusionMFTransformer3Task(hhi_args(dropout=0.3))
+            m.load_state_dict(seeded_state_dict(m, 5))
+            m = m.to(cuda).set_compute(compute, "fused").train()
+            m._egx_seed = lambda: 77
+            feats = [f.to(cuda) for f in seeded_feats(6, [(20, 15, 256)] * 3)]
+            out = m.forward_features(*feats)
+            out.square().sum().backward()
+            torch.cuda.synchronize()
+            res[slices] = (out.detach().double().cpu(), {k: q.grad.double().cpu() for k, q in m.named_parameters() if q.grad is not None})
+        finally:
+            os.environ.pop("EGX_FFN_SLICES")
+    tol_l, tol_g = (1e-5, 1e-4) if compute != "bf16" else (2e-2, 5e-2)
+    assert (res[8][0] - res[1][0]).abs().max().item() < tol_l * max(1.0, res[1][0].abs().max().item())
+    bad = {k: rel_err(res[8][1][k], v) for k, v in res[1][1].items() if not rel_err(res[8][1][k], v) < tol_g}
+    assert not bad, bad
