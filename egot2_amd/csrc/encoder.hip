@@ -219,6 +219,7 @@ static int fused_slices(const Plan& pl, int compute) {
     const int cus = device_cus(), nit = pl.dff / 128, bq = (pl.B + 7) / 8 * 8;
     int n = 1;
     while (n * 2 <= cap && n * 2 <= 8 && nit % (n * 2) == 0 && bq * n * 2 <= cus) n *= 2;
+    if (compute == EGX_BF16 && n == 2 && !e) n = 1;     // two slices of the short bf16 loop do not pay for the exchange (B = 128: +3 % / -3 %)
     return n;
 }
 // behind the fused layout: the forward's exchange buffer (L, B, n, 48, d) and the arrival counters of forward and backward (2, L, B)

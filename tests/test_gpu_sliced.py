@@ -85,7 +85,7 @@ def test_slice_count_policy(egx_lib, cuda):
     want = lambda B, cap: max(k for k in (1, 2, 4, 8) if k <= cap and (B + 7) // 8 * 8 * k <= cus)  # noqa: E731
     for B in (1, 26, 32, 33, 64, 100, 128, 129, 256):
         assert n(B, f32s) == want(B, 8), B
-        assert n(B, 1) == want(B, 4), B
+        assert n(B, 1) == (want(B, 4) if want(B, 4) >= 4 else 1), B        # bf16: two slices do not pay
     assert n(32, f32s, d_ff=256) == 2            # d_ff = 256: two hidden blocks per wave
     os.environ["EGX_FFN_SLICES"] = "1"
     try:
