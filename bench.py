@@ -494,7 +494,7 @@ def run(args) -> int:
         "config": {"workload": wl["describe"] + ", fwd+bwd" + (" + FusedAdam" if opt else "")
                                + ((" + RCCL grad all-reduce" + (" overlapped with the backward tail" if overlap else
                                                                  " in per-layer buckets overlapped with the backward" if bucketed else "")) if multi else ""),
-                   "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl, "workgroups_per_clip": F_egx.last_encoder_slices(),
                    "launch": "one hipGraph replay per step" if (use_graph and not (bucketed and not args.graph_collectives)) else "eager",
                    "deterministic": bool(args.deterministic)},
         "library_launches_per_step": launches_per_step,

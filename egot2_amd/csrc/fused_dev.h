@@ -572,9 +572,10 @@ __device__ __forceinline__ void slice_map(int n, int& clip, int& slice) {
 }
 // Arrival barrier of the n slices of a clip: `flag` counts arrivals (zeroed before the launch). ALL n workgroups must be resident
 // at the same time — the host only slices when round_up(B, 8) * n <= number of CUs (encoder.hip: fused_slices) — otherwise the
-// spin never ends; a bounded spin (a few seconds) turns that into a trap (the queue aborts with a hardware exception) instead of
-// a hung GPU. Other work on the device only delays the arrival; two sliced launches racing for the same CUs (two processes
-// training on one GPU) are the one case that can starve each other: run those with EGX_FFN_SLICES=1.
+// spin never ends; a bounded spin (about a minute: longer than any collective that may hold compute units meanwhile) turns that
+// into a trap (the queue aborts with a hardware exception) instead of a hung GPU. Other work on the device — an RCCL kernel of the
+// gradient exchange on its side stream — only delays the arrival: it never waits for this kernel. Two sliced launches racing for
+// the same CUs (two processes training on one GPU) are the one case that can starve each other: run those with EGX_FFN_SLICES=1.
 // No fences: an agent-scope release / acquire pair on gfx950 is a write-back plus an invalidate of the XCD's whole L2 (the eight
 // L2s are not coherent with each other), which throws away the packed weights every clip of the XCD streams from it. The
 // exchanged values instead travel as agent-scope relaxed atomics (xchg_store / xchg_load: write-through / coherent reads of just
@@ -590,7 +591,7 @@ __device__ __forceinline__ void slice_exchange(unsigned* flag, unsigned n) {
         unsigned spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) __builtin_trap();
+            if (++spins > (1u << 26)) __builtin_trap();
         }
     }
     __syncthreads();

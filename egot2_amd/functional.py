@@ -62,6 +62,13 @@ class EncoderSpec:
 
 _scratch_cache = {}
 _last_impl = [EGX_IMPL_AUTO]
+_last_slices = [1]
+
+
+def last_encoder_slices() -> int:
+    """Diagnostic: workgroups per clip of the most recent encoder forward (egx_encoder_slices: > 1 = sliced mode of the per-clip
+    kernels on a small batch)."""
+    return _last_slices[0]
 
 
 def last_encoder_impl() -> str:
@@ -299,6 +306,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.spec = spec
         ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_TILED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
         _last_impl[0] = ctx.impl
+        _last_slices[0] = lib.egx_encoder_slices(C.byref(cfg), segs, B) if ctx.impl == EGX_IMPL_FUSED else 1
         ctx.fused_path = ctx.impl == EGX_IMPL_FUSED
         ctx.B = B
         ctx.nseg, ctx.nproj, ctx.nhead = nseg, nproj, nhead
