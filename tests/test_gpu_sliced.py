@@ -117,3 +117,31 @@ def test_sliced_asd_translator_tokens_out(egx_lib, cuda, compute):
     assert (res[8][0] - res[1][0]).abs().max().item() < tol_l * max(1.0, res[1][0].abs().max().item())
     bad = {k: rel_err(res[8][1][k], v) for k, v in res[1][1].items() if not rel_err(res[8][1][k], v) < tol_g}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("compute,B,L", [("f32s", 32, 1), ("bf16", 61, 2)])
+def test_sliced_exchange_is_reproducible_over_many_launches(egx_lib, cuda, compute, B, L):
+    """The exchange between the slices is a hand-rolled barrier (arrival counter + write-through words): a missed ordering would
+    show up as a run-to-run difference. 300 forward + backward launches with pinned masks, every one bit-identical to the first
+    (the sums are taken in slice order in every slice)."""
+    from egot2_amd import hhi_ttm
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5, num_layers=L))
+    m.load_state_dict(seeded_state_dict(m, 3))
+    m = m.to(cuda).set_compute(compute, "fused").train().set_deterministic(True)      # (fixed-order gradient reductions instead of atomics)
+    m._egx_seed = lambda: 4242
+    feats = [f.to(cuda) for f in seeded_feats(9, [(B, 15, 256)] * 3)]
+    target = torch.arange(B, device=cuda) % 2
+    params = [q for q in m.parameters() if q.requires_grad]
+    first = None
+    from egot2_amd import functional as F_egx
+    for it in range(300):
+        for q in params:
+            q.grad = None
+        logits = m.forward_features(*feats)
+        torch.nn.functional.cross_entropy(logits, target).backward()
+        flat = torch.cat([logits.detach().flatten()] + [q.grad.flatten() for q in params if q.grad is not None])
+        if first is None:
+            assert F_egx.last_encoder_slices() > 1
+            first = flat.clone()
+        else:
+            assert torch.equal(flat, first), f"launch {it} differs from launch 0 by {(flat - first).abs().max().item()}"

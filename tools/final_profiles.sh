@@ -43,8 +43,17 @@ bench f32s_forcedist --force-dist --no-cpu-baseline --no-roofline --no-native-li
 bench c4_forcedist --config c4 --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_forcedist --config c5hoi --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_graph --config c5hoi --graph --no-cpu-baseline --no-roofline --steps 5 --warmup 2
-bench c5hoi_graph_forcedist --config c5hoi --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_graph_forcedist --config c5hoi --force-dist --graph --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c4_graph_forcedist --config c4 --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+# small batches (sliced mode of the per-clip kernels): the reference sampler's own batch, and the per-GPU share of a strong-scaled B = 256 on 8 GPUs
+bench c2_b26 --batch 26 --no-cpu-baseline --no-roofline --no-native-line
+bench c2_b32 --batch 32 --no-cpu-baseline --no-roofline --no-native-line
+bench c2_b32_forcedist --batch 32 --force-dist --no-cpu-baseline --no-roofline --no-native-line
+EGX_FFN_SLICES=1 bench c2_b32_unsliced --batch 32 --no-cpu-baseline --no-roofline --no-native-line
+# EgoT2-g HHI on long sequences (wide path with the online-softmax attention, decoder onto a 450-token memory)
+bench c5hhi_t60 --config c5hhi --frames 60 --batch 64 --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hhi_t150 --config c5hhi --frames 150 --batch 25 --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hhi_t150_enc --config c5hhi --frames 150 --batch 25 --encoder-only --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 fi
 if [[ $STAGES == *prof* ]]; then
 prof c2 f32s
