@@ -578,13 +578,16 @@ enum { DS_SELF = 1, DS_SA_OUT = 2, DS_CROSS = 3, DS_CA_OUT = 4, DS_FFN = 5, DS_F
 // backward: the input-gradient chain is ~16 dependent launches per layer that each occupy 16-64 CUs. They run on a library-owned
 // side stream, forked off the caller's stream by an event after the kernel that produces their operand and joined before the
 // slab reduction (works the same under stream capture: the side stream's launches become a parallel branch of the graph).
-// EGX_DEC_SIDE=0 keeps everything on the caller's stream.
+// EGX_DEC_SIDE=0 keeps everything on the caller's stream. Under stream CAPTURE the fork is not taken either (side_wanted()): as
+// branches of a hipGraph the side launches cost more than they hide — measured on one box, C5 HHI step as one graph 2.71 ms with
+// the branches, 2.42 ms without (eager: 2.55 with the side stream, 2.50 without); C5 HOI 4.14 vs 3.88 (eager 3.82 / 3.98).
+// EGX_DEC_SIDE=2 forks under capture as well.
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[8] = {};
     hipEvent_t kv_ev[16] = {};      // forward: layer l's K | V projection of the memory is done
     int next = 0;
-    bool on = false;
+    bool on = false, on_captured = false;
     std::mutex mu;                  // forward and (autograd-thread) backward share the event ring
     // `to` continues behind everything enqueued on `from` so far. Record + wait of one ring event under the lock: two threads
     // picking the same event between the record and the wait would wait for each other's position.
@@ -608,12 +611,19 @@ SideStream& side_stream() {
         SideStream& T = S[dev];
         const char* e = getenv("EGX_DEC_SIDE");
         if (!(e && e[0] == '0') && hipStreamCreateWithFlags(&T.s, hipStreamNonBlocking) == hipSuccess) {
-            T.on = true;
+            T.on = true; T.on_captured = e && e[0] == '2';
             for (auto& v : T.ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) T.on = false;
             for (auto& v : T.kv_ev) if (hipEventCreateWithFlags(&v, hipEventDisableTiming) != hipSuccess) T.on = false;
         }
     });
     return S[dev];
+}
+// does this call fork? (never while `st` is being captured, unless EGX_DEC_SIDE=2)
+bool side_wanted(const SideStream& SS, hipStream_t st) {
+    if (!SS.on || SS.on_captured) return SS.on;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cs == hipStreamCaptureStatusNone;
 }
 // joins the side stream back into the caller's stream when a call leaves — on the error paths too: an un-joined fork
 // would invalidate an active stream capture (and leave work running that the caller's next launch may overwrite)
@@ -708,7 +718,8 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
     // of them go to the side stream now, beside the chain's 16-WG launches; a layer's cross-attention waits for its own
     SideStream& SS = side_stream();
     SideJoin sj(SS, st);        // error paths: join whatever was forked
-    if (SS.on) {
+    const bool side = side_wanted(SS, st);
+    if (side) {
         if (SS.order(st, SS.s)) return 1;
         sj.forked = true;
         for (int l = 0; l < pl.L; ++l) {
@@ -749,7 +760,7 @@ int egx_decoder_fwd(const egx_dec_config* cfg, const int64_t* tokens, const floa
         if (ln(cat<float>(saved, o.res1), w.norm1_w, w.norm1_b, at<float>(saved, o.st1), at<float>(saved, o.x1_32), at<bf16_t>(saved, o.x1_16))) return 1;
         // cross-attention onto the memory
         if (nt(cat<bf16_t>(saved, o.x1_16), d, cat<bf16_t>(saved, o.w_q), Md, d, d, w.ca_in_b, nullptr, at<bf16_t>(saved, o.q), 0, none, nullptr)) return 1;
-        if (SS.on) EGX_HIP(hipStreamWaitEvent(st, SS.kv_ev[l], 0));
+        if (side) EGX_HIP(hipStreamWaitEvent(st, SS.kv_ev[l], 0));
         else if (nt(mem16, d, cat<bf16_t>(saved, o.w_kv), Nm, 2 * d, d, w.ca_in_b + d, nullptr, at<bf16_t>(saved, o.kv), 0, none, nullptr)) return 1;
         {
             DecAttnParams a;
@@ -802,10 +813,11 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
     float* cspart_side = at<float>(scratch, pl.cspart_side);
     // side stream for the weight gradients: fork() orders it behind everything enqueued on `st` so far
     SideStream& SS = side_stream();
-    hipStream_t sd = SS.on ? SS.s : st;
+    const bool side = side_wanted(SS, st);
+    hipStream_t sd = side ? SS.s : st;
     SideJoin sj(SS, st);
     auto fork = [&]() -> int {
-        if (!SS.on) return 0;
+        if (!side) return 0;
         if (SS.order(st, sd)) return 1;
         sj.forked = true;
         return 0;
