@@ -127,9 +127,11 @@ def test_relu_linear_and_layernorm_residual(egx_lib, cuda):
         assert (a.grad.cpu().double() - r.grad).abs().max().item() < 1e-3 * max(1.0, r.grad.abs().max().item())
 
 
-def test_decoder_trains_with_dropout(egx_lib, cuda):
+@pytest.mark.parametrize("S,compute", [(45, "f32"), (45, "bf16"), (180, "bf16"), (180, "f32")])
+def test_decoder_trains_with_dropout(egx_lib, cuda, S, compute):
     """Train-mode decode (dropout on every site): finite, deterministic per seed, and gradients reach every decoder
-    parameter; eval-mode decode is independent of the seed."""
+    parameter; eval-mode decode is independent of the seed. bf16 = the fused decoder (S = 180: its long-memory cross-attention
+    kernel with dropout on the probabilities), f32 = the composed one."""
     from types import SimpleNamespace as NS
     from egot2_amd import hhi_multitask
     from tests.util import seeded_state_dict
@@ -137,11 +139,15 @@ def test_decoder_trains_with_dropout(egx_lib, cuda):
     args = NS(hidden_dim=256, num_heads=4, num_layers=2, dropout=0.3, lam_checkpoint=None, ttm_checkpoint=None, asd_checkpoint=None)
     m = hhi_multitask.TaskTranslationPromptTransformer(args, vocab)
     m.load_state_dict(seeded_state_dict(m, 4))
-    m = m.to(cuda).train()
-    mem = torch.randn(45, 5, 256, device=cuda)
+    m = m.to(cuda).set_compute(compute).train()
+    m._egx_seed = lambda: 99
+    mem = torch.randn(S, 5, 256, device=cuda)
     y = torch.randint(0, 7, (5, 2), device=cuda)
     out = m.decode(y, mem)
     assert out.shape == (2, 5, 7) and torch.isfinite(out).all()
+    assert torch.equal(out, m.decode(y, mem)), "same seed, same masks"
+    m._egx_seed = lambda: 100
+    assert not torch.equal(out, m.decode(y, mem)), "another seed draws other masks"
     out.square().sum().backward()
     missing = [n for n, p in m.named_parameters() if ("transformer_decoder" in n or n.startswith(("fc.", "embedding."))) and p.grad is None]
     assert not missing, missing
