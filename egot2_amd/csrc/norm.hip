@@ -269,26 +269,50 @@ int colsum_accum(const float* x, int rows, int cols, int ld, float* out, hipStre
 }
 
 // ---- learned positional-embedding gradient -----------------------------------------------------
-__global__ void pos_grad_kernel(const float* __restrict__ dtok, int B, int S, int off, int T, int d,
-                                float* __restrict__ dpos, int pos_stride, uint64_t key, uint32_t thresh, float inv_keep) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * d) return;
-    int t = i / d, c = i % d;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        int orow = b * S + off + t;
-        float v = dtok[(size_t)orow * d + c];
-        if (thresh) v *= drop_scale(key, (uint32_t)orow, (uint32_t)c, thresh, inv_keep);
-        s += v;
+// dpos[t][:] += sum_b mask .* dtok[b * S + off + t][:]. One workgroup per position row t: d / 4 float4 columns x (256 / (d / 4)) clip
+// lanes, a lane walks its clips four loads at a time, the lanes are added in lane order through LDS (deterministic). (Until round 4
+// one THREAD walked all B clips of its element with dependent-latency loads: 64 us per segment at B = 256, 12 % of the PNR / OSCC step.)
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dtok, int B, int S, int off, int T, int d,
+                                                       float* __restrict__ dpos, int pos_stride, uint64_t key, uint32_t thresh, float inv_keep) {
+    __shared__ float4 red[256];
+    const int t = blockIdx.x, nc = d >> 2;              // d % 4 == 0, d <= 1024
+    const int c4 = threadIdx.x % nc, lane = threadIdx.x / nc, nl = 256 / nc;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (lane < nl) {
+        auto fetch = [&](int b) {
+            const int orow = b * S + off + t;
+            float4 v = *reinterpret_cast<const float4*>(dtok + (size_t)orow * d + 4 * c4);
+            if (thresh) {
+                v.x *= drop_scale(key, (uint32_t)orow, (uint32_t)(4 * c4), thresh, inv_keep);
+                v.y *= drop_scale(key, (uint32_t)orow, (uint32_t)(4 * c4 + 1), thresh, inv_keep);
+                v.z *= drop_scale(key, (uint32_t)orow, (uint32_t)(4 * c4 + 2), thresh, inv_keep);
+                v.w *= drop_scale(key, (uint32_t)orow, (uint32_t)(4 * c4 + 3), thresh, inv_keep);
+            }
+            return v;
+        };
+        int b = lane;
+        for (; b + 3 * nl < B; b += 4 * nl) {
+            const float4 v0 = fetch(b), v1 = fetch(b + nl), v2 = fetch(b + 2 * nl), v3 = fetch(b + 3 * nl);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; b < B; b += nl) { const float4 v = fetch(b); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     }
-    dpos[(size_t)t * pos_stride + c] += s;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0) {
+        for (int j = 1; j < nl; ++j) { const float4 v = red[j * nc + c4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        float4* o = reinterpret_cast<float4*>(dpos + (size_t)t * pos_stride + 4 * c4);
+        float4 cur = *o;
+        *o = make_float4(cur.x + s.x, cur.y + s.y, cur.z + s.z, cur.w + s.w);
+    }
 }
 
 int pos_grad_accum(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride,
                    uint64_t key, uint32_t thresh, float inv_keep, hipStream_t st) {
-    int n = T * d;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(pos_grad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, dtok, B, S, off, T, d, dpos, pos_stride,
+    if (T <= 0 || d <= 0) return 0;
+    EGX_CHECK(d % 4 == 0 && d <= 1024 && pos_stride % 4 == 0, "pos_grad: d = %d (multiple of 4, <= 1024), pos_stride = %d", d, pos_stride);
+    hipLaunchKernelGGL(pos_grad_kernel, dim3(T), dim3(256), 0, st, dtok, B, S, off, T, d, dpos, pos_stride,
                        key, thresh, inv_keep);
     EGX_LAUNCH_CHECK();
     return 0;
