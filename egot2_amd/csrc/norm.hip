@@ -405,8 +405,14 @@ __global__ __launch_bounds__(256) void pool_head_fwd_kernel(const float* __restr
         }
     } else {
         for (int c = threadIdx.x; c < d; c += 256) {
-            float s = 0.f;
-            for (int t = 0; t < S; ++t) s += tk[(size_t)t * d + c];
+            // four rows in flight per thread (one dependent load per token took 93 us per launch at C4's S = 128, d = 768)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int t = 0;
+            for (; t + 3 < S; t += 4) {
+                s0 += tk[(size_t)t * d + c]; s1 += tk[(size_t)(t + 1) * d + c]; s2 += tk[(size_t)(t + 2) * d + c]; s3 += tk[(size_t)(t + 3) * d + c];
+            }
+            for (; t < S; ++t) s0 += tk[(size_t)t * d + c];
+            float s = (s0 + s1) + (s2 + s3);
             s *= inv_s;
             y[c] = s;
             pooled[(size_t)b * d + c] = s;
