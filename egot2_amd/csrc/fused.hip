@@ -103,8 +103,11 @@ int debug_read_stamps(unsigned long long* out, int n) {
 // FUSED_MODE_PRE = token preparation + Q | K | V of layer 0; FUSED_MODE_POST = out-projection .. LayerNorm2 of layer l0 on the
 // attention output tiled_attn_fwd left in `attn_in`, then Q | K | V of layer l0 + 1 (or the output tokens). The full-clip
 // instantiation (TILED = false) compiles to the code it was before the tiled mode existed.
-template <int CM, int NT, bool TILED, int DH>
+// SLICED: the small-batch instantiation (n workgroups per clip, FusedFwdParams::n_slices > 1). A template parameter, not a run-time
+// test: with the slice code compiled into the one-workgroup-per-clip kernels their B = 256 step was 1 % (f32s) / 2.5 % (bf16) slower.
+template <int CM, int NT, bool TILED, int DH, bool SLICED = false>
 __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
+    static_assert(!(TILED && SLICED), "the tiled launches are not sliced");
     constexpr int HPW = FDH / DH;               // heads per wave: 1 (4 heads of 32) or 2 (8 heads of 16)
     constexpr int NHEAD = FH * HPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -123,14 +126,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
     int clip_ = blockIdx.x, slice_ = 0;     // TILED: the tile ("virtual clip"): index of every 48-row grid
-    if constexpr (!TILED) {
-        if (p.n_slices > 1) {
-            slice_map(p.n_slices, clip_, slice_);
-            if (clip_ >= p.B) return;
-        }
+    if constexpr (SLICED) {
+        slice_map(p.n_slices, clip_, slice_);
+        if (clip_ >= p.B) return;
     }
     const int clip = clip_, slice = slice_;
-    const int n_slices = TILED ? 1 : p.n_slices;
+    const int n_slices = SLICED ? p.n_slices : 1;
     int S, c_real, t0;                      // tokens of this workgroup, the clip they belong to, their first token within it
     size_t tokbase;                         // global index of the first token: row of the dense (Ntok, .) arrays, dropout row key
     if constexpr (TILED) {
@@ -983,11 +984,19 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, TILED, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if constexpr (!TILED)
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, false, DH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_FWD, st);
-    const int grid = (!TILED && p.n_slices > 1) ? (p.B + 7) / 8 * 8 * p.n_slices : p.B;
-    hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED, DH>), dim3(grid), dim3(256), lds, st, p);
+    bool sliced = false;
+    if constexpr (!TILED) sliced = p.n_slices > 1;
+    if (sliced) {
+        if constexpr (!TILED)
+            hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, false, DH, true>), dim3((p.B + 7) / 8 * 8 * p.n_slices), dim3(256), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
+    }
     timing_end(TIMER_FUSED_FWD, st);
     EGX_LAUNCH_CHECK();
     return 0;

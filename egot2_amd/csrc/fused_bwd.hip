@@ -1084,8 +1084,9 @@ int debug_read_bstamps(unsigned long long* out, int n) {
 // TILED (48 < S <= 512, see FusedBwdParams): the workgroup is one 48-token tile and the kernel is cut at the attention backward
 // (tiled_attn_bwd): a launch runs [P11 - P12 of layer l_front on the dQ | dK | dV rows that kernel left] + [P1 - P7 of layer
 // l_back, leaving d(attention output) and the residual gradient in HBM], or ends with the token-preparation backward.
-template <int CM, bool TILED, int DH>
+template <int CM, bool TILED, int DH, bool SLICED = false>      // SLICED: see fused_fwd_kernel
 __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
+    static_assert(!(TILED && SLICED), "the tiled launches are not sliced");
     constexpr int HPW = FDH / DH, NHEAD = FH * HPW, NCT = DH / 16;      // heads per wave, heads, 16-channel tiles per head
     constexpr int NT = 3;
     constexpr int SP = NT * 16;
@@ -1102,11 +1103,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
     int clip_ = blockIdx.x, slice_ = 0;     // TILED: the tile (index of every 48-row grid)
-    if constexpr (!TILED) {
-        if (p.n_slices > 1) slice_map(p.n_slices, clip_, slice_);      // sliced mode (FusedFwdParams): n workgroups per clip
-    }
+    if constexpr (SLICED) slice_map(p.n_slices, clip_, slice_);      // sliced mode (FusedFwdParams): n workgroups per clip
     const int clip = clip_, slice = slice_;
-    const int n_slices = TILED ? 1 : p.n_slices;
+    const int n_slices = SLICED ? p.n_slices : 1;
     int S, c_real, t0;
     size_t tok0;                            // global index of the first token (row of the dense arrays, dropout row key)
     if constexpr (TILED) {
@@ -1122,7 +1121,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
         for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
     }
-    if (clip >= p.B) return;        // (sliced mode: the grid is round_up(B, 8) * n_slices)
+    if constexpr (SLICED) { if (clip >= p.B) return; }        // (the grid is round_up(B, 8) * n_slices)
 
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
@@ -1929,11 +1928,20 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
     if (!attr_set) {
         EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, TILED, DH>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if constexpr (!TILED)
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, false, DH, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     timing_begin(TIMER_FUSED_BWD, st);
-    const int grid = (!TILED && p.n_slices > 1) ? (p.B + 7) / 8 * 8 * p.n_slices : p.B;
-    hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED, DH>), dim3(grid), dim3(256), lds, st, p);
+    bool sliced = false;
+    if constexpr (!TILED) sliced = p.n_slices > 1;
+    if (sliced) {
+        if constexpr (!TILED)
+            hipLaunchKernelGGL((fused_bwd_kernel<CM, false, DH, true>), dim3((p.B + 7) / 8 * 8 * p.n_slices), dim3(256), lds, st, p);
+    } else {
+        hipLaunchKernelGGL((fused_bwd_kernel<CM, TILED, DH>), dim3(p.B), dim3(256), lds, st, p);
+    }
     timing_end(TIMER_FUSED_BWD, st);
     EGX_LAUNCH_CHECK();
     return 0;
