@@ -198,7 +198,8 @@ static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, 
     return fused_core_bytes(cfg, segs, pl) + sliced_xchg_bytes(pl, n) + sliced_flag_bytes(pl, n);
 }
 // ---- sliced mode (small batches): n workgroups per clip, each 1 / n of the FFN hidden blocks (FusedFwdParams::n_slices). Only when
-// every workgroup of the launch is resident at once (the slices of a clip wait for each other): round_up(B, 8) * n <= CUs.
+// the workgroups of the launch can all be resident at once: round_up(B, 8) * n <= CUs (a performance rule, not a protocol: a slice
+// whose partial sum does not arrive within 100 us is computed by the waiting workgroup itself, fused_dev.h).
 // EGX_FFN_SLICES=1 turns it off, =2 / 4 / 8 caps n.
 static int device_cus() {
     static int cus[64] = {0};
@@ -211,6 +212,13 @@ static int device_cus() {
     }
     return cus[dev];
 }
+// EGX_SLICE_DROP=<hex mask> (testing aid): the workgroups of those slices leave at once; the others must compute their share
+static int slice_drop_mask(int n) {
+    const char* e = getenv("EGX_SLICE_DROP");
+    if (!e) return 0;
+    const int m = (int)strtol(e, nullptr, 16) & ((1 << n) - 1);
+    return m == (1 << n) - 1 ? 0 : m;      // at least one slice has to run
+}
 static int fused_slices(const Plan& pl, int compute) {
     const char* e = getenv("EGX_FFN_SLICES");      // (read per call: the tests compare both modes in one process)
     // measured at B = 32 (profiles/r04_sliced.txt): the exchange costs ~10 us per kernel; with bf16's short FFN loop eight slices lose to four
@@ -222,9 +230,10 @@ static int fused_slices(const Plan& pl, int compute) {
     if (compute == EGX_BF16 && n == 2 && !e) n = 1;     // two slices of the short bf16 loop do not pay for the exchange (B = 128: +3 % / -3 %)
     return n;
 }
-// behind the fused layout: the forward's exchange buffer (L, B, n, 48, d) and the arrival counters of forward and backward (2, L, B)
+// behind the fused layout: the forward's exchange buffer (L, B, n, 48, d) and the "published" words of forward and backward (2, L, B, 8)
 static size_t sliced_xchg_bytes(const Plan& pl, int n) { return n > 1 ? align_up((size_t)pl.L * pl.B * n * FUSED_TOK_PAD * pl.d * 4, 256) : 0; }
-static size_t sliced_flag_bytes(const Plan& pl, int n) { return n > 1 ? align_up((size_t)2 * pl.L * pl.B * 4, 256) : 0; }
+static size_t sliced_flag_words(const Plan& pl) { return (size_t)pl.L * pl.B * 8; }       // one "published" word per (layer, clip, slice): SLICE_MAX = 8
+static size_t sliced_flag_bytes(const Plan& pl, int n) { return n > 1 ? align_up(2 * sliced_flag_words(pl) * 4, 256) : 0; }
 
 // ---- tiled mode (d = 128, 48 < S <= 512): the same kernels over 48-token tiles, attention between the launches. Behind the fused
 // layout of the tile grid: every layer's attention output (L, N, d) and log-sum-exp (L, B, H, S), then room for the output tokens
@@ -600,7 +609,8 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         if (fp.n_slices > 1) {
             fp.xchg = (float*)((char*)saved + fused_core_bytes(cfg, segs, vp));
             fp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, fp.n_slices));
-            pk.zero_words = fp.xflags; pk.n_zero = pl.L * pl.B;        // the packing launch (always in front) zeroes the arrival counters
+            pk.zero_words = fp.xflags; pk.n_zero = (int)sliced_flag_words(pl);        // the packing launch (always in front) zeroes the flags
+            fp.slice_drop = slice_drop_mask(fp.n_slices);
         }
         if (pack_weights(pk, st)) return 1;
         if (!tiled) return fused_forward(fp, comp, st);
@@ -799,8 +809,9 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.n_slices = tiled ? 1 : fused_slices(pl, comp);
             if (bp.n_slices > 1 && stage != 2) {
                 bp.xchg = fptr(scratch, SC.xchg);
-                bp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, bp.n_slices)) + (size_t)pl.L * pl.B;
-                EGX_HIP(hipMemsetAsync(bp.xflags, 0, (size_t)pl.L * pl.B * 4, st));
+                bp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, bp.n_slices)) + sliced_flag_words(pl);
+                EGX_HIP(hipMemsetAsync(bp.xflags, 0, sliced_flag_words(pl) * 4, st));
+                bp.slice_drop = slice_drop_mask(bp.n_slices);
             }
             if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
             if (stage != 2 && tiled) {

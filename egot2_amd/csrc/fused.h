@@ -80,7 +80,8 @@ struct FusedFwdParams {
     // every slice in slice order. See slice_exchange() in fused_dev.h for the residency requirement.
     int n_slices;           // 1 = one workgroup per clip
     float* xchg;            // (L, B, n_slices, 48, 128) fp32
-    unsigned* xflags;       // (L, B)
+    unsigned* xflags;       // (L, B, 8) "published" words
+    int slice_drop;         // testing aid (EGX_SLICE_DROP): bit s set = the workgroups of slice s leave at once, as if they never became resident
 };
 enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2 };
 
@@ -191,7 +192,7 @@ struct FusedBwdParams {
     int tiled, l_front, l_back;     // l_front < 0: the launch starts from d_tokens; l_back < 0: it ends with the token preparation
     float* datt;                    // (Ntok, 128) gradient w.r.t. the attention output of layer l_back (written) 
     float* dres;                    // (Ntok, 128) gradient reaching the layer input through the residual (written for l_back, read for l_front)
-    int n_slices; float* xchg; unsigned* xflags;     // sliced mode (see FusedFwdParams): the partial FFN input gradients are exchanged
+    int n_slices; float* xchg; unsigned* xflags; int slice_drop;     // sliced mode (see FusedFwdParams): the partial FFN input gradients are exchanged
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 

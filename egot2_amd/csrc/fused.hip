@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     int clip_ = blockIdx.x, slice_ = 0;     // TILED: the tile ("virtual clip"): index of every 48-row grid
     if constexpr (SLICED) {
         slice_map(p.n_slices, clip_, slice_);
-        if (clip_ >= p.B) return;
+        if (clip_ >= p.B || ((p.slice_drop >> slice_) & 1)) return;
     }
     const int clip = clip_, slice = slice_;
     const int n_slices = SLICED ? p.n_slices : 1;
@@ -654,6 +654,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
         STAMP(6);
         EGX_PHASE();
+        // SLICED: this pass walks the hidden blocks of slice `sl_cur` — its own first; afterwards any whose partial sum does not
+        // arrive in time is computed here too (slice_wait): the launch does not depend on its workgroups being resident together
+        int sl_cur = slice, sl_k = 0;
+        for (;;) {
         // ---- FFN: hidden blocks of 32 split across waves; H^T = relu(W1 x1^T + b1) chained into Y^T += W2 H^T
         {
             // x1 as B operand: resident in registers for bf16 (48 VGPRs); re-read from LDS per hidden block in fp32,
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             WRaw<CM> w2r[8];            // W2 columns of the current hidden block
             float4 b1r[2];
             const int nit = nhb / 4 / n_slices;           // sliced mode: blocks [slice * nit, (slice + 1) * nit) of every wave's walk
-            const int j0 = slice * nit;
+            const int j0 = sl_cur * nit;
             // Every CU walks the same weights. All in step (rot_mode 1) they hammer the same few L2 lines at once (+2.5 % step
             // time); every clip at its own starting block (rot_mode 0, round 2) the XCD's instantaneous working set is the whole
             // 3-7.5 MB of packed weights and the 4 MB L2 thrashes (+150 MB of re-fetches per step). Default (rot_mode 4): the
@@ -845,13 +849,42 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         make_float4(y[i][t][0], y[i][t][1], y[i][t][2], y[i][t][3]);
         }
         __syncthreads();
+        if constexpr (!SLICED) {
+            break;
+        } else {
+            float* xc = p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD);
+            unsigned* fl = p.xflags + ((size_t)l * p.B + clip) * SLICE_MAX;
+            slice_publish(Xs, Part, Part + SP * LDX, Part + 2 * SP * LDX, LDX, S, xc + (size_t)sl_cur * (FUSED_TOK_PAD * FD), fl + sl_cur);
+            bool steal = false;
+            while (++sl_k < n_slices) {
+                const int s2 = slice + sl_k < n_slices ? slice + sl_k : slice + sl_k - n_slices;
+                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; break; }
+            }
+            if (!steal) {       // the sum over the waves AND the slices of the clip comes back in Xs
+                slice_gather(xc, n_slices, Xs, LDX, S);
+                break;
+            }
+            if constexpr (CM == CM_SPLIT) {     // the partial blocks overwrote the operand planes of x1: split it again
+                const int row = tid >> 2, c0 = (tid & 3) * 32;
+                if (row < S) {
+                    float xv[32];
+                    uint32_t h[16], m[16], lo[16];
+                    load32(X1 + row * LDX + c0, xv);
+                    split32(xv, h, m, lo);
+                    store_parts32(XP + row * LDXH + c0, (size_t)XPS, h, m, lo);
+                }
+                for (int i = tid; i < 3 * (SP - S) * (LDXH / 4); i += 256) {
+                    int pl = i / ((SP - S) * (LDXH / 4)), rem = i - pl * ((SP - S) * (LDXH / 4));
+                    *reinterpret_cast<uint2*>(XP + pl * XPS + (S + rem / (LDXH / 4)) * LDXH + (rem % (LDXH / 4)) * 4) = make_uint2(0, 0);
+                }
+                __syncthreads();
+            }
+        }
+        }
         STAMP(8);
         // ---- sum partials + bias + residual -> res2 (in X1), then LayerNorm2 -> next layer input / tokens_out
         {
             const int row = tid >> 2, c0 = (tid & 3) * 32;
-            if (n_slices > 1)       // sliced mode: the sum over the waves AND the slices of the clip comes back in Xs
-                slice_allreduce(Xs, Part, Part + SP * LDX, Part + 2 * SP * LDX, LDX, S, p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD),
-                                slice, n_slices, p.xflags + (size_t)l * p.B + clip);
             if (row < S) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {

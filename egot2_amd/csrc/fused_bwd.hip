@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
         for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
     }
-    if constexpr (SLICED) { if (clip >= p.B) return; }        // (the grid is round_up(B, 8) * n_slices)
+    if constexpr (SLICED) { if (clip >= p.B || ((p.slice_drop >> slice) & 1)) return; }        // (the grid is round_up(B, 8) * n_slices)
 
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
@@ -1375,6 +1375,10 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
         BSTAMP(2);
         EGX_PHASE();
+        // SLICED: this pass walks the hidden blocks of slice `sl_cur` — its own first; afterwards any whose partial dX1 does not arrive
+        // in time is computed here too (slice_wait, fused_dev.h)
+        int sl_cur = slice, sl_k = 0;
+        for (;;) {
         // P4: FFN input gradient. dH^T = (W2^T g2^T) .* mask (ReLU sign bits saved by the forward); dX1^T += W1^T dH^T
         {
             constexpr bool XRES = CM == CM_BF16;
@@ -1395,7 +1399,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 for (int t = 0; t < NT; ++t) dxa[i][t] = f32x4{0, 0, 0, 0};
             const int nhb = p.d_ff / 32;
             const int nit = nhb / 4 / n_slices;           // sliced mode: blocks [slice * nit, (slice + 1) * nit) of every wave's walk
-            const int j0 = slice * nit;
+            const int j0 = sl_cur * nit;
             const int wave_s = __builtin_amdgcn_readfirstlane(wave);
             const int rot = p.rot_mode == 0 ? (int)((clip * 11u + (clip >> 3) * 5u) % (unsigned)nit)
                           : p.rot_mode == 2 ? (int)(((unsigned)(clip >> 3) & 3u) * (unsigned)nit / 4u)
@@ -1507,6 +1511,76 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                             make_float4(dxa[i][t][0], dxa[i][t][1], dxa[i][t][2], dxa[i][t][3]);
             }
         }
+        if constexpr (!SLICED) {
+            break;
+        } else {
+            __syncthreads();
+            float* xc = p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD);
+            unsigned* fl = p.xflags + ((size_t)l * p.B + clip) * SLICE_MAX;
+            slice_publish(Gs, B2, B3, B4, LDX, S, xc + (size_t)sl_cur * (FUSED_TOK_PAD * FD), fl + sl_cur);
+            bool steal = false;
+            while (++sl_k < n_slices) {
+                const int s2 = slice + sl_k < n_slices ? slice + sl_k : slice + sl_k - n_slices;
+                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; break; }
+            }
+            if (!steal) {
+                // the sum over the waves and over the slices of the clip comes back in Gs (B2, B3, B4 cleared): identical results in every slice
+                slice_gather(xc, n_slices, Gs, LDX, S);
+                for (int e = tid; e < S * (FD / 4); e += 256) {
+                    const int o = (e >> 5) * LDX + (e & 31) * 4;
+                    *reinterpret_cast<float4*>(B2 + o) = make_float4(0, 0, 0, 0);
+                    *reinterpret_cast<float4*>(B3 + o) = make_float4(0, 0, 0, 0);
+                    *reinterpret_cast<float4*>(B4 + o) = make_float4(0, 0, 0, 0);
+                }
+                break;
+            }
+            // the missing slice is computed here: the partial blocks overwrote g2 (B2) and its operand planes (B3 / B4); both come
+            // back from what this workgroup stored for the weight-gradient kernel before the loop (w.g2_out)
+            if (CM == CM_SPLIT && p.xg_planes) {
+                const size_t plane = (size_t)p.B * SP * FD;
+                const unsigned short* src = reinterpret_cast<const unsigned short*>(w.g2_out) + (size_t)clip * SP * FD;
+                unsigned short* GPr = reinterpret_cast<unsigned short*>(B3 < B4 ? B3 : B4);
+                for (int i = tid; i < 3 * SP * (FD / 8); i += 256) {
+                    const int part = i / (SP * (FD / 8)), rem = i - part * (SP * (FD / 8));
+                    const int row = rem >> 4, c8 = rem & 15;
+                    const uint4 v = *reinterpret_cast<const uint4*>(src + part * plane + rem * 8);
+                    unsigned short* dst = GPr + part * (SP * LDXH) + row * LDXH + c8 * 8;
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+                    *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+                }
+            } else {
+                if (CM == CM_BF16 && p.xg_planes) {
+                    const unsigned short* src = reinterpret_cast<const unsigned short*>(w.g2_out) + (size_t)clip * FUSED_TOK_PAD * FD;
+                    for (int i = tid; i < SP * (FD / 8); i += 256) {
+                        const int row = i >> 4, c8 = i & 15;
+                        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)i * 8);       // rows >= S were stored as zeros
+                        float* d = B2 + row * LDX + c8 * 8;
+                        *reinterpret_cast<float4*>(d) = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+                        *reinterpret_cast<float4*>(d + 4) = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+                    }
+                } else {
+                    for (int i = tid; i < SP * (FD / 4); i += 256) {
+                        const int row = i >> 5, c4 = (i & 31) * 4;
+                        *reinterpret_cast<float4*>(B2 + row * LDX + c4) =
+                            row < S ? *reinterpret_cast<const float4*>(w.g2_out + (tok0 + row) * FD + c4) : make_float4(0, 0, 0, 0);
+                    }
+                }
+                if constexpr (CM == CM_SPLIT) {
+                    __syncthreads();
+                    unsigned short* GPr = reinterpret_cast<unsigned short*>(B3 < B4 ? B3 : B4);
+                    const int row = tid >> 2, c0 = (tid & 3) * 32;
+                    if (row < SP) {
+                        float g[32];
+                        uint32_t h[16], m[16], lo[16];
+                        load32(B2 + row * LDX + c0, g);
+                        split32(g, h, m, lo);
+                        store_parts32(GPr + row * LDXH + c0, (size_t)(SP * LDXH), h, m, lo);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        }
         BSTAMP(4);
         // Q | K | V rows of the clip (48 x 384 fp32, saved by the forward): QKV_PF float4 per thread, requested here and parked in
         // registers under P5 - P7 (they take ~10k cycles to arrive from HBM); written to LDS when B4 / B5 / Gs are free, after P7.
@@ -1515,19 +1589,6 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         // (f32x4 values, not float4 structs: a struct copy is an llvm.memcpy global -> private -> LDS that pins qv[] in scratch memory)
         const f32x4* qsrc = reinterpret_cast<const f32x4*>(p.saved_qkv + ((size_t)l * p.B + clip) * SP * (3 * FD));   // (L, B, 48, 384)
         f32x4 qv[QKV_PF];
-        if (n_slices > 1) {
-            // sliced mode: the sum over the waves and over the slices of the clip comes back in Gs (B2, B3, B4 cleared): identical
-            // results in every slice
-            __syncthreads();
-            slice_allreduce(Gs, B2, B3, B4, LDX, S, p.xchg + ((size_t)l * p.B + clip) * n_slices * (FUSED_TOK_PAD * FD), slice, n_slices,
-                            p.xflags + (size_t)l * p.B + clip);
-            for (int e = tid; e < S * (FD / 4); e += 256) {
-                const int o = (e >> 5) * LDX + (e & 31) * 4;
-                *reinterpret_cast<float4*>(B2 + o) = make_float4(0, 0, 0, 0);
-                *reinterpret_cast<float4*>(B3 + o) = make_float4(0, 0, 0, 0);
-                *reinterpret_cast<float4*>(B4 + o) = make_float4(0, 0, 0, 0);
-            }
-        }
         // P5: LayerNorm1 backward with dy = dX1 (four wave partials in Gs, B2, B3, B4) + d_res2 (B1); x = res1 (B5, from P3).
         __syncthreads();
         ln_bwd_rows(S, w.norm1_w, p.eps,

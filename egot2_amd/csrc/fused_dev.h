@@ -570,46 +570,52 @@ __device__ __forceinline__ void slice_map(int n, int& clip, int& slice) {
     slice = m % n;
     clip = (m / n) * 8 + x;
 }
-// Arrival barrier of the n slices of a clip: `flag` counts arrivals (zeroed before the launch). ALL n workgroups must be resident
-// at the same time — the host only slices when round_up(B, 8) * n <= number of CUs (encoder.hip: fused_slices) — otherwise the
-// spin never ends; a bounded spin (about a minute: longer than any collective that may hold compute units meanwhile) turns that
-// into a trap (the queue aborts with a hardware exception) instead of a hung GPU. Other work on the device — an RCCL kernel of the
-// gradient exchange on its side stream — only delays the arrival: it never waits for this kernel. Two sliced launches racing for
-// the same CUs (two processes training on one GPU) are the one case that can starve each other: run those with EGX_FFN_SLICES=1.
+// The partial sums of the n slices of a clip meet in `xc` ((n, 48, 128) fp32) behind one "published" word per slice (zeroed
+// before the launch). A slice publishes its own block, then waits a BOUNDED time for each of the others; a block that does not
+// arrive (its workgroup is not resident yet: another process holds the compute units, the grid is larger than the chip) is
+// simply computed here as well — every slice can run the whole FFN — and published for everybody: no launch ever depends on
+// all of its workgroups being resident at once, the slicing is an optimisation, not a protocol the hardware has to honour.
 // No fences: an agent-scope release / acquire pair on gfx950 is a write-back plus an invalidate of the XCD's whole L2 (the eight
 // L2s are not coherent with each other), which throws away the packed weights every clip of the XCD streams from it. The
 // exchanged values instead travel as agent-scope relaxed atomics (xchg_store / xchg_load: write-through / coherent reads of just
-// those words), ordered by the s_waitcnt before the barrier in front of the counter update.
+// those words), ordered by the s_waitcnt + barrier in front of the flag store.
 // (one word per lane, consecutive lanes = consecutive words: these accesses are not merged into wider ones)
 __device__ __forceinline__ void xchg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float xchg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void slice_exchange(unsigned* flag, unsigned n) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's xchg_store()s have been written through
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 26)) __builtin_trap();
-        }
-    }
-    __syncthreads();
-}
-// The exchange of one (48, 128) fp32 block held as four per-wave partial blocks in LDS (row stride ld): the sum over the waves goes
-// to this slice's block of `xc`, and behind the arrival barrier the sum over all n slices (in slice order: identical in every
-// slice) comes back into p0.
-__device__ __forceinline__ void slice_allreduce(float* p0, const float* p1, const float* p2, const float* p3, int ld, int S, float* xc, int slice, int n,
-                                                unsigned* flag) {
-    constexpr int BLK = 48 * 128;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < S * 128; e += 256) {
+constexpr int SLICE_MAX = 8;                        // slices per clip (flag words per (layer, clip))
+constexpr unsigned long long SLICE_WAIT_TICKS = 10000;      // 100 us of the 100 MHz wall clock per missing slice
+// sum of the four per-wave partial blocks in LDS (row stride ld) -> block `xs` of the exchange buffer, then its flag
+__device__ __forceinline__ void slice_publish(const float* p0, const float* p1, const float* p2, const float* p3, int ld, int S, float* xs, unsigned* flag) {
+    for (int e = threadIdx.x; e < S * 128; e += 256) {
         const int o = (e >> 7) * ld + (e & 127);
-        xchg_store(xc + (size_t)slice * BLK + e, (p0[o] + p1[o]) + (p2[o] + p3[o]));
+        xchg_store(xs + e, (p0[o] + p1[o]) + (p2[o] + p3[o]));
     }
-    slice_exchange(flag, (unsigned)n);
-    // one slice's block per round, its 24 words per thread in flight together (rows >= S: never written, read and dropped)
-    constexpr int PER = BLK / 256;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's words have been written through
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// has the block behind `flag` been published? Waits at most SLICE_WAIT_TICKS; the answer is uniform over the workgroup
+__device__ __forceinline__ bool slice_wait(const unsigned* flag) {
+    __shared__ unsigned arrived;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        unsigned a;
+        do {
+            a = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a) break;
+            __builtin_amdgcn_s_sleep(2);
+        } while (wall_clock64() - t0 < SLICE_WAIT_TICKS);
+        arrived = a;
+    }
+    __syncthreads();
+    const unsigned a = arrived;
+    __syncthreads();
+    return a != 0;
+}
+// the sum of the n published blocks, in slice order (identical bits in every slice) -> p0
+__device__ __forceinline__ void slice_gather(const float* xc, int n, float* p0, int ld, int S) {
+    constexpr int BLK = 48 * 128, PER = BLK / 256;      // one slice's block per round, its 24 words per thread in flight together
+    const int tid = threadIdx.x;                        // (rows >= S: never written, read and dropped)
     float acc[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) acc[i] = 0.f;

@@ -145,3 +145,21 @@ def test_sliced_exchange_is_reproducible_over_many_launches(egx_lib, cuda, compu
             first = flat.clone()
         else:
             assert torch.equal(flat, first), f"launch {it} differs from launch 0 by {(flat - first).abs().max().item()}"
+
+
+@pytest.mark.parametrize("compute", ["f32", "f32s", "bf16"])
+@pytest.mark.parametrize("drop,B,L", [("fe", 12, 1), ("aa", 20, 2), ("7f", 5, 1), ("0f", 32, 1)])
+def test_missing_slices_are_computed_by_the_waiting_workgroups(egx_lib, cuda, compute, drop, B, L):
+    """The slicing is an optimisation, not a protocol the scheduler has to honour: a slice whose workgroup never becomes resident
+    (simulated: EGX_SLICE_DROP makes the workgroups of the masked slices leave at once) is computed by the workgroups that wait for
+    it, in both directions; logits and gradients equal the one-workgroup-per-clip launch."""
+    lo, go, *_ = _run(cuda, compute, B, 15, L, 0.5, 1)
+    os.environ["EGX_SLICE_DROP"] = drop
+    try:
+        ls, gs, *_ = _run(cuda, compute, B, 15, L, 0.5, 8)
+    finally:
+        os.environ.pop("EGX_SLICE_DROP")
+    tol_l, tol_g = (1e-5, 1e-3 if L > 1 else 1e-4) if compute != "bf16" else (2e-2, 5e-2)
+    assert (ls - lo).abs().max().item() < tol_l * max(1.0, lo.abs().max().item())
+    bad = {k: rel_err(gs[k], go[k]) for k in go if not rel_err(gs[k], go[k]) < tol_g}
+    assert not bad, bad
