@@ -76,8 +76,8 @@ struct FusedFwdParams {
     const float* attn_in;   // (L, Ntok, 128) attention outputs (before the out-projection), written by tiled_attn_fwd
     // ---- sliced mode (small batches: B * n_slices <= CUs): n_slices workgroups per clip. Each runs the whole clip (identical
     // arithmetic, identical stores) except the FFN, of which it walks 1 / n_slices of the hidden blocks; the partial FFN outputs
-    // are exchanged through `xchg` behind a per-(layer, clip) arrival counter in `xflags` (zeroed before the launch) and summed by
-    // every slice in slice order. See slice_exchange() in fused_dev.h for the residency requirement.
+    // are exchanged through `xchg` behind one "published" word per (layer, clip, slice) in `xflags` (zeroed before the launch) and
+    // summed by every slice in slice order; a block that does not arrive in time is computed by the waiting workgroup (fused_dev.h).
     int n_slices;           // 1 = one workgroup per clip
     float* xchg;            // (L, B, n_slices, 48, 128) fp32
     unsigned* xflags;       // (L, B, 8) "published" words

@@ -189,8 +189,9 @@ int egx_encoder_impl(const egx_config* cfg, const egx_segment* segs, int B);
 /* Workgroups per clip of the per-clip kernels (EGX_IMPL_FUSED) for this batch on the current device: 1, or 2 / 4 / 8 for small
  * batches (round_up(B, 8) * n <= compute units; the reference's own TTM batches are ~26 clips, HHI/dataset/ttm/sampler.py:41, and
  * strong scaling leaves 32 clips per GPU): every workgroup of a clip runs the clip except the FFN, of which it walks 1 / n of the
- * hidden blocks; the partial sums are exchanged behind an arrival counter, which needs all workgroups of the launch resident at
- * once (they are, one per compute unit). EGX_FFN_SLICES=1 in the environment turns it off, =2 / 4 / 8 caps n. -1: invalid configuration. */
+ * hidden blocks; the partial sums are exchanged through device memory. A partial sum that does not arrive within 100 us (its
+ * workgroup is not resident: the device is shared) is computed by the waiting workgroup itself, so the result never depends on
+ * the scheduling. EGX_FFN_SLICES=1 in the environment turns it off, =2 / 4 / 8 caps n. -1: invalid configuration. */
 int egx_encoder_slices(const egx_config* cfg, const egx_segment* segs, int B);
 
 /* tokens_out: (B, S, d). `saved` is written in forward and read in backward.

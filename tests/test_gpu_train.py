@@ -273,7 +273,6 @@ def _hip_ddp_worker(rank, world, port, q, overlapped):
     import torch.distributed as dist
     from egot2_amd import ddp, functional as F_egx
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    os.environ["EGX_FFN_SLICES"] = "1"      # several processes on ONE GPU: no sliced launches (their workgroups wait for each other)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     m = _ttm(dev, 12)
