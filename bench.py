@@ -501,6 +501,20 @@ def run(args) -> int:
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
         "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
     }
+    if multi:
+        # what took part: the rank count as a REAL collective sees it (sum of ones over the group), its backend, and how much of the
+        # exchange the step actually pays for: the same step timed without any collective (same launches, same graph policy)
+        t = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(t)
+        out["rccl_ranks"] = int(round(t.item()))
+        out["collective_backend"] = dist.get_backend()
+        model.egx_defer_small = False
+        gr0 = capture(fwd_bwd) if use_graph else None
+        step_noex = gr0.replay if gr0 is not None else fwd_bwd
+        d_ne = time_trials(step_noex, max(3, args.warmup // 2), args.steps, max(3, trials // 2))
+        ms_ne = percentile(d_ne, 0.5) / args.steps * 1e3
+        out["ms_per_step_without_exchange"] = ms_ne
+        out["exposed_collective_us"] = (ms_per_step - ms_ne) * 1e3
     if allreduce_us is not None:
         out["allreduce_us"] = allreduce_us
         out["overlap"] = "staged" if overlap else ("bucketed" if bucketed else "none")
@@ -525,6 +539,17 @@ def run(args) -> int:
                              "value": B * world / (m3 * 1e-3), "unit": "clips/s",
                              "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (m3 * 1e-3) / 1e12 / PEAK_TFLOPS["f32"]}
         model.set_compute("f32s", args.impl)
+    if wl["name"] in ("c1", "c2") and not multi and not args.no_native_line and hasattr(model, "dp_rate"):
+        # two series. The line above is the reference recipe (dropout 0.5 + 0.1 on the positional encoding); this is
+        # the deterministic p = 0 configuration the parity tests check, the GPU partner of cpu_baseline.train_p0
+        p_keep, pe_keep = model.dp_rate, model.pos_embed.dropout.p
+        model.dp_rate, model.pos_embed.dropout.p = 0.0, 0.0
+        step0 = make_step(None)
+        d0 = time_trials(step0, max(3, args.warmup // 2), args.steps, max(3, trials // 2))
+        m0 = percentile(d0, 0.5) / args.steps * 1e3
+        out["dropout0"] = {"dropout": 0.0, "ms_per_step": m0, "value": B * world / (m0 * 1e-3), "unit": "clips/s",
+                           "note": "same step, train mode, every dropout probability 0 (no mask work in the kernels)"}
+        model.dp_rate, model.pos_embed.dropout.p = p_keep, pe_keep
     if rank == 0 and not args.no_roofline:
         model.egx_defer_small = False
         out["roofline"] = measure_roofline(torch, lib, fwd_bwd, wl, dtype)
@@ -670,13 +695,19 @@ def measure_roofline(torch, lib, step, wl, dtype):
     peak = PEAK_TFLOPS[dtype]
     cnt, cnt_src = committed_counters(wl["name"], dtype, wl.get("batch_arg", B), wl.get("frames"), wl.get("layers_arg"), wl.get("encoder_only", False))
     if "fused_bwd_kernel" in res:
-        t = res["fused_bwd_kernel"]
-        ach = flops["fused_bwd_kernel"] / t / 1e12
+        # dominant kernel = the longest average launch among the per-clip path's kernels (one-launch kernels: fused_bwd; cut mode: one
+        # of the FFN launches or the FFN weight-gradient kernel); the others follow in other_kernels
+        dom = max((k for k in res if k in ("fused_bwd_kernel", "fused_fwd_kernel", "ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel")),
+                  key=lambda k: res[k])
+        if tiled or "ffn_fwd_kernel" not in res:
+            dom = "fused_bwd_kernel"
+        t = res[dom]
+        ach = flops[dom] / t / 1e12
         extra = {}
         if dtype == "f32s":
             extra = {"peak_note": "bf16 dense MFMA peak (2500 TFLOP/s) / 6 instructions per algorithmic K-block; the exact fp32 MFMA peak "
                                   "is 157.3 TFLOP/s", "frac_of_native_f32_mfma_peak": ach / PEAK_TFLOPS["f32"]}
-        cf = counter_fields(cnt, "egx::fused_bwd_kernel", t * 1e6)
+        cf = counter_fields(cnt, "egx::" + dom, t * 1e6)
         step_traffic = None
         if cnt:
             step_traffic = sum(v.get("traffic_bytes", 0.0) * v.get("launches", 0) for k, v in cnt["kernels"].items()
@@ -684,13 +715,16 @@ def measure_roofline(torch, lib, step, wl, dtype):
         if tiled:
             extra["tiled"] = (f"S = {S} > 48: the per-clip kernels run over 48-token tiles, {L + 1} launches per step (times and FLOPs are "
                               "per-step sums over them), attention in tiled_attn kernels (other_kernels: wide_attn_*)")
-        return {"bound": "mfma", "kernel": "egx::fused_bwd_kernel", "achieved": ach, "peak": peak,
+        if "ffn_fwd_kernel" in res:
+            extra["cut_mode"] = ("the per-clip kernels are cut at the FFN (egot2_amd/csrc/ffn_cut.hip): ffn_fwd / ffn_bwd_kernel = the hidden loops with "
+                                 "eight waves per clip, fused_fwd / fused_bwd_kernel = the attention-side launches; `kernel` is the longest launch")
+        return {"bound": "mfma", "kernel": "egx::" + dom, "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, **extra, **cf, "traffic_unit": "bytes/launch",
                 "counters_source": cnt_src, "hbm_bytes_per_step": step_traffic,
-                "flops_per_launch": flops["fused_bwd_kernel"], "avg_launch_us": t * 1e6,
+                "flops_per_launch": flops[dom], "avg_launch_us": t * 1e6,
                 "other_kernels": {k: {"avg_launch_us": v * 1e6, "achieved_tflops": flops[k] / v / 1e12,
                                       "frac": flops[k] / v / 1e12 / peak, **counter_fields(cnt, "egx::" + k, v * 1e6)}
-                                  for k, v in res.items() if k != "fused_bwd_kernel"}}
+                                  for k, v in res.items() if k != dom}}
     if "wide_gemm_kernel" in res:
         # many launches of different shapes per step: achieved = all GEMM FLOPs of one step / all GEMM time of one step
         t_step = tot_ms["wide_gemm_kernel"] * 1e-3 / reps

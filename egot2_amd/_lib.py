@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 13
+EGX_ABI_VERSION = 14
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED = 0, 1, 2, 3, 4
@@ -115,6 +115,12 @@ SIGNATURES = {
                                   _fp, C.c_int, C.c_uint64, _fp]),
     "egx_decoder_bwd": (C.c_int, [C.POINTER(DecConfig), _fp, C.POINTER(DecLayer), _fp, C.c_int, _fp, _fp, _fp, _fp, _fp,
                                   C.POINTER(DecLayerGrads), _fp, _fp, _fp, C.c_size_t, C.c_int, C.c_uint64, _fp]),
+    "egx_comm_unique_id": (C.c_int, [_fp]),
+    "egx_comm_create": (C.c_int, [_fp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "egx_comm_size": (C.c_int, [_fp]),
+    "egx_allreduce": (C.c_int, [_fp, _fp, C.c_size_t, C.c_int, C.c_int, _fp]),
+    "egx_comm_destroy": (C.c_int, [_fp]),
+    "egx_comm_library": (C.c_char_p, []),
     "egx_relu_mask": (C.c_int, [_fp, _fp, C.c_size_t, _fp]),
     "egx_dropout": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, _fp]),
     "egx_pool_pack": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(PKG_DIR, "libegot2x.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "fused.hip", "fused_bwd.hip", "tiled_attn.hip", "feature_sink.hip", "train.hip", "decoder.hip", "wide_gemm.hip", "wide_attn.hip", "wide_rows.hip", "wide_host.hip", "wide_decoder.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "fused.hip", "fused_bwd.hip", "ffn_cut.hip", "tiled_attn.hip", "feature_sink.hip", "train.hip", "decoder.hip", "wide_gemm.hip", "wide_attn.hip", "wide_rows.hip", "wide_host.hip", "wide_decoder.hip", "comm.hip", "encoder.hip"]
 HEADERS = ["common.h", "kernels.h", "fused.h", "fused_dev.h", "wide.h", "wide_host.h", os.path.join("..", "..", "include", "egot2x.h")]
 EXTRA = os.environ.get("EGX_CXXFLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]

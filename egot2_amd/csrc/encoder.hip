@@ -187,14 +187,35 @@ static size_t fused_xin_offset(const egx_config* cfg, const egx_segment* segs, c
 static size_t fused_qkv_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_xin_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.N * pl.d * 4, 256);
 }
-static size_t fused_core_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+// behind them: x1 = LayerNorm1 output of every layer as fp32 rows (L, N, d): what the cut mode's attention-side launch hands to ffn_fwd_kernel
+static size_t fused_x1f_offset(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
     return fused_qkv_offset(cfg, segs, pl) + align_up((size_t)pl.L * pl.vB * FUSED_TOK_PAD * 3 * pl.d * 4, 256);
 }
+static size_t fused_core_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    return fused_x1f_offset(cfg, segs, pl) + (pl.tpc > 1 ? (size_t)0 : align_up((size_t)pl.L * pl.N * pl.d * 4, 256));
+}
+// Cut mode (ffn_cut.hip): the per-clip kernels cut at the FFN, whose loops run as launches of their own with eight waves per clip. One
+// workgroup per clip only (the sliced mode of small batches keeps the one-launch kernels). Policy = where it measured faster on MI355X
+// (profiles/r05_cut_ab.txt): the f32s arithmetic (six MFMAs per K-block: the hidden loops are 55 % of the one-launch kernels and gain
+// 25 % from the second wave per SIMD) with one layer per launch pair and the reference's d_ff; bf16's short loops and deeper / narrower
+// stacks pay more for the two extra launches per layer than the loops gain. EGX_FFN_CUT=1 forces it wherever it is supported (the
+// parity tests run every mode through it), =0 keeps the one-launch kernels.
+static bool use_cut(const Plan& pl, int n_slices, bool tiled, int compute) {
+    if (tiled || n_slices != 1 || !ffn_cut_supported(pl.dff)) return false;
+    const char* e = getenv("EGX_FFN_CUT");      // (read per call: the tests compare both modes in one process; no layout depends on it)
+    if (e) return e[0] != '0';
+    return compute == EGX_F32_SPLIT && pl.L == 1 && pl.dff >= 1024;
+}
 static int fused_slices(const Plan& pl, int compute);
+static int fused_slices_layout(const Plan& pl);
 static size_t sliced_xchg_bytes(const Plan& pl, int n);
 static size_t sliced_flag_bytes(const Plan& pl, int n);
+// The exchange buffer and the flag words are laid out for the LARGEST slice count the shape admits on any device and under any
+// EGX_FFN_SLICES (fused_slices_layout: a function of the shape alone), so that the workspace query, the forward and the backward —
+// which each pick their own run-time count <= that bound (fused_slices) — agree on every offset whatever the environment or the
+// current device did between the calls (a changed count used to move the flag words past the caller's buffer).
 static size_t fused_saved_bytes(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
-    const int n = (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) ? 1 : fused_slices(pl, cfg->compute);
+    const int n = (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) ? 1 : fused_slices_layout(pl);
     return fused_core_bytes(cfg, segs, pl) + sliced_xchg_bytes(pl, n) + sliced_flag_bytes(pl, n);
 }
 // ---- sliced mode (small batches): n workgroups per clip, each 1 / n of the FFN hidden blocks (FusedFwdParams::n_slices). Only when
@@ -219,8 +240,28 @@ static int slice_drop_mask(int n) {
     const int m = (int)strtol(e, nullptr, 16) & ((1 << n) - 1);
     return m == (1 << n) - 1 ? 0 : m;      // at least one slice has to run
 }
+// The exchange is built on gfx942 / gfx950 behaviour (write-through relaxed agent-scope atomics, s_waitcnt ordering; fused_dev.h): any other
+// device runs one workgroup per clip.
+static bool device_slicing_ok() {
+    static int ok[64] = {0};        // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!ok[dev]) {
+        hipDeviceProp_t pr;
+        ok[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && (strncmp(pr.gcnArchName, "gfx950", 6) == 0 || strncmp(pr.gcnArchName, "gfx942", 6) == 0)) ? 1 : 2;
+    }
+    return ok[dev] == 1;
+}
+constexpr int SLICE_LAYOUT_CUS = 512;       // no supported device has more compute units: bounds the slice count the layout provides for
+static int fused_slices_layout(const Plan& pl) {
+    const int nit = pl.dff / 128, bq = (pl.B + 7) / 8 * 8;
+    int n = 1;
+    while (n * 2 <= 8 && nit % (n * 2) == 0 && bq * n * 2 <= SLICE_LAYOUT_CUS) n *= 2;
+    return n;
+}
 static int fused_slices(const Plan& pl, int compute) {
-    const char* e = getenv("EGX_FFN_SLICES");      // (read per call: the tests compare both modes in one process)
+    if (!device_slicing_ok()) return 1;
+    const char* e = getenv("EGX_FFN_SLICES");      // (read per call: the tests compare both modes in one process; the LAYOUT does not depend on it)
     // measured at B = 32 (profiles/r04_sliced.txt): the exchange costs ~10 us per kernel; with bf16's short FFN loop eight slices lose to four
     int cap = e ? atoi(e) : (compute == EGX_BF16 ? 4 : 8);
     if (cap < 1) cap = 1;
@@ -228,7 +269,8 @@ static int fused_slices(const Plan& pl, int compute) {
     int n = 1;
     while (n * 2 <= cap && n * 2 <= 8 && nit % (n * 2) == 0 && bq * n * 2 <= cus) n *= 2;
     if (compute == EGX_BF16 && n == 2 && !e) n = 1;     // two slices of the short bf16 loop do not pay for the exchange (B = 128: +3 % / -3 %)
-    return n;
+    const int cap_layout = fused_slices_layout(pl);
+    return n < cap_layout ? n : cap_layout;
 }
 // behind the fused layout: the forward's exchange buffer (L, B, n, 48, d) and the "published" words of forward and backward (2, L, B, 8)
 static size_t sliced_xchg_bytes(const Plan& pl, int n) { return n > 1 ? align_up((size_t)pl.L * pl.B * n * FUSED_TOK_PAD * pl.d * 4, 256) : 0; }
@@ -273,6 +315,7 @@ struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes, dx0;
+    size_t dy1, dxin;                       // cut mode: what the FFN-side and the attention-side launches of the backward hand each other
     size_t xchg;                            // sliced mode only
     size_t datt, dres, delta, dtok;         // tiled mode only
     size_t ffn_slab[FUSED_MAX_LAYERS];      // slab area of each layer's FFN weight gradient (layer 0: `slabs`): one reduction launch sums them all
@@ -302,12 +345,13 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     for (int l = 1; l < pl.L && l < FUSED_MAX_LAYERS; ++l) s.ffn_slab[l] = take(cur, ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr));
     s.dhid = take(cur, fused_hid_total(cfg, pl));
     s.dx0 = take(cur, nd);         // d(token-prep output) behind its dropout mask (learned positional table gradient)
+    s.dy1 = take(cur, nd); s.dxin = take(cur, nd);
     if (pl.tpc > 1 || pl.S > FUSED_TOK_PAD) {       // tiled mode: d(attention output), the residual gradient, delta, d(tokens) of a translator call
         s.datt = take(cur, nd); s.dres = take(cur, nd);
         s.delta = take(cur, (size_t)pl.B * pl.H * pl.S * 4);
         s.dtok = take(cur, nd);
     } else {
-        s.xchg = take(cur, sliced_xchg_bytes(pl, fused_slices(pl, cfg->compute)));
+        s.xchg = take(cur, sliced_xchg_bytes(pl, fused_slices_layout(pl)));
     }
     s.bytes = cur;
     return s;
@@ -394,6 +438,7 @@ static int linear_dw(const float* dy, const float* x, float* dW, int M, int N, i
 }
 
 int debug_read_ppstamps(unsigned long long* out);       // wide_gemm.hip (development aid)
+int debug_read_cstamps(unsigned long long* out);        // ffn_cut.hip (development aid)
 
 }  // namespace egx
 
@@ -403,7 +448,7 @@ extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
-int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
+int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : n == -3000 ? debug_read_cstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
 int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }
 int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }
@@ -608,11 +653,22 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.n_slices = tiled ? 1 : fused_slices(pl, comp);
         if (fp.n_slices > 1) {
             fp.xchg = (float*)((char*)saved + fused_core_bytes(cfg, segs, vp));
-            fp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, fp.n_slices));
+            fp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, fused_slices_layout(pl)));
             pk.zero_words = fp.xflags; pk.n_zero = (int)sliced_flag_words(pl);        // the packing launch (always in front) zeroes the flags
             fp.slice_drop = slice_drop_mask(fp.n_slices);
         }
+        fp.x1f_out = tiled ? nullptr : (float*)((char*)saved + fused_x1f_offset(cfg, segs, vp));
         if (pack_weights(pk, st)) return 1;
+        if (use_cut(pl, fp.n_slices, tiled, comp)) {
+            // cut mode: per layer [token preparation | layer input .. LayerNorm1] (4 waves per clip) + [FFN .. LayerNorm2 (+ pooled head)] (8 waves)
+            fp.mode = FUSED_MODE_ATTN;
+            for (int l = 0; l < pl.L; ++l) {
+                fp.l0 = l;
+                if (fused_forward(fp, comp, st)) return 1;
+                if (ffn_cut_forward(fp, l, comp, st)) return 1;
+            }
+            return 0;
+        }
         if (!tiled) return fused_forward(fp, comp, st);
         // tiled mode: token preparation + Q | K | V of layer 0, then per layer [attention of every clip] [out-projection .. LayerNorm2
         // + Q | K | V of the next layer] (2 L + 1 launches), then the pooled head on the output tokens
@@ -809,10 +865,21 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.n_slices = tiled ? 1 : fused_slices(pl, comp);
             if (bp.n_slices > 1 && stage != 2) {
                 bp.xchg = fptr(scratch, SC.xchg);
-                bp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, bp.n_slices)) + sliced_flag_words(pl);
+                bp.xflags = (unsigned*)((char*)saved + fused_core_bytes(cfg, segs, vp) + sliced_xchg_bytes(pl, fused_slices_layout(pl))) + sliced_flag_words(pl);
                 EGX_HIP(hipMemsetAsync(bp.xflags, 0, sliced_flag_words(pl) * 4, st));
                 bp.slice_drop = slice_drop_mask(bp.n_slices);
             }
+            if (stage != 2 && use_cut(pl, bp.n_slices, tiled, comp)) {
+                // cut mode: per layer, top down, [LayerNorm2 backward + FFN input gradient] (8 waves per clip) + [LayerNorm1 backward .. the layer
+                // input's gradient, or the token-preparation backward] (4 waves)
+                bp.cut = 1; bp.dy1 = fptr(scratch, SC.dy1); bp.dxin = fptr(scratch, SC.dxin);
+                for (int l = pl.L - 1; l >= 0; --l) {
+                    bp.cut_layer = l;
+                    if (ffn_cut_backward(bp, l, comp, st)) return 1;
+                    bp.zero_buf = nullptr;
+                    if (fused_backward(bp, comp, st)) return 1;
+                }
+            } else
             if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
             if (stage != 2 && tiled) {
                 // L + 1 launches of the tile kernel with the attention backward of every clip between them

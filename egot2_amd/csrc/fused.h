@@ -82,8 +82,12 @@ struct FusedFwdParams {
     float* xchg;            // (L, B, n_slices, 48, 128) fp32
     unsigned* xflags;       // (L, B, 8) "published" words
     int slice_drop;         // testing aid (EGX_SLICE_DROP): bit s set = the workgroups of slice s leave at once, as if they never became resident
+    // ---- cut mode (round 5, ffn_cut.hip): the clip kernel is CUT at the FFN. FUSED_MODE_ATTN runs [token preparation (layer 0) or the
+    // saved layer input (xin_out, layer l0 > 0)] .. LayerNorm1 of layer l0 and leaves x1 (fp32 rows in x1f_out + the bf16 operand planes
+    // in x1p_out); ffn_fwd_kernel (512 threads: two waves per SIMD) runs the FFN, the second residual, LayerNorm2 and the pooled head.
+    float* x1f_out;         // (L, Ntok, 128) fp32: the FFN input x1 = LayerNorm1 output of every layer
 };
-enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2 };
+enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2, FUSED_MODE_ATTN = 3 };
 
 // one matrix to rewrite into MFMA-fragment order (A operand, rows = M dimension); transpose reads src[k][row]
 struct PackDesc {
@@ -193,8 +197,19 @@ struct FusedBwdParams {
     float* datt;                    // (Ntok, 128) gradient w.r.t. the attention output of layer l_back (written) 
     float* dres;                    // (Ntok, 128) gradient reaching the layer input through the residual (written for l_back, read for l_front)
     int n_slices; float* xchg; unsigned* xflags; int slice_drop;     // sliced mode (see FusedFwdParams): the partial FFN input gradients are exchanged
+    // ---- cut mode (see FusedFwdParams): per layer l = cut_layer, ffn_bwd_kernel (512 threads) runs [head backward] + LayerNorm2 backward +
+    // the FFN input gradient and leaves dy1 = dX1 + d_res2; fused_bwd_kernel<CUT> picks it up at LayerNorm1's backward and runs on to
+    // the in-projection input gradient, which it leaves in dxin for the next (lower) layer's ffn_bwd_kernel — or to the token preparation.
+    int cut, cut_layer;
+    float* dy1;             // (Ntok, 128) gradient reaching LayerNorm1's output (FFN path + residual path)
+    float* dxin;            // (Ntok, 128) gradient w.r.t. the input of layer cut_layer (= LayerNorm2 output of the layer below)
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
+// cut mode (ffn_cut.hip): the FFN of layer l as launches of their own, eight waves per clip
+bool ffn_cut_supported(int d_ff);
+size_t ffn_cut_lds_bytes();
+int ffn_cut_forward(const FusedFwdParams& p, int l, int compute, hipStream_t st);
+int ffn_cut_backward(const FusedBwdParams& p, int l, int compute, hipStream_t st);
 
 // One "dW[R][C] += G^T X" problem of the grouped small-weight-gradient kernel: G (K, R) and X (K, C) token-major.
 struct SmallDwProblem {

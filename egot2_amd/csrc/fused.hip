@@ -105,9 +105,12 @@ int debug_read_stamps(unsigned long long* out, int n) {
 // instantiation (TILED = false) compiles to the code it was before the tiled mode existed.
 // SLICED: the small-batch instantiation (n workgroups per clip, FusedFwdParams::n_slices > 1). A template parameter, not a run-time
 // test: with the slice code compiled into the one-workgroup-per-clip kernels their B = 256 step was 1 % (f32s) / 2.5 % (bf16) slower.
-template <int CM, int NT, bool TILED, int DH, bool SLICED = false>
+// CUT (round 5, ffn_cut.hip): the launch runs [token preparation (l0 = 0) | the saved input of layer l0] .. LayerNorm1 of layer l0 and
+// leaves x1; the FFN, the second residual and LayerNorm2 are ffn_fwd_kernel's (eight waves per clip).
+template <int CM, int NT, bool TILED, int DH, bool SLICED = false, bool CUT = false>
 __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     static_assert(!(TILED && SLICED), "the tiled launches are not sliced");
+    static_assert(!(CUT && (TILED || SLICED)), "the cut launches are neither tiled nor sliced");
     constexpr int HPW = FDH / DH;               // heads per wave: 1 (4 heads of 32) or 2 (8 heads of 16)
     constexpr int NHEAD = FH * HPW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -204,7 +207,22 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         }
     }
-    if (!TILED || !skip_front) {
+    if constexpr (CUT) {
+        l_begin = p.l0;
+        if (p.l0 > 0) {     // the layer input ffn_fwd_kernel of the layer below left (padded rows zero)
+            for (int i = tid; i < SP * LDX / 4; i += 256) {
+                reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0, 0, 0, 0};
+                reinterpret_cast<f32x4*>(X1)[i] = f32x4{0, 0, 0, 0};
+            }
+            __syncthreads();
+            const f32x4* xs = reinterpret_cast<const f32x4*>(p.xin_out + ((size_t)l_begin * p.B + clip) * S * FD);
+            for (int i = tid; i < S * (FD / 4); i += 256) {
+                const int row = i >> 5, c = (i & 31) << 2;
+                *reinterpret_cast<f32x4*>(Xs + row * LDX + c) = xs[i];
+            }
+        }
+    }
+    if ((!TILED || !skip_front) && !(CUT && p.l0 > 0)) {
     // ---- token preparation: proj GEMM (feature-major) -> LDS token-major -> LN + task embedding + position.
     // Steps = (segment, 16-row tile, 128-wide K chunk), two register sets. ROLLING REFILL as in the FFN loop: a fragment's
     // registers are reloaded with the same fragment of step i + 2 right behind the MFMAs that consumed it, every load is
@@ -452,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     }
                 }
             }
+            if (!(CUT && l > 0))    // (cut mode, l > 0: the input was loaded from there)
             store_block(TILED ? p.xin_out + ((size_t)l * p.Ntok + tokbase) * FD : p.xin_out + ((size_t)l * p.B + clip) * S * FD, Xs, S);      // no global load follows before the out-projection
             if constexpr (TILED) return;        // the attention of the whole clip is another launch (tiled_attn_fwd)
             if (NT < 4) {   // zero the key padding columns SP..63 of V^T
@@ -652,6 +671,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         }
 
+        if constexpr (CUT) {        // x1 as fp32 rows: ffn_fwd_kernel's residual (and, in exact-fp32 mode, its operand; the weight-gradient kernel's too)
+            store_block(p.x1f_out + ((size_t)l * p.Ntok + tokbase) * FD, X1, S);
+            return;
+        }
         STAMP(6);
         EGX_PHASE();
         // SLICED: this pass walks the hidden blocks of slice `sl_cur` — its own first; afterwards any whose partial sum does not
@@ -1024,6 +1047,20 @@ static int launch_fwd(const FusedFwdParams& p, hipStream_t st) {
     timing_begin(TIMER_FUSED_FWD, st);
     bool sliced = false;
     if constexpr (!TILED) sliced = p.n_slices > 1;
+    if constexpr (!TILED) {
+        if (p.mode == FUSED_MODE_ATTN) {
+            static bool cut_attr = false;
+            if (!cut_attr) {
+                EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<CM, 3, false, DH, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                cut_attr = true;
+            }
+            EGX_CHECK(!sliced && p.x1f_out, "cut mode: one workgroup per clip, x1f_out set");
+            hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, false, DH, false, true>), dim3(p.B), dim3(256), lds, st, p);
+            timing_end(TIMER_FUSED_FWD, st);
+            EGX_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (sliced) {
         if constexpr (!TILED)
             hipLaunchKernelGGL((fused_fwd_kernel<CM, 3, false, DH, true>), dim3((p.B + 7) / 8 * 8 * p.n_slices), dim3(256), lds, st, p);
@@ -1042,7 +1079,7 @@ int ffn_rot_mode() {
 }
 
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st) {
-    if (p.mode != FUSED_MODE_FULL) {        // tiled mode: bf16 and split only (the exact-fp32 mode stays on the generic kernels for S > 48)
+    if (p.mode != FUSED_MODE_FULL && p.mode != FUSED_MODE_ATTN) {        // tiled mode: bf16 and split only (the exact-fp32 mode stays on the generic kernels for S > 48)
         EGX_CHECK(compute == CM_BF16 || compute == CM_SPLIT, "tiled mode: compute must be bf16 or f32s");
         EGX_CHECK(p.n_heads == FH, "tiled mode: 4 heads of 32");
         return compute == CM_BF16 ? launch_fwd<CM_BF16, true, 32>(p, st) : launch_fwd<CM_SPLIT, true, 32>(p, st);

@@ -1084,9 +1084,12 @@ int debug_read_bstamps(unsigned long long* out, int n) {
 // TILED (48 < S <= 512, see FusedBwdParams): the workgroup is one 48-token tile and the kernel is cut at the attention backward
 // (tiled_attn_bwd): a launch runs [P11 - P12 of layer l_front on the dQ | dK | dV rows that kernel left] + [P1 - P7 of layer
 // l_back, leaving d(attention output) and the residual gradient in HBM], or ends with the token-preparation backward.
-template <int CM, bool TILED, int DH, bool SLICED = false>      // SLICED: see fused_fwd_kernel
+// CUT (round 5, ffn_cut.hip): the launch runs LayerNorm1 backward .. the in-projection input gradient of layer p.cut_layer on the dy1 rows
+// ffn_bwd_kernel left, and leaves d(layer input) in p.dxin for the layer below — or, for layer 0, runs on into the token-preparation backward.
+template <int CM, bool TILED, int DH, bool SLICED = false, bool CUT = false>      // SLICED: see fused_fwd_kernel
 __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     static_assert(!(TILED && SLICED), "the tiled launches are not sliced");
+    static_assert(!(CUT && (TILED || SLICED)), "the cut launches are neither tiled nor sliced");
     constexpr int HPW = FDH / DH, NHEAD = FH * HPW, NCT = DH / 16;      // heads per wave, heads, 16-channel tiles per head
     constexpr int NT = 3;
     constexpr int SP = NT * 16;
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     } else {
         c_real = clip; t0 = 0; S = p.S; tok0 = (size_t)clip * S;
     }
-    if (p.zero_buf) {       // the caller's flat gradient buffer: every accumulation into it happens in later launches
+    if (!CUT && p.zero_buf) {       // the caller's flat gradient buffer: every accumulation into it happens in later launches (cut mode: ffn_bwd_kernel zeroes it)
         const size_t n4 = p.zero_n / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
         for (size_t k = b0 + threadIdx.x; k < b1; k += 256) reinterpret_cast<float4*>(p.zero_buf)[k] = make_float4(0, 0, 0, 0);
@@ -1167,8 +1170,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     auto res_ptr = [&](int slot) -> const float* {
         return TILED ? p.saved_res + ((size_t)slot * p.Ntok + tok0) * FD : p.saved_res + ((size_t)slot * p.B + clip) * S * FD;
     };
-    const int l_first = TILED ? p.l_back : p.n_layers - 1;      // the layer whose P1 - P7 this launch runs first (TILED: < 0 = none)
-    blk_request(pf_a, l_first >= 0 ? res_ptr(2 * l_first + 1) : p.saved_pre + tok0 * FD);
+    const int l_first = CUT ? p.cut_layer : TILED ? p.l_back : p.n_layers - 1;      // the layer whose P1 - P7 this launch runs first (TILED: < 0 = none)
+    // (CUT: dy1 in place of res2 — it goes to Gs, the sum LayerNorm1's backward starts from)
+    blk_request(pf_a, CUT ? p.dy1 + tok0 * FD : l_first >= 0 ? res_ptr(2 * l_first + 1) : p.saved_pre + tok0 * FD);
     blk_request(pf_b, l_first >= 0 ? res_ptr(2 * l_first) : p.saved_pre + tok0 * FD);
     static_assert((6 * BLK) % 4 == 0, "the blocks are zeroed in 16-byte pieces");
     for (int i = tid; i < 6 * BLK / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
@@ -1239,8 +1243,21 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             blk_store(pf_b, B5, nullptr);
         }
     }
+    if constexpr (CUT) {        // dy1 -> Gs (B1 .. B4 stay zero: P5 adds them), res1 -> B5
+        blk_store(pf_a, Gs, nullptr);
+        blk_store(pf_b, B5, nullptr);
+        // x1 = LayerNorm1(res1) is an operand of the FFN weight gradient; without operand planes from the forward (exact-fp32 mode) it is
+        // rebuilt here, as P3 of the one-launch kernel does
+        if (!(CM != CM_F32 && p.xg_planes)) {
+            const FusedBwdLayer& wc = p.layer[p.cut_layer];
+            __syncthreads();
+            ln_rows(B5, S, wc.norm1_w, wc.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+                store32(wc.x1_out + (tok0 + row) * FD + c0, y);
+            });
+        }
+    }
     // res2 -> B1 (LayerNorm2 backward; with the fused head also -> Gs, normalised in place below), res1 -> B5 (P3 / P5)
-    if constexpr (!TILED) {
+    if constexpr (!TILED && !CUT) {
     blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);
     blk_store(pf_b, B5, nullptr);
     if (p.head.n_out > 0) {
@@ -1294,7 +1311,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(p.d_tokens + ((size_t)clip * p.out_T + row) * FD + c);
         }
     }
-    }       // !TILED
+    }       // !TILED && !CUT
 
     for (int l = l_first; l >= 0; --l) {
         const FusedBwdLayer& w = p.layer[l];
@@ -1305,11 +1322,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 
         BSTAMP(0);
         // P1: res2 -> B1, res1 -> B5: requested during the previous layer's P11 / P12 (the last layer's before the LDS zero fill)
-        if (!TILED && l != p.n_layers - 1) {
+        if (!TILED && !CUT && l != p.n_layers - 1) {
             blk_store(pf_a, B1, nullptr);
             blk_store(pf_b, B5, nullptr);
         }
         __syncthreads();
+        if constexpr (!CUT) {       // P2 - P4 (LayerNorm2 backward, FFN input gradient): ffn_bwd_kernel's in cut mode
         // P2: LayerNorm2 backward. B1 <- d_res2 (in place), B3 <- dY * xhat, B2 <- g2 = d_res2 .* dropout2 mask
         ln_bwd_rows(S, w.norm2_w, p.eps,
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) { load32(Gs + row * LDX + c0, dy); load32(B1 + row * LDX + c0, x); },
@@ -1581,6 +1599,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             __syncthreads();
         }
         }
+        }       // !CUT: P2 - P4
         BSTAMP(4);
         // Q | K | V rows of the clip (48 x 384 fp32, saved by the forward): QKV_PF float4 per thread, requested here and parked in
         // registers under P5 - P7 (they take ~10k cycles to arrive from HBM); written to LDS when B4 / B5 / Gs are free, after P7.
@@ -1924,6 +1943,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         }
         __syncthreads();
         { float* t = Gs; Gs = B2; B2 = t; }
+        if constexpr (CUT) {
+            if (l > 0) {        // d(layer input): the dY of the layer below, picked up by its ffn_bwd_kernel
+                store_block(p.dxin + tok0 * FD, Gs, S);
+                return;
+            }
+        }
     }
 
         BSTAMP(10);
@@ -1997,6 +2022,21 @@ static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
     timing_begin(TIMER_FUSED_BWD, st);
     bool sliced = false;
     if constexpr (!TILED) sliced = p.n_slices > 1;
+    if constexpr (!TILED) {
+        if (p.cut) {
+            static bool cut_attr = false;
+            if (!cut_attr) {
+                EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, false, DH, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                cut_attr = true;
+            }
+            EGX_CHECK(!sliced && p.dy1 && (p.cut_layer == 0 || p.dxin), "cut mode: one workgroup per clip, dy1 / dxin set");
+            hipLaunchKernelGGL((fused_bwd_kernel<CM, false, DH, false, true>), dim3(p.B), dim3(256), lds, st, p);
+            timing_end(TIMER_FUSED_BWD, st);
+            EGX_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (sliced) {
         if constexpr (!TILED)
             hipLaunchKernelGGL((fused_bwd_kernel<CM, false, DH, true>), dim3((p.B + 7) / 8 * 8 * p.n_slices), dim3(256), lds, st, p);

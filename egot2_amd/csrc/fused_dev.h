@@ -580,6 +580,13 @@ __device__ __forceinline__ void slice_map(int n, int& clip, int& slice) {
 // exchanged values instead travel as agent-scope relaxed atomics (xchg_store / xchg_load: write-through / coherent reads of just
 // those words), ordered by the s_waitcnt + barrier in front of the flag store.
 // (one word per lane, consecutive lanes = consecutive words: these accesses are not merged into wider ones)
+// This ordering argument is a property of gfx942 / gfx950 (sc1 write-through stores, L2-bypassing coherent loads, in-order completion
+// counted by vmcnt), not of the HIP memory model: the device code refuses to build for anything else, the host (encoder.hip
+// device_slicing_ok) runs one workgroup per clip on any other device, and tools/micro/slice_litmus.hip shows the protocol failing
+// once the s_waitcnt is taken out (tests/test_gpu_sliced.py runs it).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "the sliced-mode exchange (slice_publish / slice_wait / slice_gather) is validated on gfx942 / gfx950 only"
+#endif
 __device__ __forceinline__ void xchg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float xchg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 constexpr int SLICE_MAX = 8;                        // slices per clip (flag words per (layer, clip))
@@ -590,7 +597,9 @@ __device__ __forceinline__ void slice_publish(const float* p0, const float* p1, 
         const int o = (e >> 7) * ld + (e & 127);
         xchg_store(xs + e, (p0[o] + p1[o]) + (p2[o] + p3[o]));
     }
+#ifndef EGX_LITMUS_NO_WAITCNT      // (tools/micro/slice_litmus.hip builds this function without the wait to show what it is there for)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's words have been written through
+#endif
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

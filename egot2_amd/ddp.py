@@ -213,3 +213,68 @@ class BucketedExchange:
                 self.collectives += allreduce_gradients(rest, self.group, self.average, self.force)
         self._work = []
         return False
+
+
+class EgxComm:
+    """RCCL communicator under the C ABI (include/egot2x.h: egx_comm_* / egx_allreduce) for harnesses that have no torch process
+    group. One per process, on the current device. The 128-byte id is drawn by rank 0 and carried to the others by `bcast`
+    (any callable bytes -> bytes that returns rank 0's argument on every rank: an MPI bcast, a file, a torch.distributed
+    object broadcast). `allreduce_gradients(params)` is the same exchange as the module-level function: the flat gradient
+    buffer(s) of the backward, summed and divided by the rank count, asynchronous on the current stream."""
+
+    def __init__(self, rank: int, world: int, bcast=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        buf = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self._lib.egx_comm_unique_id(buf))
+        idb = bytes(buf)
+        if self.world > 1:
+            if bcast is None:
+                raise ValueError("EgxComm: world > 1 needs a `bcast` callable to carry rank 0's id to the other ranks")
+            idb = bcast(idb)
+        h = C.c_void_p()
+        _lib.check(self._lib.egx_comm_create(C.c_char_p(idb), self.rank, self.world, C.byref(h)))
+        self._h = h
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.egx_comm_size(self._h))
+
+    def allreduce_(self, t: torch.Tensor, average: bool = True) -> torch.Tensor:
+        from . import _lib
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
+            raise _lib.EgxError("EgxComm.allreduce_: contiguous fp32 / bf16 CUDA tensor expected")
+        _lib.check(self._lib.egx_allreduce(self._h, t.data_ptr(), t.numel(), int(t.dtype == torch.bfloat16), int(average),
+                                           torch.cuda.current_stream().cuda_stream))
+        return t
+
+    @torch.no_grad()
+    def allreduce_gradients(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
+        flats, singles = _flat_groups([p for p in params if p.grad is not None])
+        n = 0
+        for f in flats:
+            self.allreduce_(f, average)
+            n += 1
+        if singles:
+            coalesced = torch.cat([g.reshape(-1) for g in singles])
+            self.allreduce_(coalesced, average)
+            off = 0
+            for g in singles:
+                g.copy_(coalesced[off:off + g.numel()].view_as(g))
+                off += g.numel()
+            n += 1
+        return n
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.egx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass

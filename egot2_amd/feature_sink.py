@@ -39,10 +39,12 @@ class FeatureSink:
         self.device, self.dtype = torch.device(device), dtype
         self._buf: Dict[str, torch.Tensor] = {}
 
-    def alloc(self, name: str, B: int, T: int, d_in: int, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-        """(Re)uses the stream's buffer when the shape matches: a training loop allocates once."""
+    def alloc(self, name: str, B: int, T: int, d_in: int, dtype: Optional[torch.dtype] = None, fresh: bool = False) -> torch.Tensor:
+        """(Re)uses the stream's buffer when the shape matches: an inference loop allocates once. `fresh=True` hands out a NEW
+        tensor: the producers fill the stream through raw pointers (no autograd version bump), so a stream that a pending
+        backward may still read — the translator's projections save their input for dW — must not be refilled in place."""
         dt = dtype or self.dtype
-        t = self._buf.get(name)
+        t = None if fresh else self._buf.get(name)
         if t is None or tuple(t.shape) != (B, T, d_in) or t.dtype != dt:
             t = torch.empty((B, T, d_in), dtype=dt, device=self.device)
             self._buf[name] = t

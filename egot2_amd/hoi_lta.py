@@ -182,7 +182,9 @@ class TaskFusionMFTransformerLTA4Task(_LTATranslator):
         # pass over its res5 map, straight into token row i of the packed (B, n, 8192) stream the projection GEMM reads in place
         B, n = x.shape[0], x.shape[1]
         stream = head._stream_name
-        self._sink.alloc(stream, B, n, self.proj_pnr.in_features)
+        # with autograd recording, every forward gets a stream of its own: proj_pnr / proj_oscc save it for their weight gradient,
+        # and a second forward before that backward (micro-batches, an eval pass in between) would otherwise overwrite it unseen
+        self._sink.alloc(stream, B, n, self.proj_pnr.in_features, fresh=torch.is_grad_enabled())
         try:
             for i in range(n):
                 head.token = i

@@ -468,3 +468,16 @@ def ref_hoi_ga(args, vocab=None) -> nn.Module:
     _patch_decoder_layer(m)
     args.ff_dim = 2048
     return m.TaskTranslationPromptTransformerActionTask(args, vocab or HOI_G_VOCAB)
+
+
+# ---- HOI: the PNR / OSCC backbones' head, producer side of the feature hand-off -------------------
+def ref_pnr_head(num_classes: int, pool_size, act_func: str = "softmax_2", dropout_rate: float = 0.0) -> nn.Module:
+    """The REAL `ResNetKeyframeLocalizationHead` (HOI/models/pnr/head_helper.py:293-381; built at
+    HOI/models/pnr/video_model_builder.py:310-322 with pool (1, 7, 7) for keyframe localisation and :350-362 with
+    (T, 7, 7) for state-change classification). Only the import of detectron2's ROIAlign (used by a different head of the
+    same file) is stubbed; `forward(inputs, middle)` is the reference's own."""
+    use_tree("HOI")
+    _install_hoi_stubs()
+    from models.pnr import head_helper
+    return head_helper.ResNetKeyframeLocalizationHead(dim_in=[2048], num_classes=num_classes, pool_size=[list(pool_size)],
+                                                      dropout_rate=dropout_rate, act_func=act_func)

@@ -18,6 +18,8 @@ Follows (paths relative to the reference checkout):
   EgoT2-g encoder        HHI/models/multitask/task_prompt_model.py:224-258
   HOI translators        HOI/models/lta/lta_models_lta_transfer.py:355-363, HOI/models/pnr/video_model_transfer_3task.py:249-257
   LTA head               HOI/models/lta/head_helper.py:261-290 (training branch: Linear per future action)
+  PNR / OSCC head        HOI/models/pnr/head_helper.py:353-381 (AvgPool3d stride 1 -> permute -> (N, T', 8192) rows -> Linear);
+                         the per-clip `.mean(dim=1)` of HOI/models/lta/lta_models_lta_transfer.py:335-345
   loss                   HHI/tasks/ttm/video_task_2loader.py:21-22,34 (CrossEntropyLoss(weight=[0.266, 0.734]))
 """
 from __future__ import annotations
@@ -368,6 +370,33 @@ def g_decode(sd, n_heads: int, y: torch.Tensor, memory: torch.Tensor) -> torch.T
     for i in range(n_layers_of(sd, "transformer_decoder.")):
         x = decoder_layer(x, mem, sd, f"transformer_decoder.layers.{i}.", n_heads)
     return linear(x, sd["fc.weight"], sd["fc.bias"]).permute(1, 0, 2)
+
+
+def pnr_head_forward(fmap: torch.Tensor, pool: Sequence[int], proj_w=None, proj_b=None, middle: bool = True,
+                     act_dim: Optional[int] = None, clip_mean: bool = False) -> torch.Tensor:
+    """`ResNetKeyframeLocalizationHead.forward(inputs, middle)` for its single pathway (HOI/models/pnr/head_helper.py:353-381),
+    producer side of the feature hand-off, written out as window sums (no nn.AvgPool3d):
+      fmap (N, C, T, H, W) res5 map -> AvgPool3d(pool, stride=1) -> permute (N, T', H', W', C) -> rows (N, T', H'W'C)   [:359-372]
+      middle: return the rows [:373-374] (clip_mean: their `.mean(dim=1)`, lta_models_lta_transfer.py:335-345)
+      else  : Linear(8192, classes) on the rows [:375], softmax over `act_dim` when given (eval mode, :378-379),
+              permute(0, 2, 1) [:381]."""
+    kt, kh, kw = (int(v) for v in pool)
+    N, C, T, H, W = fmap.shape
+    To, Ho, Wo = T - kt + 1, H - kh + 1, W - kw + 1
+    acc = torch.zeros((N, C, To, Ho, Wo), dtype=fmap.dtype)
+    for a in range(kt):
+        for b in range(kh):
+            for c in range(kw):
+                acc = acc + fmap[:, :, a:a + To, b:b + Ho, c:c + Wo]
+    x = (acc / float(kt * kh * kw)).permute(0, 2, 3, 4, 1).reshape(N, To, Ho * Wo * C)
+    if middle:
+        return x.mean(dim=1) if clip_mean else x
+    y = linear(x, proj_w, proj_b)
+    if act_dim is not None:
+        y = y - y.max(dim=act_dim, keepdim=True).values
+        y = torch.exp(y)
+        y = y / y.sum(dim=act_dim, keepdim=True)
+    return y.permute(0, 2, 1)
 
 
 def to_dtype(sd: Dict[str, torch.Tensor], dtype) -> Dict[str, torch.Tensor]:

@@ -44,6 +44,11 @@ HOI_CASES = [
     dict(name="hoig2_B2_L2_d256", kind="hoig2", B=2, L=2, d=256, h=8, wseed=105, fseed=106),
     dict(name="hoiga_B3_L2_d128", kind="hoiga", B=3, L=2, d=128, h=4, wseed=107, fseed=108),
 ]
+# row F4 (producer side): the REAL PNR / OSCC head (`ResNetKeyframeLocalizationHead`) on a seeded res5 map — `middle=True` rows
+# for the keyframe head (kt = 1) and the state-change head (kt = T), and the `projection` + activation + permute path
+HEAD_CASES = [
+    dict(name="pnrhead_N2_T3", kind="pnrhead", N=2, C=2048, T=3, H=8, W=8, classes_kf=17, classes_sc=2, wseed=111, fseed=112),
+]
 
 
 def g_targets(c, task, batch, vocab_size, sy=2):
@@ -217,9 +222,41 @@ def run_hoi():
         print("wrote", c["name"], "loss", float(loss))
 
 
+def run_head():
+    """HOI/models/pnr/head_helper.py:293-381 as built at HOI/models/pnr/video_model_builder.py:310-322 (keyframe localisation:
+    pool (1, 7, 7), softmax over the frames) and :350-362 (state change: pool (T, 7, 7), softmax over the classes)."""
+    import numpy as np
+    import torch
+    from oracle import ref_harness as rh
+    from tests.util import seeded_feats, seeded_state_dict
+    lin = lambda o: (o * torch.linspace(-1, 1, o.numel()).view_as(o)).sum()  # noqa: E731
+    for c in HEAD_CASES:
+        fmap = seeded_feats(c["fseed"], [(c["N"], c["C"], c["T"], c["H"], c["W"])])[0]
+        out = {"config": np.array(json.dumps(c))}
+        for tag, classes, pool, act in (("kf", c["classes_kf"], (1, 7, 7), "softmax_1"), ("sc", c["classes_sc"], (c["T"], 7, 7), "softmax_2")):
+            head = rh.ref_pnr_head(classes, pool, act)
+            head.load_state_dict(seeded_state_dict(head, c["wseed"]))
+            out[f"sd_keys_{tag}"] = np.array(sd_keys(head))
+            head.train()
+            mid = head([fmap], middle=True)                     # (N, T', 8192)
+            out[f"mid_{tag}"] = mid.detach().numpy()
+            if tag == "kf":                                     # encode_clips_pnr: one row per input clip (lta_models_lta_transfer.py:335-345)
+                out["mid_kf_clipmean"] = mid.mean(dim=1).detach().numpy()
+            y = head([fmap])                                    # train mode: projection, no activation, permute(0, 2, 1)
+            out[f"proj_train_{tag}"] = y.detach().numpy()
+            head.zero_grad()
+            lin(y).backward()
+            digest({f"{tag}/{k}": p.grad for k, p in head.named_parameters()}, out)
+            head.eval()
+            with torch.no_grad():
+                out[f"proj_eval_{tag}"] = head([fmap]).numpy()
+        np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **out)
+        print("wrote", c["name"])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        {"hhi": run_hhi, "hoi": run_hoi}[sys.argv[1]]()
+        {"hhi": run_hhi, "hoi": lambda: (run_hoi(), run_head())}[sys.argv[1]]()
     else:  # HHI and HOI share top-level package names -> one process per tree
         for tree in ("hhi", "hoi"):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), tree])

@@ -15,10 +15,65 @@ pytestmark = pytest.mark.gpu
 
 
 def _head_ref(fmap, pool):
-    """The reference head's `middle=True` arithmetic in torch (fp64)."""
-    x = nn.AvgPool3d(pool, stride=1)(fmap.double())
-    x = x.permute((0, 2, 3, 4, 1))
-    return x.reshape(x.shape[0], x.shape[1], -1)
+    """The reference head's `middle=True` arithmetic: the oracle's restatement (fp64), itself pinned to the REAL
+    `ResNetKeyframeLocalizationHead` by tests/golden/pnrhead_*.npz (tests/test_oracle_golden.py)."""
+    return tr.pnr_head_forward(fmap.double(), pool)
+
+
+def test_pool_pack_and_drop_in_head_match_the_real_reference_head(egx_lib, cuda):
+    """One hop to the reference: `egx_pool_pack` / `PooledFeatureHead` against the outputs the REAL head
+    (HOI/models/pnr/head_helper.py:293-381, imported by tests/golden/make_golden.py) produced on the same seeded res5 map —
+    `middle=True` rows for kt = 1 and kt = T, the per-clip temporal mean of encode_clips_pnr, the projection + permute path in
+    train mode (with the projection's gradients) and with the eval-mode activation. fp32 throughout."""
+    import json
+    from egot2_amd.feature_sink import FeatureSink, PooledFeatureHead
+    from tests.test_oracle_golden import HEAD_FIXTURES, head_fixture_cases, load_fixture
+    assert HEAD_FIXTURES, "tests/golden/pnrhead_*.npz is missing"
+    lin = lambda o: (o * torch.linspace(-1, 1, o.numel(), device=o.device).view_as(o)).sum()  # noqa: E731
+    for name in HEAD_FIXTURES:
+        c, z = load_fixture(name)
+        fmap = seeded_feats(c["fseed"], [(c["N"], c["C"], c["T"], c["H"], c["W"])])[0].to(cuda)
+        for tag, classes, pool, act_dim in head_fixture_cases(c):
+            ref_mid = torch.from_numpy(z[f"mid_{tag}"])
+            # (1) the kernel itself, all rows
+            sink = FeatureSink(cuda, torch.float32)
+            sink.alloc("x", c["N"], ref_mid.shape[1], ref_mid.shape[2]).fill_(float("nan"))
+            got = sink.put_pooled_map("x", fmap, pool).cpu()
+            assert (got - ref_mid).abs().max().item() < 2e-6, (name, tag)
+            # (2) the drop-in head: same constructor arguments and state_dict keys as the reference head
+            head = PooledFeatureHead([c["C"]], classes, [list(pool)], dropout_rate=0.0, act_func=f"softmax_{act_dim}")
+            assert {k: list(v.shape) for k, v in head.state_dict().items()} == json.loads(str(z[f"sd_keys_{tag}"]))
+            head.load_state_dict(seeded_state_dict(head, c["wseed"]))
+            head = head.to(cuda).train()
+            mid = head([fmap], middle=True)
+            assert mid.dtype == torch.float32 and (mid.cpu() - ref_mid).abs().max().item() < 2e-6
+            y = head([fmap])
+            ref_y = torch.from_numpy(z[f"proj_train_{tag}"])
+            assert tuple(y.shape) == tuple(ref_y.shape) and (y.detach().cpu() - ref_y).abs().max().item() < 1e-4 * (1 + ref_y.abs().max().item())
+            lin(y).backward()
+            torch.cuda.synchronize()
+            for k, p in head.named_parameters():
+                g = p.grad.double().cpu().reshape(-1)
+                n_ref = float(z[f"gnorm/{tag}/{k}"])
+                assert abs(g.norm().item() - n_ref) < 1e-4 * n_ref, (name, tag, k)
+                h_ref = torch.from_numpy(z[f"ghead/{tag}/{k}"]).double()
+                assert (g[:h_ref.numel()] - h_ref).abs().max().item() < 1e-4 * (1 + h_ref.abs().max().item()), (name, tag, k)
+            head.eval()
+            with torch.no_grad():
+                ye = head([fmap])
+            assert (ye.cpu() - torch.from_numpy(z[f"proj_eval_{tag}"])).abs().max().item() < 1e-5
+        # (3) encode_clips_pnr: AvgPool + permute + per-clip `.mean(dim=1)` fused into token row i of a packed (N, n, 8192) stream
+        ref_cm = torch.from_numpy(z["mid_kf_clipmean"])
+        sink = FeatureSink(cuda, torch.float32)
+        sink.alloc("pnr", c["N"], 3, ref_cm.shape[1]).fill_(float("nan"))
+        for i in range(3):
+            sink.put_pooled_map("pnr", fmap, (1, 7, 7), token=i, frames_mean=True)
+        got = sink.get("pnr").cpu()
+        assert all((got[:, i] - ref_cm).abs().max().item() < 2e-6 for i in range(3))
+        s16 = FeatureSink(cuda, torch.bfloat16)      # what the wide path's projection GEMM reads in place: one bf16 rounding of the same rows
+        s16.alloc("pnr", c["N"], 1, ref_cm.shape[1])
+        got16 = s16.put_pooled_map("pnr", fmap, (1, 7, 7), token=0, frames_mean=True).float().cpu()[:, 0]
+        assert (got16 - ref_cm).abs().max().item() <= 2 ** -8 * ref_cm.abs().max().item() + 1e-6
 
 
 @pytest.mark.parametrize("N,C,T,H,W,pool", [(3, 2048, 4, 8, 8, (1, 7, 7)), (2, 192, 3, 7, 7, (1, 6, 6)), (2, 100, 5, 8, 8, (5, 7, 7)),
@@ -149,6 +204,35 @@ def test_backbone_stub_through_the_sink_equals_todays_forward_and_the_oracle(egx
     assert set(ga) == set(gb)
     for k in ga:
         assert (ga[k] - gb[k]).norm().item() <= 5e-2 * ga[k].norm().item() + 1e-7, k      # two bf16 roundings of the 8192-wide operand
+
+
+def test_two_forwards_before_backward_keep_their_own_sink_streams(egx_lib, cuda):
+    """the sink stream is refilled through a raw pointer; a second forward before the first one's backward must not
+    overwrite the features the first one's projections saved. Summed micro-batch gradients = gradients of the two runs apart."""
+    B, n, F, d, L = 2, 4, 2, 256, 1
+    g = torch.Generator().manual_seed(17)
+    xa = torch.randn(B, n, 2048, F, 8, 8, generator=g).to(cuda)
+    xb = torch.randn(B, n, 2048, F, 8, 8, generator=g).to(cuda)
+    act, lta = [f.to(cuda) for f in seeded_feats(18, [(B, n, d), (B, n, 2048)])]
+    lin = lambda out: sum((t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum() for t in out)  # noqa: E731
+    m, _ = _lta_model(cuda, n, d, L)
+    m.enable_feature_sink(torch.bfloat16)
+    grads = []
+    for x in (xa, xb):
+        m.zero_grad()
+        lin(m([act, lta], x)).backward()
+        grads.append(m.proj_pnr.weight.grad.clone())
+    m.zero_grad()
+    la = lin(m([act, lta], xa))
+    pa = m._sink.get("pnr").data_ptr()
+    lb = lin(m([act, lta], xb))                 # second forward BEFORE the first backward
+    assert m._sink.get("pnr").data_ptr() != pa
+    (la + lb).backward()
+    want = grads[0] + grads[1]
+    assert (m.proj_pnr.weight.grad - want).norm().item() <= 2e-3 * want.norm().item()
+    with torch.no_grad():                       # inference keeps reusing one buffer
+        m([act, lta], xa); p1 = m._sink.get("pnr").data_ptr()
+        m([act, lta], xb); assert m._sink.get("pnr").data_ptr() == p1
 
 
 def test_pooled_head_projection_path_and_cache_roundtrip(egx_lib, cuda, tmp_path):

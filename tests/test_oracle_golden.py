@@ -179,7 +179,9 @@ def oracle_run(c, sd, feats, dtype=torch.float64):
     raise KeyError(c["kind"])
 
 
-FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+ALL_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+HEAD_FIXTURES = [n for n in ALL_FIXTURES if n.startswith("pnrhead_")]      # row F4: the PNR / OSCC head (producer side)
+FIXTURES = [n for n in ALL_FIXTURES if n not in HEAD_FIXTURES]
 
 
 def check_against_fixture(z, outs, loss, grads, tol_out, tol_grad, tol_dec=None):
@@ -221,6 +223,43 @@ def test_oracle_matches_reference_fixture(name):
     loss.backward()
     grads = {k: v.grad for k, v in sdd.items() if v.grad is not None}
     check_against_fixture(z, outs, loss, grads, tol_out=2e-5, tol_grad=2e-4)
+
+
+def head_fixture_cases(c):
+    """(tag, classes, pool, softmax dim of the eval-mode activation AFTER the projection, i.e. on (N, T', classes))"""
+    return (("kf", c["classes_kf"], (1, 7, 7), 1), ("sc", c["classes_sc"], (c["T"], 7, 7), 2))
+
+
+@pytest.mark.parametrize("name", HEAD_FIXTURES)
+def test_oracle_head_matches_reference_fixture(name):
+    """Row F4 producer side: oracle.pnr_head_forward against the REAL ResNetKeyframeLocalizationHead's recorded outputs
+    (middle=True rows for kt = 1 and kt = T, the per-clip mean, projection in train and eval mode, projection gradients)."""
+    c, z = load_fixture(name)
+    fmap = seeded_feats(c["fseed"], [(c["N"], c["C"], c["T"], c["H"], c["W"])])[0]
+    lin = lambda o: (o * torch.linspace(-1, 1, o.numel(), dtype=o.dtype).view_as(o)).sum()  # noqa: E731
+    for tag, classes, pool, act_dim in head_fixture_cases(c):
+        head = torch.nn.Module()
+        head.projection = torch.nn.Linear(8192, classes)
+        assert {k: list(v.shape) for k, v in head.state_dict().items()} == json.loads(str(z[f"sd_keys_{tag}"]))
+        sd = {k: v.double().requires_grad_(True) for k, v in seeded_state_dict(head, c["wseed"]).items()}
+        mid = tr.pnr_head_forward(fmap.double(), pool)
+        ref_mid = torch.from_numpy(z[f"mid_{tag}"]).double()
+        assert mid.shape == ref_mid.shape and (mid - ref_mid).abs().max().item() < 2e-6
+        if tag == "kf":
+            cm = tr.pnr_head_forward(fmap.double(), pool, clip_mean=True)
+            assert (cm - torch.from_numpy(z["mid_kf_clipmean"]).double()).abs().max().item() < 2e-6
+        y = tr.pnr_head_forward(fmap.double(), pool, sd["projection.weight"], sd["projection.bias"], middle=False)
+        ref_y = torch.from_numpy(z[f"proj_train_{tag}"]).double()
+        assert y.shape == ref_y.shape and (y - ref_y).abs().max().item() < 2e-5
+        lin(y).backward()
+        for k in ("projection.weight", "projection.bias"):
+            g = sd[k].grad.reshape(-1)
+            assert abs(g.norm().item() - float(z[f"gnorm/{tag}/{k}"])) < 2e-5 * float(z[f"gnorm/{tag}/{k}"])
+            head_ref = torch.from_numpy(z[f"ghead/{tag}/{k}"]).double()
+            assert (g[:head_ref.numel()] - head_ref).abs().max().item() < 2e-5 * (1.0 + head_ref.abs().max().item())
+        with torch.no_grad():
+            ye = tr.pnr_head_forward(fmap.double(), pool, sd["projection.weight"], sd["projection.bias"], middle=False, act_dim=act_dim)
+        assert (ye - torch.from_numpy(z[f"proj_eval_{tag}"]).double()).abs().max().item() < 2e-6
 
 
 def test_stock_module_matches_fixture():
