@@ -94,9 +94,63 @@ def _build(srcs, OBJ_DIR, LIB_PATH, force, verbose) -> str:
     return LIB_PATH
 
 
+# ---- host-side sanitizer build -------------------------------------------------------------------------
+# The C++ orchestration (workspace layouts, configuration validation, error paths, the RCCL binding) runs on the host and can be
+# exercised without a GPU. build_sanitized() recompiles exactly those translation units with AddressSanitizer + UBSan on the HOST side
+# (-fno-gpu-sanitize: GPU ASAN / XNACK are not available on this pool and are never asked for) and links them with the ordinary
+# objects of the rest; tests/test_cpu_host.py runs the host-only entry points against it in a subprocess with the ASAN runtime preloaded.
+SANITIZED_SOURCES = ["encoder.hip", "wide_host.hip", "wide_decoder.hip", "comm.hip"]
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g"]
+
+
+def asan_runtime() -> str:
+    import glob
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not hits:
+        raise RuntimeError("libclang_rt.asan-x86_64.so not found under /opt/rocm/lib/llvm")
+    return hits[-1]
+
+
+def build_sanitized(verbose: bool = False) -> str:
+    build(verbose=verbose)                      # the ordinary objects of every other translation unit
+    hipcc = _hipcc()
+    obj_dir = os.path.join(CSRC, "_obj", "asan")
+    lib_path = os.path.join(PKG_DIR, "_variants", "lib_asan.so")
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
+    flags = SAN_FLAGS + [f for f in FLAGS if f != "-O3"] + ["-O1"]
+    objs, rebuilt = [], False
+    for s in SOURCES:
+        plain = os.path.join(CSRC, "_obj", s.replace(".hip", ".o"))
+        if s not in SANITIZED_SOURCES:
+            objs.append(plain)
+            continue
+        src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s.replace(".hip", ".o"))
+        stamp, dg = obj + ".sha", _digest([src] + hdr_paths) + "asan"
+        objs.append(obj)
+        if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dg:
+            continue
+        r = subprocess.run([hipcc] + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (sanitized) failed for {src}:\n{r.stdout}\n{r.stderr}")
+        open(stamp, "w").write(dg)
+        rebuilt = True
+    newest = max(os.path.getmtime(o) for o in objs)
+    if rebuilt or not os.path.exists(lib_path) or os.path.getmtime(lib_path) < newest:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", lib_path] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (sanitized) failed:\n{r.stdout}\n{r.stderr}")
+    return lib_path
+
+
 if __name__ == "__main__":
     # python -m egot2_amd.build [--force] [--variant NAME -DFLAG ...]
     argv = sys.argv[1:]
+    if "--sanitize" in argv:
+        print(build_sanitized(verbose=True))
+        sys.exit(0)
     variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
     extra = [a for a in argv if a.startswith("-D") or a.startswith("-m") or a.startswith("-f")]
     print(build(force="--force" in argv, verbose=True, variant=variant, extra_flags=extra))

@@ -439,6 +439,7 @@ static int linear_dw(const float* dy, const float* x, float* dW, int M, int N, i
 
 int debug_read_ppstamps(unsigned long long* out);       // wide_gemm.hip (development aid)
 int debug_read_cstamps(unsigned long long* out);        // ffn_cut.hip (development aid)
+int debug_read_sstamps(unsigned long long* out);        // small_dw_kernel (development aid)
 
 }  // namespace egx
 
@@ -448,7 +449,7 @@ extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
-int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : n == -3000 ? debug_read_cstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
+int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : n == -3000 ? debug_read_cstamps(out) : n == -4000 ? debug_read_sstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
 int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }
 int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }

@@ -844,10 +844,21 @@ int seed_advance(uint64_t* seed, hipStream_t st) {
 // G[32][64] and X[32][128] in LDS (coalesced, next block prefetched in registers); wave w owns rows 16w..16w+15 and
 // gathers its A fragment (and the 8 B fragments) transposed from the token-major tiles. Partials are atomically
 // added into the zero-initialised gradient buffers (<= `splits` adders per element).
+__device__ unsigned long long g_sstamps[16];
+#ifdef EGX_STAMPS
+#define SSTAMP(i) do { if (blockIdx.x == EGX_SSTAMP_BLOCK && threadIdx.x == 0) g_sstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef EGX_SSTAMP_BLOCK
+#define EGX_SSTAMP_BLOCK 0
+#endif
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+int debug_read_sstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sstamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1; }
 template <int CM, bool TAIL>
 __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwTail tl) {
     constexpr int LDG = 64 + 4, LDXS = 128 + 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LDG + 32 * LDXS)];
+    SSTAMP(0);
     if constexpr (TAIL) {
         // The FFN weight-gradient slabs and the per-clip partial rows are summed here, 1 / grid of the units per workgroup, before
         // the workgroup's own GEMM work: the reduction launch of its own cost 14 us of mostly exposed latency. (As EXTRA
@@ -858,6 +869,7 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
             __syncthreads();
         }
     }
+    SSTAMP(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     int pi = 0;
@@ -949,10 +961,13 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
                 mma<CM_SPLIT>(acc[j], a, b);
             }
         };
+        SSTAMP(2);
         for (int kb = kb_beg; kb < kb_end; kb += 2) {
             block(kb, pgA, pxA);
+            if (kb == kb_beg) SSTAMP(3);
             if (kb + 1 < kb_end) block(kb + 1, pgB, pxB);
         }
+        SSTAMP(4);
     } else {
     auto block = [&](int kb, int cur, float4 (&pg)[2], float4 (&px)[4]) {
         float* gt = lds + cur * (32 * LDG + 32 * LDXS);
@@ -987,6 +1002,9 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
             int row = row0 + wave * 16 + 4 * q + e, col = col0 + j * 16 + r;
             if (row < pr.R && col < pr.C) atomicAdd(pr.out + (size_t)row * pr.C + col, acc[j][e]);
         }
+    SSTAMP(5);
+    __builtin_amdgcn_s_waitcnt(0);
+    SSTAMP(6);
 }
 
 // out[row][col] += sum over the splits of one (problem, item) of its slab tiles, in split order. grid.x = work items, 8 blocks each.

@@ -312,6 +312,7 @@ int pos_grad_accum(const float* dtok, int B, int S, int off, int T, int d, float
                    uint64_t key, uint32_t thresh, float inv_keep, hipStream_t st) {
     if (T <= 0 || d <= 0) return 0;
     EGX_CHECK(d % 4 == 0 && d <= 1024 && pos_stride % 4 == 0, "pos_grad: d = %d (multiple of 4, <= 1024), pos_stride = %d", d, pos_stride);
+    EGX_CHECK((((uintptr_t)dtok) & 15) == 0 && (((uintptr_t)dpos) & 15) == 0, "pos_grad: d_tokens and the positional gradient must be 16-byte aligned (float4 accesses)");
     hipLaunchKernelGGL(pos_grad_kernel, dim3(T), dim3(256), 0, st, dtok, B, S, off, T, d, dpos, pos_stride,
                        key, thresh, inv_keep);
     EGX_LAUNCH_CHECK();

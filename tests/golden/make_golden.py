@@ -7,7 +7,8 @@ gradient digests are stored) travel with the repo.
     python tests/golden/make_golden.py            # regenerates every *.npz here
 
 Each fixture stores: the config (JSON), the weight/feature seeds, the reference outputs, a scalar loss, and for every
-trainable parameter the gradient's L2 norm, sum and first 64 entries (full gradient when it has <= 4096 entries).
+trainable parameter the gradient's L2 norm, sum and first 64 entries (full gradient when it has <= 4096 entries);
+ttm3_B4_T15_L1 (the bench configuration at B = 4) also the WHOLE gradients of linear1 / linear2 / in_proj as scaled fp16.
 Weights: tests/util.seeded_state_dict(model, seed); features: tests/util.seeded_feats(seed, shapes).
 """
 import json
@@ -64,12 +65,19 @@ def sd_keys(m):
     return json.dumps({k: list(v.shape) for k, v in m.state_dict().items()})
 
 
-def digest(grads, out):
+def digest(grads, out, full=()):
+    """`full`: substrings of parameter names whose WHOLE gradient is stored too (fp16 of g / max|g| + the scale: 2.5e-4 of the
+    largest entry per element) - a one-hop per-element check of the large weight gradients against the reference."""
+    import numpy as np
     for k, g in grads.items():
         g = g.detach().double().reshape(-1)
         out[f"gnorm/{k}"] = g.norm().numpy()
         out[f"gsum/{k}"] = g.sum().numpy()
         out[f"ghead/{k}"] = (g if g.numel() <= 4096 else g[:64]).float().numpy()
+        if any(f in k for f in full):
+            scale = g.abs().max().clamp_min(1e-30)
+            out[f"gfull_scale/{k}"] = scale.numpy()
+            out[f"gfull/{k}"] = (g / scale).numpy().astype(np.float16).reshape(tuple(grads[k].shape))
 
 
 def run_hhi():
@@ -117,7 +125,9 @@ def run_hhi():
         m.zero_grad()
         loss.backward()
         out["loss"] = loss.detach().numpy()
-        digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, out)
+        # the bench configuration's fixture carries the FULL gradients of its three large matrices (FFN, in-projection)
+        full = ("linear1.weight", "linear2.weight", "in_proj_weight") if c["name"] == "ttm3_B4_T15_L1" else ()
+        digest({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, out, full)
         np.savez_compressed(os.path.join(HERE, c["name"] + ".npz"), **out)
         print("wrote", c["name"], "loss", float(loss))
 

@@ -42,6 +42,33 @@ def test_workspace_query_and_config_errors(egx_lib):
     assert egx_lib.egx_encoder_workspace(C.byref(cfg), segs, 0, C.byref(sv), C.byref(sc)) != 0   # empty batch
 
 
+def test_host_entry_points_sweep(egx_lib):
+    """tests/host_paths.py on the product library: every implementation's workspace layout over shapes, compute modes and batches,
+    the implementation / slice policy, the error paths, the decoder layouts, the RCCL binding's resolver."""
+    from egot2_amd import _lib
+    from tests import host_paths
+    assert host_paths.exercise(host_paths.bind(_lib.LIB_PATH)) > 10000
+
+
+def test_host_code_under_address_and_ub_sanitizers():
+    """SURVEY.md §5 / VERDICT r4 item 9d: the same sweep against a build whose C++ orchestration (encoder.hip, wide_host.hip,
+    wide_decoder.hip, comm.hip) is compiled with AddressSanitizer + UBSan on the HOST side (egot2_amd/build.py build_sanitized;
+    -fno-gpu-sanitize: no GPU ASAN, no XNACK), in a subprocess with the ASAN runtime preloaded and without torch. Any report —
+    an out-of-bounds read of a layout table, a signed overflow in a size computation, a misaligned access — aborts the child."""
+    import subprocess
+    import sys
+    from egot2_amd import build as egx_build
+    lib = egx_build.build_sanitized()
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout
+    assert "__asan_init" in syms and "__ubsan_handle" in syms, "the sanitized build carries no sanitizer instrumentation"
+    env = dict(os.environ, LD_PRELOAD=egx_build.asan_runtime(), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", PYTHONPATH=ROOT)
+    env.pop("EGX_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_paths.py"), lib], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "host paths ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
 def test_workspace_sizes_above_2_gib_are_not_truncated(egx_lib):
     """C4 at B=256 (HOI LTA 4-task, S=128, d=768, 4 layers) keeps > 4 GiB of intermediates: the size must come back
     intact (an unqualified max() in hipcc host code resolves to max(int, int) and used to return 0 here)."""

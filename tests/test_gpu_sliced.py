@@ -170,7 +170,7 @@ def test_exchange_litmus_shipped_protocol_never_reads_stale_words_and_shows_what
     barrier, outside the HIP memory model. tools/micro/slice_litmus.hip runs the product's OWN slice_publish / slice_wait / slice_gather
     as producer / consumer workgroup pairs on neighbouring XCDs while NOISE workgroups keep the fabric and the memory channels busy
     (on an idle chip the flag never overtakes its data, with or without the wait). The shipped protocol must never deliver a stale
-    word (hard assertion, 3 x 38 400 published blocks). The same program built WITHOUT the s_waitcnt (-DEGX_LITMUS_NO_WAITCNT) runs
+    word (hard assertion, 3 x 32 000 published blocks). The same program built WITHOUT the s_waitcnt (-DEGX_LITMUS_NO_WAITCNT) runs
     beside it: it does deliver stale words (profiles/r05_slice_litmus.txt: 320 - 832 per 19 200 blocks at 256 - 512 noise workgroups)
     — the demonstration that this test sees the bug the wait guards against. That second half is timing-dependent, so by default a run
     in which the reordering does not show up only warns; EGX_LITMUS_STRICT=1 (how the committed profile was made) asserts it."""
@@ -189,7 +189,9 @@ def test_exchange_litmus_shipped_protocol_never_reads_stale_words_and_shows_what
         exes[name] = exe
 
     def run(name, noise):
-        out = subprocess.run([exes[name], "128", "100", "3", "8", str(noise), "2"], capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
+        # 64 pairs = 128 workgroups of 101 KB LDS: half the CUs, so that the noise workgroups are RESIDENT BESIDE them (with 128 pairs the
+        # pairs fill the chip, the noise runs after them and nothing is ever reordered: gpurun call r5k)
+        out = subprocess.run([exes[name], "64", "100", "5", "8", str(noise), "2"], capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
         print(out)
         tok = out.split()
         return {tok[i]: tok[i + 1] for i in range(0, len(tok) - 1, 2)}

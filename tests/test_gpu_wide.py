@@ -408,3 +408,62 @@ def test_hoi_egot2g_encoder_real_dimensions(egx_lib, cuda, compute, tol_out, tol
     assert len(errs) > 30
     bad = {k: v for k, v in errs.items() if not v < tol_grad}
     assert not bad, bad
+
+
+def test_c4_at_bench_batch_against_the_oracle_on_sampled_clips(egx_lib, cuda):
+    """BASELINE.json configs[3] at the batch `bench.py --config c4` times (B = 256, S = 128, d = 768, 8 heads of
+    96, 4 layers, 8192-wide features) UNDER A CHECKER. Clips are independent units, so the fp64 oracle is run on three sampled clips
+    only: the wide path's outputs for those rows of the 256-clip launch must match it, and with a loss that reads only those clips'
+    outputs every parameter gradient of the full-size launch (its grids, token splits and slab reductions are those of B = 256; the
+    other 253 clips contribute exact zeros) must equal the oracle's gradient on the three clips."""
+    from egot2_amd import hoi_lta
+    B, pick = 256, [0, 101, 255]
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(_lta_cfg(32, 768, 8, 4))
+    sd = seeded_state_dict(m, 33)
+    m.load_state_dict(sd)
+    m = m.to(cuda).set_compute("bf16").train()
+    feats = seeded_feats(901, [(B, 32, 8192), (B, 32, 8192), (B, 32, 768), (B, 32, 2048)])
+    outs = m.forward_features(*[f.to(cuda) for f in feats])
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    idx = torch.tensor(pick, device=cuda)
+    (lin(outs[0][idx]) + lin(outs[1][idx])).backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = tr.lta4_forward(sd64, 8, *[f[pick].double() for f in feats], [5, 7])
+    (lin(ref[0]) + lin(ref[1])).backward()
+    for o, r in zip(outs, ref):
+        assert (o[idx].detach().cpu().double() - r.detach()).abs().max().item() < 1e-2 * max(1.0, r.abs().max().item())
+    errs = _grad_errs(m, sd64)
+    bad = {k: v for k, v in errs.items() if not v < 6e-2}
+    assert len(errs) > 40 and not bad, bad
+
+
+def test_c5_hoi_encoder_at_bench_batch_against_the_oracle_on_sampled_clips(egx_lib, cuda):
+    """The same full-size check for BASELINE.json configs[4] (HOI EgoT2-g encoder, d = 512, 8 heads of 64, 3 layers, 48 tokens) at
+    B = 256 in bf16: memory rows and parameter gradients of the 256-clip launch against the fp64 oracle on three sampled clips."""
+    from tests.test_oracle_golden import build_ours
+    B, pick = 256, [3, 128, 254]
+    c = dict(kind="hoig", B=B, n=3, L=3, d=512, h=8, wseed=211, fseed=212)
+    model = build_ours(c)
+    sd = seeded_state_dict(model, c["wseed"])
+    model.load_state_dict(sd)
+    model = model.to(cuda).set_compute("bf16").train()
+    model.pos_embed.dropout.p = 0.0
+    feats = seeded_feats(902, [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)])
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    out = model.encode_features("pnr", *[f.to(cuda) for f in feats])            # (48, B, 512)
+    assert out.shape == (48, B, 512)
+    idx = torch.tensor(pick, device=cuda)
+    lin(out[:, idx].contiguous()).backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    ref = tr.hoi_g_encode(sd64, 8, "pnr", *[f[pick].double() for f in feats])
+    lin(ref).backward()
+    assert (out[:, idx].detach().cpu().double() - ref.detach()).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item())
+    errs = {}
+    for k, p in model.named_parameters():
+        r = sd64[k].grad if k in sd64 else None
+        if r is not None and p.grad is not None:
+            errs[k] = (p.grad.detach().cpu().double() - r).norm().item() / (r.norm().item() + 1e-12)
+    bad = {k: v for k, v in errs.items() if not v < 6e-2}
+    assert len(errs) > 30 and not bad, bad

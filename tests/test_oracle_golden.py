@@ -206,6 +206,16 @@ def check_against_fixture(z, outs, loss, grads, tol_out, tol_grad, tol_dec=None)
         e_head = (g[:head.numel()] - head).norm().item() / (head.norm().item() + typical + 1e-12)
         e_norm = abs(g.norm().item() - n_ref) / (n_ref + 1e-12)
         assert e_norm < tol_grad and e_head < 3 * tol_grad, f"{k}: norm err {e_norm}, head err {e_head}"
+        if "gfull/" + k in z.files:
+            # ONE hop to the reference for every element of the large weight gradients: the fixture holds
+            # g / max|g| in fp16 (2^-11 of the largest entry per element). A permutation or a dropped block past the stored
+            # head that preserved norm and sum would show up here.
+            scale = float(z["gfull_scale/" + k])
+            full = torch.from_numpy(z["gfull/" + k].astype("float32")).double().reshape(-1) * scale
+            assert full.numel() == g.numel(), k
+            e_max = (g - full).abs().max().item() / scale
+            e_l2 = (g - full).norm().item() / full.norm().item()
+            assert e_max < max(3 * tol_grad, 2 ** -10) and e_l2 < max(tol_grad, 2 ** -10), f"{k}: full-gradient max err {e_max} (of max|g|), L2 err {e_l2}"
 
 
 @pytest.mark.parametrize("name", FIXTURES)
