@@ -71,7 +71,7 @@ def parse_args(argv=None):
     ap.add_argument("--impl", default="auto", choices=["auto", "generic", "fused", "wide", "tiled"])
     ap.add_argument("--dropout", type=float, default=None, help="encoder dropout (default: the reference recipe of the configuration)")
     ap.add_argument("--optimizer", action="store_true", help="run the Adam update inside the timed step (headline excludes it by default)")
-    ap.add_argument("--graph", action="store_true", help="capture the step into one hipGraph also where eager launches are the default (c5hoi)")
+    ap.add_argument("--graph", action="store_true", help="(default since round 5: every configuration replays as one hipGraph; kept for old command lines)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one captured hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-line", action="store_true", help="skip the separate fwd+bwd+Adam measurement")
@@ -303,10 +303,10 @@ def run(args) -> int:
 
     # device-resident dropout seed: the per-clip / tiled kernels derive their keys in-kernel, the wide bf16 path and the fused
     # decoder from a key table computed on the stream (round 4) - every configuration replays as one hipGraph
-    # (c5hoi - 225 launches with many side-stream forks in the decoder's backward - measures 7-10 % SLOWER as one graph than with
-    # eager launches, c5hhi 11 % faster, c4 equal: profiles/r04_wide_graph.txt; eager stays its default, --graph forces the capture)
-    fused_graph_ok = wl["name"] != "c5hoi" or args.graph
-    use_graph = not args.no_graph and fused_graph_ok
+    # (round 4: c5hoi measured 7-10 % slower as one graph than with eager launches - the decoder backward's side-stream forks became
+    # graph branches; round 5: under capture its weight gradients leave as one grouped launch instead (wide_gemm.hip wide_tn_queue_*)
+    # and the captured step is the faster one, 3.68 vs 3.83 ms: profiles/r05_dec_group.txt. --no-graph keeps eager launches.)
+    use_graph = not args.no_graph
     if use_graph:
         model.enable_device_seed()
     opt = FusedAdam(params, lr=5e-4) if args.optimizer else None     # Adam(lr=5e-4): video_task_2loader.py:62-64

@@ -40,6 +40,13 @@ struct WideReduceDesc { const float* slabs; float* C; size_t stride; int splits,
 constexpr int WIDE_REDUCE_MAX = 40;
 struct WideReduceBatch { WideReduceDesc d[WIDE_REDUCE_MAX]; int n = 0, total_blocks = 0; };
 int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer = nullptr);
+// grouped weight-gradient launches (wide_gemm.hip): independent TN problems queued by tile variant, one grid per variant at the flush
+struct WideTnDesc { const bf16_t* A; const bf16_t* B; float* slabs; size_t slab_stride; int M, N, K, lda, ldb, ntM, ntN, kps, splits, first_block; };
+constexpr int WIDE_TN_GROUP_MAX = 40;
+struct WideTnGroup { WideTnDesc d[WIDE_TN_GROUP_MAX]; const void* zero_page = nullptr; int n = 0, epi_lds = 0; };
+struct WideTnQueue { WideTnGroup g[3]; int blocks[3] = {0, 0, 0}; };
+int wide_tn_queue_add(WideTnQueue& Q, const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer);
+int wide_tn_queue_flush(WideTnQueue& Q, hipStream_t st);
 int wide_reduce_flush(WideReduceBatch& b, hipStream_t st);
 
 // dst[r][c] = bf16(src[r][c]) and / or dst_t[c][r] = bf16(src[r][c]); src (R, ld) fp32

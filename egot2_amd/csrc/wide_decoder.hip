@@ -826,7 +826,16 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
 
     WideReduceBatch rb;
     size_t slab_cur = 0;
-    // (enqueued on the side stream; the caller forks first)
+    // Round 5: the weight gradients are QUEUED and leave as one grouped launch per tile variant at the end of the call (wide_gemm.hip
+    // wide_tn_queue_*): 35 launches of 14 us each over 512 target rows become one or two grids that fill the chip. Their operands sit in
+    // per-(layer, use) buffers until then. Used where the side stream is not (a captured step, EGX_DEC_SIDE=0): with eager launches the
+    // side stream already hides these GEMMs beside the target-token chain and grouping them at the end measured 1.4 % slower (C5 HOI
+    // 3.80 -> 3.86 ms); captured, C5 HHI 2.42 -> 2.26 ms (profiles/r05_dec_group.txt). EGX_DEC_GROUP=0 / 1 forces either.
+    WideTnQueue tq;
+    static int group_env = -2;
+    if (group_env == -2) { const char* e = getenv("EGX_DEC_GROUP"); group_env = e ? atoi(e) : -1; }
+    const bool grouped = group_env >= 0 ? group_env != 0 : !side;
+    // (ungrouped: enqueued on the side stream; the caller forks first)
     auto dw_tn = [&](const bf16_t* dy, int ldy, const bf16_t* x, int ldx, float* dW, int n_out, int k_in, int tokens_k) -> int {
         if (!dW) return 0;
         WideGemmParams t;
@@ -847,6 +856,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         EGX_CHECK(slab_cur + need <= pl.slab_all_bytes, "decoder backward: slab region exhausted");
         void* region = at<char>(scratch, pl.slab_all) + slab_cur;
         slab_cur += need;
+        if (grouped && !t.tn_max_splits) return wide_tn_queue_add(tq, t, region, st, &rb);
         return wide_gemm_tn(t, region, sd, &rb);
     };
     auto nt = [&](const bf16_t* A, int lda, const bf16_t* Wt, int M, int N, int K, float* Cf, bf16_t* Cb, const float* residual,
@@ -988,6 +998,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
                                de.key, de.thresh, de.inv);
         EGX_LAUNCH_CHECK();
     }
+    if (wide_tn_queue_flush(tq, st)) return 1;      // every queued weight gradient: one grid per tile variant, then their slab sums
     return wide_reduce_flush(rb, st);
 }
 

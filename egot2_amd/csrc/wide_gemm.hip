@@ -745,8 +745,10 @@ int wide_gemm_nt(const WideGemmParams& p_in, hipStream_t st) {
 // BM x BN output tile (BM columns of dY against BN columns of X), (BM / WTM) x (BN / 64) waves of WTM x 64, ring of D stages
 // as above. A stage holds BM / 128 dY images and BN / 128 X images, each [64 tokens][128 columns] (256-byte rows).
 // Variants: 256 x 128 / 128 x 128 (wave 64 x 64) and 256 x 256 (wave 128 x 64, 2 stages): 1.5x fewer operand bytes per FLOP.
+// (the body takes the tile and split ids as arguments: wide_gemm_tn_kernel passes its block ids, the GROUPED launch those of the
+// problem the workgroup belongs to)
 template <int BM, int BN, int WTM, int D>
-__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
+__device__ __forceinline__ void tn_tile(const WideGemmParams& p, int tile_id, int split, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
     constexpr int WM = BM / WTM, NW = WM * (BN / 64);               // waves along m, waves
     constexpr int NIY = BM / 128, NIX = BN / 128, NI = NIY + NIX;   // images per stage
     constexpr int TJ = WTM / 16;
@@ -756,9 +758,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_k
     static_assert(NI * 16 % NW == 0, "staging instructions must divide among the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = xcd_tile(blockIdx.x, ntM * ntN);
+    const int t = tile_id;
     const int m0 = (t / ntN) * BM, n0 = (t % ntN) * BN;
-    const int split = blockIdx.y;
     const int kbeg = split * kps, kend = min(p.K, kbeg + kps);
 
     // staging: 4 token rows (256 B each) of one image per instruction
@@ -854,6 +855,26 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_k
             *reinterpret_cast<float4*>(out + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
     }
+}
+
+template <int BM, int BN, int WTM, int D>
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
+    tn_tile<BM, BN, WTM, D>(p, xcd_tile(blockIdx.x, ntM * ntN), blockIdx.y, ntM, ntN, kps, slabs, slab_stride);
+}
+
+// GROUPED launch: up to WIDE_TN_GROUP_MAX independent weight-gradient problems of ONE tile variant as one grid (workgroup ->
+// problem by prefix sums of their tile x split counts). The EgoT2-g decoder's backward issued 35 such GEMMs over its 512 target rows
+// per step, 14 us each and almost all of it launch latency and pipeline fill (profiles/r04_bench_c5hhi_kernel_stats.csv): together
+// they are ~15 GFLOP — one launch that fills the chip. Their operands live in per-(layer, use) buffers until the call returns.
+template <int BM, int BN, int WTM, int D>
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_grouped_kernel(WideTnGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.d[i + 1].first_block) ++i;
+    const WideTnDesc& q = g.d[i];
+    const int local = blockIdx.x - q.first_block, tiles = q.ntM * q.ntN;
+    WideGemmParams p;
+    p.A = q.A; p.B = q.B; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.zero_page = g.zero_page; p.epi_lds = g.epi_lds;
+    tn_tile<BM, BN, WTM, D>(p, local % tiles, local / tiles, q.ntM, q.ntN, q.kps, q.slabs, q.slab_stride);
 }
 
 // C[m][n] (+)= sum_s slab[s][m][n], fixed order
@@ -955,6 +976,64 @@ static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs,
     hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, BN, WTM, D>), dim3(ntM * ntN, splits), dim3(THREADS), LDS, st, p, ntM, ntN, kps, slabs, slab_stride);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BM, int BN, int WTM, int D>
+static int launch_tn_grouped(const WideTnGroup& g, int blocks, hipStream_t st) {
+    constexpr int LDS = D * (BM / 128 + BN / 128) * TBK * 128 * 2;
+    constexpr int THREADS = (BM / WTM) * (BN / 64) * 64;
+    static bool attr = false;
+    if (!attr) {
+        EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_grouped_kernel<BM, BN, WTM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = true;
+    }
+    timing_begin(TIMER_WIDE_GEMM, st);
+    hipLaunchKernelGGL((wide_gemm_tn_grouped_kernel<BM, BN, WTM, D>), dim3(blocks), dim3(THREADS), LDS, st, g);
+    timing_end(TIMER_WIDE_GEMM, st);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// queue one weight-gradient problem for the grouped launch of its tile variant (the slab reduction is queued in `defer` as
+// wide_gemm_tn does); `scratch` = this problem's own slab region. wide_tn_queue_flush() launches what is queued: ONE grid per variant.
+int wide_tn_queue_add(WideTnQueue& Q, const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer) {
+    EGX_CHECK(p.A && p.B && p.Cf && scratch && p.zero_page && defer, "wide_tn_queue_add: null operand");
+    EGX_CHECK(p.M % TBM == 0 && p.N % TBN == 0 && p.K > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0,
+              "wide_tn_queue_add: %dx%dx%d needs M, N multiples of 128 and 16-byte aligned rows", p.M, p.N, p.K);
+    int kps = 0;
+    int splits = tn_splits(p.M, p.N, p.K, &kps);
+    const int v = tn_variant(p.M, p.N);
+    WideTnGroup& g = Q.g[v];
+    if (g.n == WIDE_TN_GROUP_MAX && wide_tn_queue_flush(Q, st)) return 1;
+    if (defer->n == WIDE_REDUCE_MAX) {       // the reduction reads slabs the queued GEMMs have not written yet: flush them first
+        if (wide_tn_queue_flush(Q, st) || wide_reduce_flush(*defer, st)) return 1;
+    }
+    g.zero_page = p.zero_page; g.epi_lds = epi_lds_mode();
+    WideTnDesc& q = g.d[g.n++];
+    q.A = p.A; q.B = p.B; q.M = p.M; q.N = p.N; q.K = p.K; q.lda = p.lda; q.ldb = p.ldb;
+    q.ntM = p.M / (v ? 256 : 128); q.ntN = p.N / (v == 2 ? 256 : TBN); q.kps = kps; q.splits = splits;
+    q.slabs = (float*)scratch; q.slab_stride = (size_t)p.M * p.N;
+    q.first_block = Q.blocks[v];
+    Q.blocks[v] += q.ntM * q.ntN * splits;
+    // the slab reduction (even a single slab goes through it: C (+)= slab), batched by the caller
+    const size_t n4 = q.slab_stride / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    WideReduceDesc& r = defer->d[defer->n++];
+    r.slabs = q.slabs; r.stride = q.slab_stride; r.splits = splits; r.C = p.Cf; r.ldc = p.ldc; r.M = p.M; r.N = p.N;
+    r.accumulate = p.accumulate; r.first_block = defer->total_blocks; r.blocks = blocks;
+    defer->total_blocks += blocks;
+    return 0;
+}
+int wide_tn_queue_flush(WideTnQueue& Q, hipStream_t st) {
+    for (int v = 0; v < 3; ++v) {
+        if (!Q.g[v].n) continue;
+        int rc = v == 2 ? launch_tn_grouped<256, 256, 128, 2>(Q.g[v], Q.blocks[v], st)
+               : v == 1 ? launch_tn_grouped<256, 128, 64, 3>(Q.g[v], Q.blocks[v], st) : launch_tn_grouped<128, 128, 64, 4>(Q.g[v], Q.blocks[v], st);
+        if (rc) return rc;
+        Q.g[v].n = 0; Q.blocks[v] = 0;
+    }
     return 0;
 }
 
