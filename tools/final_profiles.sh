@@ -3,7 +3,7 @@
 # Bench lines, rocprofv3 kernel stats and PMC counters of every BASELINE configuration -> gpurun_out/final/ (copy what is to
 # be kept into profiles/). Every step checks its exit code: a failed bench never leaves a half-written JSON behind.
 set -euo pipefail
-R=${1:-r04}
+R=${1:-r05}
 STAGES=${2:-bench,prof,trace,pmc}      # which parts to run (run pmc first and copy its files into profiles/ when the bench lines are to carry the counters)
 OUT=gpurun_out/final
 mkdir -p $OUT
@@ -42,8 +42,13 @@ bench f32s_deterministic --deterministic --no-cpu-baseline --no-roofline --no-na
 bench f32s_forcedist --force-dist --no-cpu-baseline --no-roofline --no-native-line
 bench c4_forcedist --config c4 --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_forcedist --config c5hoi --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
-bench c5hoi_graph --config c5hoi --graph --no-cpu-baseline --no-roofline --steps 5 --warmup 2
-bench c5hoi_graph_forcedist --config c5hoi --force-dist --graph --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_eager --config c5hoi --no-graph --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+bench c5hoi_graph_forcedist --config c5hoi --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
+# cut mode (ffn_cut.hip) against the one-launch kernels, both ways round (default: cut for c2 f32s, one launch elsewhere)
+EGX_FFN_CUT=0 bench f32s_onelaunch --no-cpu-baseline --no-native-line
+EGX_FFN_CUT=1 bench bf16_cut --dtype bf16 --no-cpu-baseline
+EGX_FFN_CUT=1 bench c3_cut --config c3 --no-cpu-baseline
+EGX_DEC_GROUP=0 bench c5hhi_ungrouped --config c5hhi --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c4_graph_forcedist --config c4 --force-dist --graph-collectives --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 # small batches (sliced mode of the per-clip kernels): the reference sampler's own batch, and the per-GPU share of a strong-scaled B = 256 on 8 GPUs
 bench c2_b26 --batch 26 --no-cpu-baseline --no-roofline --no-native-line
