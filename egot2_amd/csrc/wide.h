@@ -87,13 +87,24 @@ struct WideLnBwdParams {
     float* dw = nullptr; float* db = nullptr; float* dbias = nullptr; float* dadd = nullptr;   // += targets (any may be null)
 };
 size_t wide_ln_bwd_scratch(int rows, int d);
-int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st);
+// Deferred row reductions (round 5): the second stage of every two-stage column sum of a backward — LayerNorm parameter gradients,
+// bias gradients from GEMM epilogues and from bf16 arrays — was a launch of its own (4.6-5.1 us each, 35 of them per EgoT2-g HHI
+// step: 7 % of it). With a batch they are queued and summed by ONE launch (wide_row_reduce_flush); every queued reduction needs a
+// partial buffer of its own that stays untouched until the flush.
+struct WideRowReduceDesc {
+    const float* part; float* o0; float* o1; float* o2; float* o3;      // kind 0: out o0 (ld / row_len); kind 1 (LayerNorm): dw, db, dbias, dadd
+    int nt, cols, d, kind, first_block, out_ld, row_len, pad_;
+};
+constexpr int WIDE_ROWRED_MAX = 48;
+struct WideRowReduceBatch { WideRowReduceDesc d[WIDE_ROWRED_MAX]; int n = 0, total_blocks = 0; };
+int wide_row_reduce_flush(WideRowReduceBatch& b, hipStream_t st);
+int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st, WideRowReduceBatch* defer = nullptr);
 
 // out[c] += sum_r x[r][c] over a bf16 (rows, ld) matrix, deterministic two-stage reduction; scratch >= wide_colsum_scratch
 size_t wide_colsum_scratch(int rows, int cols);
-int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st);
+int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st, WideRowReduceBatch* defer = nullptr);
 // out[c] += sum_t part[t][c], t < nt (fixed order)
-int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st);
+int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st, WideRowReduceBatch* defer = nullptr);
 
 // dpos[t * pos_stride + c] += sum_b mask .* dtok[(b * S + off + t) * d + c] (learned positional table), fixed-order chunk sums
 size_t wide_pos_grad_scratch(int B, int T, int d);

@@ -480,7 +480,7 @@ struct DPlan {
     size_t zero, mem16, xL32, qkv32, keys;
     DLayer layer[16];
     size_t saved_bytes;
-    size_t gA, gB, dres, dattn16, dqkv32, slab_all, slab_all_bytes, lnpart, cspart, cspart_side, fcslab, fcslab_bytes, scratch_bytes;
+    size_t gA, gB, dres, dattn16, dqkv32, slab_all, slab_all_bytes, lnpart, cspart, cspart_side, rowpart, rowpart_bytes, fcslab, fcslab_bytes, scratch_bytes;
     // operands of the weight-gradient GEMMs: one buffer per (layer, use) — those GEMMs run on a side stream beside the input-gradient
     // chain (decoder_bwd), so the chain must not overwrite an operand while its weight gradient may still be reading it
     struct { size_t dy16[3], dhid16, dqkv16, dq16, dkv16; } g[16];
@@ -551,6 +551,10 @@ int make_dplan(const egx_dec_config* c, int B, DPlan& pl) {
     cs = dmax(cs, (size_t)(4 * cdiv((int)Md, 256) + 4) * pl.dff * 4);
     pl.cspart = dtake(sc, cs);
     pl.cspart_side = dtake(sc, cs);
+    // a partial buffer per deferred row reduction of the backward (wide.h WideRowReduceBatch): per layer three LayerNorm backwards,
+    // the lin1 bias sums and three bf16 column sums (self-attention in-projection, cross-attention q and k | v)
+    pl.rowpart_bytes = (size_t)pl.L * (3 * align_up(wide_ln_bwd_scratch((int)Md, pl.d), 256) + 4 * align_up(cs, 256));
+    pl.rowpart = dtake(sc, pl.rowpart_bytes);
     pl.fcslab_bytes = dmax(gemm_scratch_bytes(2, pl.V, pl.d, (int)Md), gemm_scratch_bytes(1, (int)Md, pl.d, pl.V));
     pl.fcslab_bytes = dmax(pl.fcslab_bytes, dmax(gemm_scratch_bytes(2, 3 * pl.d, pl.d, (int)Md), gemm_scratch_bytes(1, (int)Md, pl.d, 3 * pl.d)));
     pl.fcslab = dtake(sc, pl.fcslab_bytes);
@@ -826,6 +830,19 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
 
     WideReduceBatch rb;
     size_t slab_cur = 0;
+    // second stages of the two-stage column sums (LayerNorm / bias gradients): queued with a partial buffer of their own each, summed
+    // by ONE launch at the end (every target is a different parameter: concurrent sums never meet)
+    WideRowReduceBatch rrb;
+    size_t row_cur = 0;
+    static int row_env = -2;
+    if (row_env == -2) { const char* e = getenv("EGX_ROW_DEFER"); row_env = e ? atoi(e) : 1; }
+    auto row_region = [&](size_t need) -> void* {
+        need = align_up(need, 256);
+        if (row_env == 0 || row_cur + need > pl.rowpart_bytes) return nullptr;
+        void* r = at<char>(scratch, pl.rowpart) + row_cur;
+        row_cur += need;
+        return r;
+    };
     // Round 5: the weight gradients are QUEUED and leave as one grouped launch per tile variant at the end of the call (wide_gemm.hip
     // wide_tn_queue_*): 35 launches of 14 us each over 512 target rows become one or two grids that fill the chip. Their operands sit in
     // per-(layer, use) buffers until then. Used where the side stream is not (a captured step, EGX_DEC_SIDE=0): with eager launches the
@@ -871,7 +888,8 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         b.dy = dy; b.pre = pre; b.stats = stats; b.w = w; b.dx32 = dres; b.dx16 = dy16; b.rows = Md; b.d = d;
         b.out_key = outm.key; b.out_thresh = outm.thresh; b.out_inv = outm.inv;
         b.dw = dw; b.db = db; b.dbias = dbias;
-        return wide_ln_bwd(b, lnpart, st);
+        void* reg = row_region(wide_ln_bwd_scratch(b.rows, b.d));
+        return reg ? wide_ln_bwd(b, reg, st, &rrb) : wide_ln_bwd(b, lnpart, st);
     };
 
     // vocabulary head: d(fc_w) += d_logits^T x, d(fc_b) += colsum, g = d_logits fc_w
@@ -904,9 +922,11 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         if (ln_bwd(g, cat<float>(saved, o.res3), cat<float>(saved, o.st3), w.norm3_w, ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_FFN_OUT),
                    gw.norm3_w, gw.norm3_b, gw.lin2_b, dy16a)) return 1;
         if (fork() || dw_tn(dy16a, d, cat<bf16_t>(saved, o.hid), dff, gw.lin2_w, d, dff, Md)) return 1;
+        float* cs_l1 = cspart;
+        if (gw.lin1_b) { void* rg = row_region((size_t)wide_gemm_nt_colsum_rows(Md, dff) * dff * 4); if (rg) cs_l1 = (float*)rg; }
         if (nt(dy16a, d, cat<bf16_t>(saved, o.w2_t), Md, dff, d, nullptr, dhid16, nullptr, cat<bf16_t>(saved, o.hid),
-               ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_FFN).inv, gw.lin1_b ? cspart : nullptr)) return 1;
-        if (gw.lin1_b && wide_reduce_rows(cspart, wide_gemm_nt_colsum_rows(Md, dff), dff, gw.lin1_b, st)) return 1;
+               ddrop(training, cfg->p_drop, seed, (uint32_t)l, DS_FFN).inv, gw.lin1_b ? cs_l1 : nullptr)) return 1;
+        if (gw.lin1_b && wide_reduce_rows(cs_l1, wide_gemm_nt_colsum_rows(Md, dff), dff, gw.lin1_b, st, cs_l1 != cspart ? &rrb : nullptr)) return 1;
         if (fork() || dw_tn(dhid16, dff, cat<bf16_t>(saved, o.x2_16), d, gw.lin1_w, dff, d, Md)) return 1;
         float* g1 = (g == gA) ? gB : gA;
         if (nt(dhid16, dff, cat<bf16_t>(saved, o.w1_t), Md, d, dff, g1, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
@@ -928,8 +948,10 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
         }
         if (fork()) return 1;
         if (gw.ca_in_b) {
-            if (wide_colsum_bf16(dq16, Md, d, d, gw.ca_in_b, cspart_side, sd)) return 1;
-            if (wide_colsum_bf16(dkv16, Nm, 2 * d, 2 * d, gw.ca_in_b + d, cspart_side, sd)) return 1;
+            void* r1 = row_region(wide_colsum_scratch(Md, d));
+            void* r2 = row_region(wide_colsum_scratch(Nm, 2 * d));
+            if (wide_colsum_bf16(dq16, Md, d, d, gw.ca_in_b, r1 ? r1 : (void*)cspart_side, sd, r1 ? &rrb : nullptr)) return 1;
+            if (wide_colsum_bf16(dkv16, Nm, 2 * d, 2 * d, gw.ca_in_b + d, r2 ? r2 : (void*)cspart_side, sd, r2 ? &rrb : nullptr)) return 1;
         }
         if (dw_tn(dq16, d, cat<bf16_t>(saved, o.x1_16), d, gw.ca_in_w, d, d, Md)) return 1;
         if (dw_tn(dkv16, 2 * d, mem16, d, gw.ca_in_w ? gw.ca_in_w + (size_t)d * d : nullptr, 2 * d, d, Nm)) return 1;
@@ -976,7 +998,10 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
             if (nt(dqkv16, 3 * d, cat<bf16_t>(saved, o.w_sa_in_t), Md, d, 3 * d, g0, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         } else {
             if (fork()) return 1;
-            if (gw.sa_in_b && wide_colsum_bf16(dqkv16, Md, 3 * d, 3 * d, gw.sa_in_b, cspart_side, sd)) return 1;
+            if (gw.sa_in_b) {
+                void* r3 = row_region(wide_colsum_scratch(Md, 3 * d));
+                if (wide_colsum_bf16(dqkv16, Md, 3 * d, 3 * d, gw.sa_in_b, r3 ? r3 : (void*)cspart_side, sd, r3 ? &rrb : nullptr)) return 1;
+            }
             if (dw_tn(dqkv16, 3 * d, cat<bf16_t>(saved, o.x16), d, gw.sa_in_w, 3 * d, d, Md)) return 1;
             if (nt(dqkv16, 3 * d, cat<bf16_t>(saved, o.w_sa_in_t), Md, d, 3 * d, g0, nullptr, dres, nullptr, 1.f, nullptr)) return 1;
         }
@@ -998,6 +1023,7 @@ int egx_decoder_bwd(const egx_dec_config* cfg, const int64_t* tokens, const egx_
                                de.key, de.thresh, de.inv);
         EGX_LAUNCH_CHECK();
     }
+    if (wide_row_reduce_flush(rrb, st)) return 1;   // every queued LayerNorm / bias column sum
     if (wide_tn_queue_flush(tq, st)) return 1;      // every queued weight gradient: one grid per tile variant, then their slab sums
     return wide_reduce_flush(rb, st);
 }

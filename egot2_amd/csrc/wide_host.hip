@@ -28,7 +28,7 @@ struct WPlan {
     WLayer layer[64];
     size_t saved_bytes;
     // scratch
-    size_t gA, gB, dres, dy16, dhid16, dattn16, dqkv16, adelta, dseg16, slabs, slab_all, slab_all_bytes, lnpart, cspart, scratch_bytes;
+    size_t gA, gB, dres, dy16, dhid16, dattn16, dqkv16, adelta, dseg16, slabs, slab_all, slab_all_bytes, lnpart, cspart, rowpart, rowpart_bytes, scratch_bytes;
 };
 
 size_t take(size_t& cur, size_t bytes) { size_t o = cur; cur = align_up(cur + bytes, 256); return o; }
@@ -109,6 +109,16 @@ void make_wplan(const egx_config* cfg, const egx_segment* segs, int B, WPlan& pl
     size_t cs = smax(wide_colsum_scratch((int)N, 3 * pl.d), (size_t)(4 * cdiv((int)N, 256) + 4) * pl.dff * 4);
     for (int i = 0; i < pl.nseg; ++i) cs = smax(cs, wide_pos_grad_scratch(B, segs[i].T, pl.d));
     pl.cspart = take(sc, cs);
+    // a partial buffer per deferred row reduction of a backward (wide_row_reduce_flush: ONE launch sums them all at its end):
+    // two LayerNorm backwards + the lin1 / in-projection bias column sums per layer
+    {
+        const size_t ln = (wide_ln_bwd_scratch((int)N, pl.d) + 255) / 256 * 256;
+        const size_t c1 = ((size_t)(4 * cdiv((int)N, 256) + 4) * pl.dff * 4 + 255) / 256 * 256, c2 = (wide_colsum_scratch((int)N, 3 * pl.d) + 255) / 256 * 256;
+        size_t all_r = (size_t)pl.L * (2 * ln + c1 + c2);
+        if (all_r > ((size_t)256 << 20)) all_r = 0;
+        pl.rowpart = take(sc, all_r);
+        pl.rowpart_bytes = all_r;
+    }
     pl.scratch_bytes = sc;
 }
 
@@ -310,6 +320,24 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
     WideReduceBatch rb;
     size_t slab_cur = 0;
     const bool defer_ok = pl.slab_all_bytes > 0 && !cfg->bucket_cb;     // bucketed exchange: a layer's gradients must be final when its bucket is announced
+    // second stages of the two-stage column sums (LayerNorm / bias gradients): queued, one launch at the end (wide.h WideRowReduceBatch);
+    // each gets a partial buffer of its own out of `rowpart` (none left, or a bucketed exchange: the shared buffer and its own launch)
+    WideRowReduceBatch rrb;
+    size_t row_cur = 0;
+    static int row_env = -2;
+    if (row_env == -2) { const char* e = getenv("EGX_ROW_DEFER"); row_env = e ? atoi(e) : 1; }      // 0: every second stage as its own launch (A/B aid)
+    const bool row_defer = row_env != 0 && pl.rowpart_bytes > 0 && !cfg->bucket_cb;
+    auto row_region = [&](size_t need) -> void* {
+        need = (need + 255) / 256 * 256;
+        if (!row_defer || row_cur + need > pl.rowpart_bytes) return nullptr;
+        void* r = at<char>(scratch, pl.rowpart) + row_cur;
+        row_cur += need;
+        return r;
+    };
+    auto ln_bwd_q = [&](WideLnBwdParams& b) -> int {
+        void* reg = row_region(wide_ln_bwd_scratch(b.rows, b.d));
+        return reg ? wide_ln_bwd(b, reg, st, &rrb) : wide_ln_bwd(b, lnpart, st);
+    };
     auto dw_tn = [&](const bf16_t* dy, int ldy, const bf16_t* x, int ldx, float* dW, int n_out, int k_in, int tokens) -> int {
         if (!dW) return 0;
         WideGemmParams t;
@@ -333,7 +361,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             Drop d2 = mkdrop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES2);
             b.out_key = d2.key; b.out_thresh = d2.thresh; b.out_inv = d2.inv;
             b.dw = gw.norm2_w; b.db = gw.norm2_b; b.dbias = gw.lin2_b;
-            if (wide_ln_bwd(b, lnpart, st)) return 1;
+            if (ln_bwd_q(b)) return 1;
         }
         if (dw_tn(dy16, d, cat<bf16_t>(saved, o.hid), dff, gw.lin2_w, d, dff, N)) return 1;
         {   // d(hidden) = (dy W2) .* alive / keep, column sums -> d(lin1_b)
@@ -341,9 +369,10 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             q.A = dy16; q.B = cat<bf16_t>(saved, o.w2_t); q.M = N; q.N = dff; q.K = d; q.lda = d; q.ldb = d;
             q.Cb = dhid16; q.ldc = dff; q.mask = cat<bf16_t>(saved, o.hid); q.ldm = dff; q.zero_page = zero;
             q.mask_scale = mkdrop(training, cfg->p_drop, seed, (uint32_t)l, SITE_FFN).inv;
-            q.colsum = gw.lin1_b ? cspart : nullptr;
+            float* cs_reg = gw.lin1_b ? (float*)row_region((size_t)wide_gemm_nt_colsum_rows(N, dff) * dff * 4) : nullptr;
+            q.colsum = gw.lin1_b ? (cs_reg ? cs_reg : cspart) : nullptr;
             if (wide_gemm_nt(q, st)) return 1;
-            if (gw.lin1_b && wide_reduce_rows(cspart, wide_gemm_nt_colsum_rows(N, dff), dff, gw.lin1_b, st)) return 1;
+            if (gw.lin1_b && wide_reduce_rows(q.colsum, wide_gemm_nt_colsum_rows(N, dff), dff, gw.lin1_b, st, cs_reg ? &rrb : nullptr)) return 1;
         }
         if (dw_tn(dhid16, dff, cat<bf16_t>(saved, o.x1_16), d, gw.lin1_w, dff, d, N)) return 1;
         float* g1 = (g == gA) ? gB : gA;
@@ -360,7 +389,7 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             Drop d1 = mkdrop(training, cfg->p_drop, seed, (uint32_t)l, SITE_RES1);
             b.out_key = d1.key; b.out_thresh = d1.thresh; b.out_inv = d1.inv;
             b.dw = gw.norm1_w; b.db = gw.norm1_b; b.dbias = gw.out_proj_b;
-            if (wide_ln_bwd(b, lnpart, st)) return 1;
+            if (ln_bwd_q(b)) return 1;
         }
         if (dw_tn(dy16, d, cat<bf16_t>(saved, o.attn), d, gw.out_proj_w, d, d, N)) return 1;
         {   // d(attention output) = dy W_o
@@ -378,7 +407,10 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             a.drop_key = da.key; a.drop_thresh = da.thresh; a.drop_inv = da.inv;
             if (wide_attn_bwd(a, st)) return 1;
         }
-        if (gw.in_proj_b && wide_colsum_bf16(dqkv16, N, 3 * d, 3 * d, gw.in_proj_b, cspart, st)) return 1;
+        if (gw.in_proj_b) {
+            void* reg = row_region(wide_colsum_scratch(N, 3 * d));
+            if (wide_colsum_bf16(dqkv16, N, 3 * d, 3 * d, gw.in_proj_b, reg ? reg : (void*)cspart, st, reg ? &rrb : nullptr)) return 1;
+        }
         if (dw_tn(dqkv16, 3 * d, cat<bf16_t>(saved, o.x16), d, gw.in_proj_w, 3 * d, d, N)) return 1;
         float* g0 = (g1 == gA) ? gB : gA;
         {   // d(layer input) = dqkv W_in + d(res1)
@@ -415,10 +447,12 @@ int wide_encoder_bwd(const egx_config* cfg, const egx_segment* segs, const float
             b.out_key = df.key; b.out_thresh = df.thresh; b.out_inv = df.inv;
         }
         b.dw = d_ln_w; b.db = d_ln_b; b.dadd = sgr.add_vec; b.dbias = sg.proj_w ? sgr.proj_b : nullptr;
+        // (not queued: every segment adds into the SAME shared-LayerNorm gradient; queued reductions run concurrently and must have targets of their own)
         if (wide_ln_bwd(b, lnpart, st)) return 1;
         const bf16_t* f16 = (sg.feat_bf16 && sg.pool <= 1) ? reinterpret_cast<const bf16_t*>(sg.feat) : cat<bf16_t>(saved, pl.seg_feat16[i]);
         if (sg.proj_w && dw_tn(dseg16, d, f16, sg.d_in, sgr.proj_w, d, sg.d_in, rows)) return 1;
     }
+    if (wide_row_reduce_flush(rrb, st)) return 1;
     return wide_reduce_flush(rb, st);
 }
 

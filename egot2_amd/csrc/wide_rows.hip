@@ -215,6 +215,40 @@ __global__ __launch_bounds__(1024) void wide_ln_bwd_reduce_kernel(const float* _
     else { if (dbias) dbias[c] += s; }
 }
 
+// every queued reduction in one launch: workgroup -> (reduction, 64-column group) by prefix sums
+__global__ __launch_bounds__(1024) void wide_row_reduce_batch_kernel(WideRowReduceBatch b) {
+    __shared__ float red[16][64];
+    int di = 0;
+    while (di + 1 < b.n && (int)blockIdx.x >= b.d[di + 1].first_block) ++di;
+    const WideRowReduceDesc& q = b.d[di];
+    const int c = ((int)blockIdx.x - q.first_block) * 64 + (threadIdx.x & 63);
+    const float s = reduce_rows_1024(q.part, q.nt, (size_t)q.cols, c, c < q.cols, red);
+    if (threadIdx.x >= 64 || c >= q.cols) return;
+    if (q.kind == 0) {
+        q.o0[(size_t)(c / q.row_len) * q.out_ld + c % q.row_len] += s;
+    } else {
+        const int k = c / q.d, cc = c % q.d;
+        if (k == 0) { if (q.o0) q.o0[cc] += s; }
+        else if (k == 1) { if (q.o1) q.o1[cc] += s; if (q.o3) q.o3[cc] += s; }
+        else { if (q.o2) q.o2[cc] += s; }
+    }
+}
+int wide_row_reduce_flush(WideRowReduceBatch& b, hipStream_t st) {
+    if (!b.n) return 0;
+    hipLaunchKernelGGL(wide_row_reduce_batch_kernel, dim3(b.total_blocks), dim3(1024), 0, st, b);
+    EGX_LAUNCH_CHECK();
+    b.n = 0; b.total_blocks = 0;
+    return 0;
+}
+static int row_reduce_queue(WideRowReduceBatch& b, const WideRowReduceDesc& in, hipStream_t st) {
+    if (b.n == WIDE_ROWRED_MAX && wide_row_reduce_flush(b, st)) return 1;      // (what is queued has been produced on this stream already)
+    WideRowReduceDesc& q = b.d[b.n++];
+    q = in;
+    q.first_block = b.total_blocks;
+    b.total_blocks += cdiv(q.cols, 64);
+    return 0;
+}
+
 static int ln_bwd_blocks(int rows) {
     int blocks = cdiv(rows, 16);          // >= 4 rows per wave; at most 1024 partial rows to reduce
     if (blocks > 1024) blocks = 1024;
@@ -222,7 +256,7 @@ static int ln_bwd_blocks(int rows) {
 }
 size_t wide_ln_bwd_scratch(int rows, int d) { return (size_t)ln_bwd_blocks(rows) * 3 * d * sizeof(float); }
 
-int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st) {
+int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st, WideRowReduceBatch* defer) {
     EGX_CHECK(p.dy && p.pre && p.stats && p.w && scratch, "wide_ln_bwd: null pointer");
     EGX_CHECK(p.d > 0 && p.d <= 1024 && p.d % 4 == 0, "wide_ln_bwd: d=%d unsupported", p.d);
     if (p.rows <= 0) return 0;
@@ -231,6 +265,13 @@ int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st) {
     const int rpb = cdiv(p.rows, p.blocks);
     p.blocks = cdiv(p.rows, rpb);
     hipLaunchKernelGGL(wide_ln_bwd_kernel, dim3(p.blocks), dim3(256), 0, st, p, rpb);
+    if (defer && (p.dw || p.db || p.dbias || p.dadd)) {
+        EGX_LAUNCH_CHECK();
+        WideRowReduceDesc q;
+        q.part = p.partials; q.o0 = p.dw; q.o1 = p.db; q.o2 = p.dbias; q.o3 = p.dadd; q.nt = p.blocks; q.cols = 3 * p.d; q.d = p.d; q.kind = 1;
+        q.first_block = 0; q.out_ld = 0; q.row_len = 1; q.pad_ = 0;
+        return row_reduce_queue(*defer, q, st);
+    }
     if (p.dw || p.db || p.dbias || p.dadd)
         hipLaunchKernelGGL(wide_ln_bwd_reduce_kernel, dim3(cdiv(3 * p.d, 64)), dim3(1024), 0, st, (const float*)p.partials, p.blocks,
                            p.d, p.dw, p.db, p.dbias, p.dadd);
@@ -271,8 +312,14 @@ __global__ __launch_bounds__(1024) void wide_reduce_rows_kernel(const float* __r
     if (threadIdx.x < 64 && c < cols) out[(size_t)(c / row_len) * out_ld + c % row_len] += s;
 }
 
-int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st) {
+int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_t st, WideRowReduceBatch* defer) {
     if (nt <= 0 || cols <= 0) return 0;
+    if (defer) {
+        WideRowReduceDesc q;
+        q.part = part; q.o0 = out; q.o1 = q.o2 = q.o3 = nullptr; q.nt = nt; q.cols = cols; q.d = cols; q.kind = 0;
+        q.first_block = 0; q.out_ld = cols; q.row_len = cols; q.pad_ = 0;
+        return row_reduce_queue(*defer, q, st);
+    }
     hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, st, part, nt, cols, out, cols, cols);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -301,14 +348,21 @@ __global__ __launch_bounds__(256) void wide_pos_grad_kernel(const float* __restr
     *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * T * d + (size_t)i4 * 4) = s;
 }
 
-size_t wide_pos_grad_scratch(int B, int T, int d) { return (size_t)cdiv(B, 8) * T * d * sizeof(float); }
+// clip chunks summed by separate workgroups. (Until round 5 the scratch query said cdiv(B, 8) chunks while the launch used the count
+// below: for B < 256 the partial sums ran past the buffer — found when the deferred row reductions put their first partial buffer behind it.)
+static int pos_grad_chunks(int B, int* bchunk_out = nullptr) {
+    const int want = B >= 64 ? 32 : cdiv(B, 2);
+    const int bchunk = cdiv(B, want);
+    if (bchunk_out) *bchunk_out = bchunk;
+    return cdiv(B, bchunk);
+}
+size_t wide_pos_grad_scratch(int B, int T, int d) { return (size_t)pos_grad_chunks(B) * T * d * sizeof(float); }
 
 int wide_pos_grad(const float* dtok, int B, int S, int off, int T, int d, float* dpos, int pos_stride, uint64_t key, uint32_t thresh,
                   float inv, void* scratch, hipStream_t st) {
     EGX_CHECK(d % 4 == 0 && scratch, "wide_pos_grad: bad arguments");
-    int chunks = B >= 64 ? 32 : cdiv(B, 2);
-    const int bchunk = cdiv(B, chunks);
-    chunks = cdiv(B, bchunk);
+    int bchunk = 1;
+    const int chunks = pos_grad_chunks(B, &bchunk);
     hipLaunchKernelGGL(wide_pos_grad_kernel, dim3(cdiv(T * d / 4, 256), chunks), dim3(256), 0, st, dtok, B, S, off, T, d, bchunk,
                        (float*)scratch, key, thresh, inv);
     hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(T * d, 64)), dim3(1024), 0, st, (const float*)scratch, chunks, T * d, dpos,
@@ -326,7 +380,7 @@ static int colsum_row_blocks(int rows, int cols) {
 }
 size_t wide_colsum_scratch(int rows, int cols) { return (size_t)colsum_row_blocks(rows, cols) * cols * sizeof(float); }
 
-int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st) {
+int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, void* scratch, hipStream_t st, WideRowReduceBatch* defer) {
     EGX_CHECK(x && out && scratch && cols % 8 == 0 && ld % 8 == 0, "wide_colsum: bad arguments");
     if (rows <= 0) return 0;
     int rb = colsum_row_blocks(rows, cols);
@@ -334,7 +388,7 @@ int wide_colsum_bf16(const bf16_t* x, int rows, int cols, int ld, float* out, vo
     rb = cdiv(rows, rpb);
     hipLaunchKernelGGL(wide_colsum_kernel, dim3(cdiv(cols, 512), rb), dim3(256), 0, st, x, rows, cols, ld, rpb, (float*)scratch);
     EGX_LAUNCH_CHECK();
-    return wide_reduce_rows((const float*)scratch, rb, cols, out, st);
+    return wide_reduce_rows((const float*)scratch, rb, cols, out, st, defer);
 }
 
 }  // namespace egx
