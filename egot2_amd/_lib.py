@@ -147,6 +147,7 @@ SIGNATURES = {
     "egx_layernorm_fwd": (C.c_int, [_fp, _fp, _fp, _fp, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp]),
     "egx_attention_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, _fp]),
+    "egx_slices_stolen": (C.c_longlong, [C.c_int]),
     "egx_debug_stamps": (C.c_int, [_fp, C.c_int]),
     "egx_seed_advance": (C.c_int, [_fp, _fp]),
     "egx_timing_enable": (None, [C.c_int]),

@@ -450,6 +450,10 @@ extern "C" {
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
 long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
 int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : n == -3000 ? debug_read_cstamps(out) : n == -4000 ? debug_read_sstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
+long long egx_slices_stolen(int reset) {
+    const long long a = slices_stolen_fwd(reset), b = slices_stolen_bwd(reset);
+    return a < 0 || b < 0 ? -1 : a + b;
+}
 int egx_seed_advance(uint64_t* seed, void* stream) { EGX_CHECK(seed, "null seed"); return seed_advance(seed, (hipStream_t)stream); }
 void egx_timing_enable(int on) { timing_enable(on); }
 int egx_timing_read(int which, double* total_ms, int* count) { return timing_read(which, total_ms, count); }

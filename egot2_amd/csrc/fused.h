@@ -267,6 +267,8 @@ int tiled_attn_bwd(const TiledAttnParams& p, int compute, hipStream_t st);
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj);      // n_heads 4 or 8
 size_t fused_lds_bytes(int NT);
+long long slices_stolen_fwd(int reset);     // sliced-mode diagnostic (fused_dev.h slice_stolen_note); synchronous device reads
+long long slices_stolen_bwd(int reset);
 int debug_read_stamps(unsigned long long* out, int n);
 int debug_read_bstamps(unsigned long long* out, int n);
 int fused_forward(const FusedFwdParams& p, int compute, hipStream_t st);

@@ -77,6 +77,13 @@ int pack_weights(PackParams& pp, hipStream_t st) {
     return 0;
 }
 
+__device__ unsigned g_stolen_fwd;      // slices the forward's waiting workgroups computed themselves (fused_dev.h slice_stolen_note)
+long long slices_stolen_fwd(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_stolen_fwd), sizeof(v)) != hipSuccess) return -1;
+    if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stolen_fwd), &z, sizeof(z)); }
+    return v;
+}
 // Development aid: phase timestamps of workgroup 0 / wave 0 (s_memtime), read back by egx_debug_stamps().
 __device__ unsigned long long g_stamps[32];
 #ifdef EGX_STAMPS
@@ -881,7 +888,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             bool steal = false;
             while (++sl_k < n_slices) {
                 const int s2 = slice + sl_k < n_slices ? slice + sl_k : slice + sl_k - n_slices;
-                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; break; }
+                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; slice_stolen_note(&g_stolen_fwd); break; }
             }
             if (!steal) {       // the sum over the waves AND the slices of the clip comes back in Xs
                 slice_gather(xc, n_slices, Xs, LDX, S);

@@ -1085,6 +1085,13 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t 
     return 0;
 }
 
+__device__ unsigned g_stolen_bwd;      // slices the backward's waiting workgroups computed themselves
+long long slices_stolen_bwd(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_stolen_bwd), sizeof(v)) != hipSuccess) return -1;
+    if (reset) { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stolen_bwd), &z, sizeof(z)); }
+    return v;
+}
 __device__ unsigned long long g_bstamps[32];
 #ifdef EGX_STAMPS
 #define BSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bstamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1557,7 +1564,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             bool steal = false;
             while (++sl_k < n_slices) {
                 const int s2 = slice + sl_k < n_slices ? slice + sl_k : slice + sl_k - n_slices;
-                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; break; }
+                if (!slice_wait(fl + s2)) { sl_cur = s2; steal = true; slice_stolen_note(&g_stolen_bwd); break; }
             }
             if (!steal) {
                 // the sum over the waves and over the slices of the clip comes back in Gs (B2, B3, B4 cleared): identical results in every slice

@@ -603,6 +603,9 @@ __device__ __forceinline__ void slice_publish(const float* p0, const float* p1, 
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// diagnostic: how many slices a waiting workgroup had to compute itself (a late or absent partner, EGX_SLICE_DROP). A non-zero
+// count on a quiet GPU means the launches pay 100 us timeouts + recomputed FFN slices: egx_slices_stolen() makes that visible.
+__device__ inline void slice_stolen_note(unsigned* counter) { if (threadIdx.x == 0) atomicAdd(counter, 1u); }
 // has the block behind `flag` been published? Waits at most SLICE_WAIT_TICKS; the answer is uniform over the workgroup
 __device__ __forceinline__ bool slice_wait(const unsigned* flag) {
     __shared__ unsigned arrived;

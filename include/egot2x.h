@@ -445,6 +445,11 @@ int egx_dropout(float* x, int rows, int cols, float p_drop, uint64_t seed, uint3
  * egx_timing_read synchronises on the recorded events; never call it inside a timed or captured region. */
 void egx_timing_enable(int on);
 int egx_timing_read(int which, double* total_ms, int* count);
+/* Sliced mode (small batches, egx_encoder_slices() > 1) diagnostic: how many FFN slices waiting workgroups have computed themselves since the
+ * last reset because a partner workgroup's partial sum did not arrive within 100 us (a busy GPU shared with another process — or a stray
+ * EGX_SLICE_DROP in the environment). 0 on a quiet GPU; every count is ~100 us of waiting plus a recomputed slice. Synchronous (reads device
+ * memory): never inside a timed or captured region. -1 on error. */
+long long egx_slices_stolen(int reset);
 /* development aid: phase timestamps of the fused forward (only meaningful in -DEGX_STAMPS builds) */
 int egx_debug_stamps(unsigned long long* out, int n);
 

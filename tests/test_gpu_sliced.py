@@ -154,11 +154,14 @@ def test_missing_slices_are_computed_by_the_waiting_workgroups(egx_lib, cuda, co
     (simulated: EGX_SLICE_DROP makes the workgroups of the masked slices leave at once) is computed by the workgroups that wait for
     it, in both directions; logits and gradients equal the one-workgroup-per-clip launch."""
     lo, go, *_ = _run(cuda, compute, B, 15, L, 0.5, 1)
+    egx_lib.egx_slices_stolen(1)
     os.environ["EGX_SLICE_DROP"] = drop
     try:
         ls, gs, *_ = _run(cuda, compute, B, 15, L, 0.5, 8)
     finally:
         os.environ.pop("EGX_SLICE_DROP")
+    # the diagnostic counts what happened: every surviving workgroup computed the missing slices itself, forward and backward
+    assert egx_lib.egx_slices_stolen(1) > 0
     tol_l, tol_g = (1e-5, 1e-3 if L > 1 else 1e-4) if compute != "bf16" else (2e-2, 5e-2)
     assert (ls - lo).abs().max().item() < tol_l * max(1.0, lo.abs().max().item())
     bad = {k: rel_err(gs[k], go[k]) for k in go if not rel_err(gs[k], go[k]) < tol_g}
