@@ -43,7 +43,7 @@ int wide_gemm_tn(const WideGemmParams& p, void* scratch, hipStream_t st, WideRed
 // grouped weight-gradient launches (wide_gemm.hip): independent TN problems queued by tile variant, one grid per variant at the flush
 struct WideTnDesc { const bf16_t* A; const bf16_t* B; float* slabs; size_t slab_stride; int M, N, K, lda, ldb, ntM, ntN, kps, splits, first_block; };
 constexpr int WIDE_TN_GROUP_MAX = 40;
-struct WideTnGroup { WideTnDesc d[WIDE_TN_GROUP_MAX]; const void* zero_page = nullptr; int n = 0, epi_lds = 0; };
+struct WideTnGroup { WideTnDesc d[WIDE_TN_GROUP_MAX]; const void* zero_page = nullptr; int n = 0, epi_lds = 0, by_slice = 0; };
 struct WideTnQueue { WideTnGroup g[3]; int blocks[3] = {0, 0, 0}; };
 int wide_tn_queue_add(WideTnQueue& Q, const WideGemmParams& p, void* scratch, hipStream_t st, WideReduceBatch* defer);
 int wide_tn_queue_flush(WideTnQueue& Q, hipStream_t st);

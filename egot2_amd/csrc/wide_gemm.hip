@@ -858,8 +858,17 @@ __device__ __forceinline__ void tn_tile(const WideGemmParams& p, int tile_id, in
 }
 
 template <int BM, int BN, int WTM, int D>
-__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride) {
-    tn_tile<BM, BN, WTM, D>(p, xcd_tile(blockIdx.x, ntM * ntN), blockIdx.y, ntM, ntN, kps, slabs, slab_stride);
+__global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_kernel(WideGemmParams p, int ntM, int ntN, int kps, float* slabs, size_t slab_stride, int by_slice) {
+    const int tiles = ntM * ntN;
+    if (by_slice) {
+        // round 5: the workgroups sharing an XCD (id % 8) get a contiguous range of (K slice, tile) pairs, slice-major: all tiles of a K
+        // slice read its rows of A and B through ONE L2. With (tile, slice) grids the tiles of a slice sat on all eight XCDs and every
+        // XCD fetched the slice's B rows from HBM for itself: 471 MB read per launch at C4 against ~170 MB of operands
+        // (profiles/r05_pmc_c4_bf16.json), the launches at 4 TB/s.
+        const int c = xcd_tile(blockIdx.x, (int)gridDim.x);
+        tn_tile<BM, BN, WTM, D>(p, c % tiles, c / tiles, ntM, ntN, kps, slabs, slab_stride);
+    } else
+        tn_tile<BM, BN, WTM, D>(p, xcd_tile(blockIdx.x, tiles), blockIdx.y, ntM, ntN, kps, slabs, slab_stride);
 }
 
 // GROUPED launch: up to WIDE_TN_GROUP_MAX independent weight-gradient problems of ONE tile variant as one grid (workgroup ->
@@ -874,7 +883,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / 64) * 64, 1) void wide_gemm_tn_g
     const int local = blockIdx.x - q.first_block, tiles = q.ntM * q.ntN;
     WideGemmParams p;
     p.A = q.A; p.B = q.B; p.M = q.M; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb; p.zero_page = g.zero_page; p.epi_lds = g.epi_lds;
-    tn_tile<BM, BN, WTM, D>(p, local % tiles, local / tiles, q.ntM, q.ntN, q.kps, q.slabs, q.slab_stride);
+    const int c = g.by_slice ? xcd_tile(local, tiles * q.splits) : local;     // slice-major per XCD (see wide_gemm_tn_kernel)
+    tn_tile<BM, BN, WTM, D>(p, c % tiles, c / tiles, q.ntM, q.ntN, q.kps, q.slabs, q.slab_stride);
 }
 
 // C[m][n] (+)= sum_s slab[s][m][n], fixed order
@@ -962,6 +972,12 @@ size_t wide_gemm_tn_scratch(int M, int N, int K) {
     return (size_t)tn_splits(M, N, K, nullptr) * M * N * sizeof(float);
 }
 
+static int tn_slice_major() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_TN_SLICE_XCD"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <int BM, int BN, int WTM, int D>
 static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs, size_t slab_stride, hipStream_t st) {
     constexpr int LDS = D * (BM / 128 + BN / 128) * TBK * 128 * 2;
@@ -972,8 +988,12 @@ static int launch_tn(const WideGemmParams& p, int splits, int kps, float* slabs,
         attr = true;
     }
     const int ntM = p.M / BM, ntN = p.N / BN;
+    const int by_slice = tn_slice_major();
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, BN, WTM, D>), dim3(ntM * ntN, splits), dim3(THREADS), LDS, st, p, ntM, ntN, kps, slabs, slab_stride);
+    if (by_slice)
+        hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, BN, WTM, D>), dim3(ntM * ntN * splits), dim3(THREADS), LDS, st, p, ntM, ntN, kps, slabs, slab_stride, 1);
+    else
+        hipLaunchKernelGGL((wide_gemm_tn_kernel<BM, BN, WTM, D>), dim3(ntM * ntN, splits), dim3(THREADS), LDS, st, p, ntM, ntN, kps, slabs, slab_stride, 0);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -988,8 +1008,10 @@ static int launch_tn_grouped(const WideTnGroup& g, int blocks, hipStream_t st) {
         EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_gemm_tn_grouped_kernel<BM, BN, WTM, D>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr = true;
     }
+    WideTnGroup gg = g;
+    gg.by_slice = tn_slice_major();
     timing_begin(TIMER_WIDE_GEMM, st);
-    hipLaunchKernelGGL((wide_gemm_tn_grouped_kernel<BM, BN, WTM, D>), dim3(blocks), dim3(THREADS), LDS, st, g);
+    hipLaunchKernelGGL((wide_gemm_tn_grouped_kernel<BM, BN, WTM, D>), dim3(blocks), dim3(THREADS), LDS, st, gg);
     timing_end(TIMER_WIDE_GEMM, st);
     EGX_LAUNCH_CHECK();
     return 0;
