@@ -97,6 +97,21 @@ __device__ __forceinline__ void drop_scale4(uint64_t key, uint32_t row, uint32_t
     out[2] = (h.y & 0xffffu) >= thresh ? inv_keep : 0.f;
     out[3] = (h.y >> 16) >= thresh ? inv_keep : 0.f;
 }
+// Keep bits of a 16 x 16 tile held in MFMA accumulator layout with the mask ROWS on the registers: lane (r = lane & 15, g = lane >> 4)
+// holds rows row0 + 4g + e (e = 0 .. 3) of ONE column 4 cq0 + r — four different hashes of which one 16-bit field each would be used
+// (the transposed passes of the attention backwards: dK / dV tiles, mask keyed (query, key)). The tile needs 16 rows x 4 column quads =
+// 64 hashes in all: every lane draws ONE, that of (row row0 + 4g + (r & 3), column quad cq0 + (r >> 2)), and the four lanes of a quad
+// exchange their 4-bit results by DPP quad broadcasts. Element e is kept iff bit (r & 3) of m4[e] is set.
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {       // quad_perm [e, e, e, e]: every lane of a quad reads quad-lane e
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void tile_keep_rows(uint64_t key, uint32_t row0, uint32_t cq0, int r, int g, uint32_t thresh, uint32_t (&m4)[4]) {
+    const uint2 h = rand_quad(key, row0 + (uint32_t)(4 * g + (r & 3)), cq0 + (uint32_t)(r >> 2));
+    const uint32_t mw = (uint32_t)((h.x & 0xffffu) >= thresh) | ((uint32_t)((h.x >> 16) >= thresh) << 1) |
+                        ((uint32_t)((h.y & 0xffffu) >= thresh) << 2) | ((uint32_t)((h.y >> 16) >= thresh) << 3);
+    m4[0] = quad_bcast<0x00>(mw); m4[1] = quad_bcast<0x55>(mw); m4[2] = quad_bcast<0xAA>(mw); m4[3] = quad_bcast<0xFF>(mw);
+}
 static inline uint32_t drop_threshold(float p) {
     double t = (double)p * 65536.0;
     if (t <= 0) return 0u;

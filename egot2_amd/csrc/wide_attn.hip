@@ -267,11 +267,15 @@ __global__ __launch_bounds__(NKT * 64) void wide_attn_bwd_kernel(WideAttnParams 
             const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + 4 * g);
             const float4 d4 = *reinterpret_cast<const float4*>(delta_s + qt * 16 + 4 * g);
             const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+            // the lane's four elements are four mask ROWS (queries) of one key: one hash per lane and tile (common.h tile_keep_rows)
+            uint32_t m4[4] = {0xFu, 0xFu, 0xFu, 0xFu};
+            if (p.drop_thresh) tile_keep_rows(dkey, (uint32_t)(bh * 128 + qt * 16), (uint32_t)(kt * 4), r, g, p.drop_thresh, m4);
+            const float kinv = p.drop_thresh ? p.drop_inv : 1.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int query = qt * 16 + 4 * g + e;
                 float pv = (key < S && query < S) ? __expf(a[e] * scale - lq[e]) : 0.f;
-                float ks = p.drop_thresh ? drop_scale(dkey, (uint32_t)(bh * 128 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
+                float ks = ((m4[e] >> (r & 3)) & 1u) ? kinv : 0.f;
                 a[e] = pv * ks;                                   // dropped P
                 c[e] = pv * (ks * c[e] - dq4[e]) * scale;         // dS
             }
@@ -531,11 +535,14 @@ __global__ __launch_bounds__(WAL_NTH) void wide_attn_long_dkv_kernel(WideAttnPar
                 const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 16 + 4 * g);
                 const float4 d4 = *reinterpret_cast<const float4*>(delta_s + qt * 16 + 4 * g);
                 const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+                uint32_t m4[4] = {0xFu, 0xFu, 0xFu, 0xFu};      // (common.h tile_keep_rows: one hash per lane and tile)
+                if (p.drop_thresh) tile_keep_rows(dkey, (uint32_t)(bh * 512 + qt * 16), (uint32_t)(kt * 4), r, g, p.drop_thresh, m4);
+                const float kinv = p.drop_thresh ? p.drop_inv : 1.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int query = qt * 16 + 4 * g + e;
                     const float pv = (key < S && query < S) ? __builtin_amdgcn_exp2f(a[e] * c2 - lq[e]) : 0.f;
-                    const float ks = p.drop_thresh ? drop_scale(dkey, (uint32_t)(bh * 512 + query), (uint32_t)key, p.drop_thresh, p.drop_inv) : 1.f;
+                    const float ks = ((m4[e] >> (r & 3)) & 1u) ? kinv : 0.f;
                     pn[j][e] = pv * ks;
                     dsn[j][e] = pv * (ks * c[e] - dq4[e]) * scale;
                 }

@@ -5,7 +5,8 @@ import torch
 from egot2_amd import hhi_ttm
 from egot2_amd.synth import hhi_args
 dev = torch.device("cuda:0")
-m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5)).to(dev).set_compute("bf16").train()
+torch.autograd.set_multithreading_enabled(False)      # the backward's python (EncoderFn.backward) runs in this thread: cProfile sees it
+m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5)).to(dev).set_compute(sys.argv[1] if len(sys.argv) > 1 else "bf16").train()
 feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]
 target = torch.randint(0, 2, (256,), device=dev)
 w = torch.tensor([0.266, 0.734], device=dev)
@@ -31,4 +32,5 @@ for _ in range(200):
     step()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
