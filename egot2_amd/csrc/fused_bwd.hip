@@ -916,35 +916,43 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
     };
     gload(kb_beg, pgA, pxA);
     gload(kb_beg + 1 < kb_end ? kb_beg + 1 : kb_beg, pgB, pxB);
-    if constexpr (CM == CM_SPLIT) {
-        // Operands are split ONCE per K-block while staging (three bf16 planes per tile, single-buffered: 42 KB) and read back
-        // as token-along-K fragments by the hardware-transposed ds_read_b64_tr_b16: no per-wave gather or split work.
+    if constexpr (CM == CM_SPLIT || CM == CM_BF16) {
+        // Operands are converted (bf16: one plane) or split (f32s: three planes) ONCE per K-block while staging (single-buffered:
+        // 14 / 42 KB) and read back as token-along-K fragments by the hardware-transposed ds_read_b64_tr_b16: no per-wave gather,
+        // conversion or split work. (bf16 took the fp32-tile path below until round 5: eight scalar LDS reads and four converts per
+        // fragment and lane, VALU : MFMA = 23, profiles/r05_pmc_c2_bf16.json.)
+        constexpr int NPL = CM == CM_SPLIT ? 3 : 1;
         constexpr int LGH = 80, LXH = 144;            // halfword row strides: conflict-free transposed reads
         constexpr int GPL = 32 * LGH, XPL = 32 * LXH;
         unsigned short* gp = reinterpret_cast<unsigned short*>(lds);
-        unsigned short* xp = gp + 3 * GPL;
+        unsigned short* xp = gp + NPL * GPL;
         static_assert((3 * GPL + 3 * XPL) * 2 <= (int)sizeof(lds), "split planes must fit the staging buffer");
         typedef short s4v __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s4v lds_s4v;
         const int i16 = lane & 15;
         auto tr_frag = [&](const unsigned short* base, int ld, int plane_stride, int c0) {
             const unsigned short* b = base + (4 * q + (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
-            Frag<CM_SPLIT> f;
+            Frag<CM> f;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < NPL; ++pl) {
                 s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * plane_stride));
                 s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(b + pl * plane_stride + 16 * ld));
-                f.p[pl] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 w = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (CM == CM_SPLIT) f.p[pl] = w; else f.v = w;
             }
             return f;
         };
         auto put = [&](unsigned short* d, int plane_stride, const float4& v) {
-            uint32_t h0, m0, l0, h1, m1, l1;
-            split_pair(v.x, v.y, h0, m0, l0);
-            split_pair(v.z, v.w, h1, m1, l1);
-            *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l0, l1);
+            if constexpr (CM == CM_SPLIT) {
+                uint32_t h0, m0, l0, h1, m1, l1;
+                split_pair(v.x, v.y, h0, m0, l0);
+                split_pair(v.z, v.w, h1, m1, l1);
+                *reinterpret_cast<uint2*>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(d + plane_stride) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(d + 2 * plane_stride) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<uint2*>(d) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+            }
         };
         auto block = [&](int kb, float4 (&pg)[2], float4 (&px)[4]) {
             if (kb > kb_beg) __syncthreads();           // everyone is done reading the previous K-block
@@ -954,11 +962,11 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
             for (int i = 0; i < 4; ++i) { int f = tid + i * 256; put(xp + (f >> 5) * LXH + ((f & 31) << 2), XPL, px[i]); }
             __syncthreads();
             gload(kb + 2 < kb_end ? kb + 2 : kb, pg, px);      // (past the end: a re-read that nobody uses)
-            Frag<CM_SPLIT> a = tr_frag(gp, LGH, GPL, wave * 16);
+            Frag<CM> a = tr_frag(gp, LGH, GPL, wave * 16);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                Frag<CM_SPLIT> b = tr_frag(xp, LXH, XPL, j * 16);
-                mma<CM_SPLIT>(acc[j], a, b);
+                Frag<CM> b = tr_frag(xp, LXH, XPL, j * 16);
+                mma<CM>(acc[j], a, b);
             }
         };
         SSTAMP(2);
