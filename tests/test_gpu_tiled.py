@@ -31,6 +31,8 @@ def _sd64(sd):
     (3, 3, 150, 1, 0.0),      # S = 450: the longest training / validation segment
     (3, 1, 150, 2, 0.5),      # validation batch of ONE clip, two layers, train-mode masks
     (3, 2, 32, 1, 0.0),       # S = 96: exactly two tiles
+    (2, 2, 160, 1, 0.5),      # S = 320: the largest clip whose f32s planes are ONE chunk of the LDS operand
+    (3, 2, 107, 1, 0.5),      # S = 321 (padded 352): two chunks of 192 rows in f32s, the last K-block half empty, masks across the chunk edge
 ])
 def test_tiled_ttm_translator_vs_oracle(egx_lib, cuda, compute, n_tasks, B, T, L, p):
     from egot2_amd import functional as F_egx, hhi_ttm
