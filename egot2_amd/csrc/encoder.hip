@@ -529,7 +529,7 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
         Plan vp = pl;
         plan_tiled(vp);
         tsv = tiled_saved_bytes(cfg, segs, vp);
-        tsc = fused_bwd_scratch(cfg, segs, vp, 0).bytes;
+        tsc = fused_bwd_scratch(cfg, segs, vp, FUSED_HEAD_MAX_OUT).bytes;       // (the pooled head's partial-row section: sized for the largest head)
     }
     if (saved_bytes) *saved_bytes = size_max(size_max(size_max(pl.saved_bytes, wsv), tsv), fused_ok(cfg, segs, pl) ? fused_saved_bytes(cfg, segs, pl) : (size_t)0);
     if (scratch_bytes) *scratch_bytes = size_max(size_max(size_max(pl.scratch_bytes, wsc), tsc), fused_ok(cfg, segs, pl) ? fused_bwd_scratch(cfg, segs, pl, FUSED_HEAD_MAX_OUT).bytes : (size_t)0);
@@ -807,7 +807,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             Plan vp = pl;
             if (tiled) plan_tiled(vp);
             FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, (char*)saved + fused_act_bytes(vp));
-            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, (with_head && !tiled) ? head->n_out : 0);
+            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, with_head ? head->n_out : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
             for (int i = 0; i < pl.nseg; ++i) {
@@ -846,10 +846,11 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.tiled = tiled ? 1 : 0; bp.tpc = vp.tpc; bp.S_clip = S; bp.Ntok = pl.N;
             bp.d_tokens = d_tokens;
             bp.out_T = cfg->out_tokens > 0 ? cfg->out_tokens : S;
-            if (with_head && !tiled) {
+            if (with_head) {        // (tiled mode since round 5 too: the first tile launch runs the head backward from the saved token means)
                 bp.head.ln_w = head->ln_w; bp.head.ln_b = head->ln_b; bp.head.W = head->W; bp.head.b = head->b; bp.head.n_out = head->n_out;
                 bp.d_logits = d_logits;
                 bp.head_off = fused_partial_len(pl.L, pl.nseg);
+                if (tiled) bp.pooled = (const float*)((const char*)saved + tiled_tokens_offset(cfg, segs, vp)) + (size_t)N * d;
             }
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
@@ -888,15 +889,6 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
             if (stage != 2 && tiled) {
                 // L + 1 launches of the tile kernel with the attention backward of every clip between them
-                if (with_head) {        // pooled head backward -> d(tokens); it accumulates into the caller's buffer: zero that first
-                    const float* extra = (const float*)((const char*)saved + tiled_tokens_offset(cfg, segs, vp));
-                    float* dt = fptr(scratch, SC.dtok);
-                    if (bp.zero_buf) { EGX_HIP(hipMemsetAsync(bp.zero_buf, 0, bp.zero_n * 4, st)); bp.zero_buf = nullptr; }
-                    if (pool_head_bwd(d_logits, extra + (size_t)N * d, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->n_out, dt,
-                                      head_grads ? head_grads->ln_w : nullptr, head_grads ? head_grads->ln_b : nullptr,
-                                      head_grads ? head_grads->W : nullptr, head_grads ? head_grads->b : nullptr, st)) return 1;
-                    bp.d_tokens = dt;
-                }
                 bp.datt = fptr(scratch, SC.datt); bp.dres = fptr(scratch, SC.dres);
                 const float* lse = (const float*)((const char*)saved + tiled_lse_offset(cfg, segs, vp));
                 for (int l = pl.L - 1; l >= 0; --l) {
@@ -938,7 +930,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(seg_grads[i].add_vec, og + 256 + i * 256, 128);
                 add_dst(seg_grads[i].proj_b, og + 256 + i * 256 + 128, 128);
             }
-            if (with_head && head_grads && !tiled) {
+            if (with_head && head_grads) {
                 int oh = fused_partial_len(pl.L, pl.nseg);
                 add_dst(head_grads->ln_w, oh, 128); add_dst(head_grads->ln_b, oh + 128, 128);
                 add_dst(head_grads->b, oh + 256, head->n_out);

@@ -175,6 +175,7 @@ struct FusedBwdParams {
     const float* d_tokens;     // (B, out_T, 128), or null when the head is fused (then d_logits drives the backward)
     int out_T;                 // tokens of every clip that carry an upstream gradient (S, or egx_config.out_tokens)
     FusedHead head; const float* d_logits; int head_off;   // head_off: offset of the head section in the partial row
+    const float* pooled;       // tiled mode with the fused head: (B, 128) token means saved by the forward's pool_head_fwd
     const float* saved_pre;    // from the forward
     const float* saved_res;
     const float* saved_qkv;    // (L, B, 48, 384) from the forward (FusedFwdParams::qkv_out)

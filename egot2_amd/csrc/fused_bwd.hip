@@ -1265,6 +1265,49 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             }
             __syncthreads();
             { float* t = Gs; Gs = B2; B2 = t; }
+        } else if (p.head.n_out > 0) {
+            // Tiled mode with the pooled head (round 5): d(tokens) = d(pooled) / S_clip on every row of the tile, from the token mean
+            // the forward saved — pool_head_bwd as a launch of its own (9.5 us at 25 clips: one workgroup per clip), the dense d(tokens)
+            // rows and the fill of the caller's gradient buffer in front of its atomics are gone. Every tile of a clip repeats the
+            // 128-wide head backward (wave 0); the head's parameter gradients leave in the partial row of the clip's FIRST tile.
+            float* hp = part + p.head_off;
+            float* pooled = B2;        // [0,128): pooled; [128,256): d(pooled) / S_clip (B2 is all zero here and is zeroed again below)
+            if (tid < FD) pooled[tid] = p.pooled[(size_t)c_real * FD + tid];
+            __syncthreads();
+            if (wave == 0) {
+                const float first = t0 == 0 ? 1.f : 0.f;
+                float2 x = *reinterpret_cast<float2*>(pooled + 2 * lane);
+                float mean = wsum(x.x + x.y) * (1.f / FD);
+                float xh0 = x.x - mean, xh1 = x.y - mean;
+                float rstd = rsqrtf(wsum(xh0 * xh0 + xh1 * xh1) * (1.f / FD) + p.eps);
+                xh0 *= rstd; xh1 *= rstd;
+                float2 lw = *reinterpret_cast<const float2*>(p.head.ln_w + 2 * lane);
+                float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
+                float y0 = xh0 * lw.x + lb.x, y1 = xh1 * lw.y + lb.y;
+                float d0 = 0.f, d1 = 0.f;
+                for (int o = 0; o < p.head.n_out; ++o) {
+                    float go = p.d_logits[(size_t)c_real * p.head.n_out + o];
+                    float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
+                    d0 += go * wv.x; d1 += go * wv.y;
+                    *reinterpret_cast<float2*>(hp + 256 + FUSED_HEAD_MAX_OUT + o * FD + 2 * lane) = make_float2(first * go * y0, first * go * y1);
+                    if (lane == 0) hp[256 + o] = first * go;
+                }
+                *reinterpret_cast<float2*>(hp + 2 * lane) = make_float2(first * d0 * xh0, first * d1 * xh1);      // d(head ln_w)
+                *reinterpret_cast<float2*>(hp + 128 + 2 * lane) = make_float2(first * d0, first * d1);            // d(head ln_b)
+                float g0 = d0 * lw.x, g1 = d1 * lw.y;
+                float s1 = wsum(g0 + g1) * (1.f / FD);
+                float s2 = wsum(g0 * xh0 + g1 * xh1) * (1.f / FD);
+                float inv_s = 1.f / (float)p.S_clip;
+                *reinterpret_cast<float2*>(pooled + 128 + 2 * lane) =
+                    make_float2(rstd * (g0 - s1 - xh0 * s2) * inv_s, rstd * (g1 - s1 - xh1 * s2) * inv_s);
+            }
+            __syncthreads();
+            for (int i = tid; i < S * (FD / 4); i += 256) {
+                int row = i >> 5, c = (i & 31) << 2;
+                *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(pooled + 128 + c);
+            }
+            __syncthreads();
+            pooled[tid] = 0.f;
         } else {
             for (int i = tid; i < S * (FD / 4); i += 256) {
                 int row = i >> 5, c = (i & 31) << 2;
