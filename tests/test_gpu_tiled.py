@@ -120,6 +120,36 @@ def test_tiled_matches_per_clip_kernels_on_shared_work(egx_lib, cuda):
     assert (a - g).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("compute", ["f32s", "bf16"])
+def test_tiled_deterministic_mode_repeats_bit_for_bit(egx_lib, cuda, compute):
+    """set_deterministic() on the tiled path (two layers, train-mode masks, the pooled head whose backward runs inside the first backward
+    tile launch and leaves its parameter gradients in the partial row of a clip's first tile): logits and every gradient repeat bit for
+    bit, and agree with the default (atomic) mode to summation-order noise."""
+    from egot2_amd import functional as F_egx, hhi_ttm
+    B, T = 21, 40                                   # S = 120: three tiles per clip, the last one half empty
+    feats = [f.to(cuda) for f in seeded_feats(91, [(B, T, 256)] * 3)]
+    target = (torch.arange(B, device=cuda) * 5) % 2
+    w = torch.tensor(CE_W, device=cuda)
+
+    def run(det):
+        m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(num_layers=2, dropout=0.3))
+        m.load_state_dict(seeded_state_dict(m, 17))
+        m = m.to(cuda).set_compute(compute).set_deterministic(det).train()
+        m._egx_seed = lambda: 0x7D37
+        logits = m.forward_features(*feats)
+        assert F_egx.last_encoder_impl() == "tiled"
+        torch.nn.functional.cross_entropy(logits, target, weight=w).backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    a, b, c = run(True), run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    assert set(a[1]) == set(c[1]) and any(k.startswith("mlp_head") or "head" in k for k in a[1])
+    for k in a[1]:
+        assert torch.equal(a[1][k], b[1][k]), k
+        assert torch.allclose(a[1][k], c[1][k], rtol=3e-3, atol=2e-6), k
+
+
 def test_tiled_refuses_what_it_cannot_run(egx_lib, cuda):
     from egot2_amd import hhi_ttm, _lib
     m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args())
