@@ -1,6 +1,6 @@
 """Randomised parity sweep of the d = 128 translators against the fp64 oracle (GPU box, repo root) — development aid.
 
-    python3 tools/fuzz_parity.py [seconds, default 300] [rng seed]
+    python3 tools/fuzz_parity.py [--wide] [seconds, default 300] [rng seed]          (--wide: the bf16 wide path through the HOI LTA 4-task translator)
 
 Draws (model, tasks, B, T, layers, compute mode, dropout, deterministic, env knobs) at random, lets the library pick its implementation
 (per-clip kernels with / without the cut at the FFN, sliced small batches, tiled long clips), runs forward + weighted CE + backward and
@@ -109,14 +109,57 @@ def one_case(rng, cuda, idx):
             os.environ.pop(k, None)
 
 
+def one_wide_case(rng, cuda, idx):
+    """HOI LTA 4-task translator (learned positions, 8192-wide PNR / OSCC features, d >= 256) in bf16: the wide path, p = 0."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import functional as F_egx, hoi_lta
+    d, heads = [(256, 4), (256, 8), (512, 8), (768, 8), (384, 4), (512, 4), (1024, 8)][int(rng.integers(0, 7))]
+    L = int(rng.choice([1, 1, 2, 3]))
+    n = int(rng.choice([rng.integers(1, 33), rng.integers(33, 121)]))          # clips per task: S = 4 n (<= 128: one-pass attention; beyond: online softmax)
+    B = int(rng.integers(1, max(2, min(9, 900 // (4 * n))) + 1))
+    cfg = NS(FORECASTING=NS(NUM_INPUT_CLIPS=n, NUM_ACTIONS_TO_PREDICT=3),
+             MODEL=NS(TRANSLATION_HEADS=heads, TRANSLATION_LAYERS=L, TRANSLATION_INPUT_FEATURES=d, TRANSLATION_DROPOUT=0.0,
+                      NUM_CLASSES=[5, 7], DROPOUT_RATE=0.0, HEAD_ACT="softmax"), TEST=NS(NO_ACT=False))
+    m = hoi_lta.TaskFusionMFTransformerLTA4Task(cfg)
+    sd = seeded_state_dict(m, 2000 + idx)
+    m.load_state_dict(sd)
+    m = m.to(cuda).set_compute("bf16").train()
+    feats = seeded_feats(4000 + idx, [(B, n, 8192), (B, n, 8192), (B, n, d), (B, n, 2048)])
+    outs = m.forward_features(*[f.to(cuda) for f in feats])
+    impl = F_egx.last_encoder_impl()
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    (lin(outs[0]) + lin(outs[1])).backward()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref = tr.lta4_forward(sd64, heads, *[f.double() for f in feats], [5, 7])
+    (lin(ref[0]) + lin(ref[1])).backward()
+    torch.cuda.synchronize()
+    err_o = max(((o.detach().cpu().double() - r.detach()).abs().max() / max(1.0, r.abs().max().item())).item() for o, r in zip(outs, ref))
+    errs = {}
+    for k, q in m.named_parameters():
+        r = sd64[k].grad
+        if r is not None and q.grad is not None:
+            errs[k] = (q.grad.detach().cpu().double() - r).norm().item() / (r.norm().item() + 1e-12)
+    missing = [k for k, q in m.named_parameters() if sd64[k].grad is not None and sd64[k].grad.abs().max() > 0 and q.grad is None]
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    tol_g = 6e-2 if L < 3 else 1.0e-1
+    if B * 4 * n < 128:
+        tol_g = max(tol_g, 9e-2)              # a hundred tokens: few terms per weight-gradient element, bf16 operand noise averages out less
+    ok = err_o < 1e-2 and worst[1] < tol_g and not missing and all(np.isfinite(v) for v in errs.values())
+    print(f"[{idx:4d}] {'ok  ' if ok else 'FAIL'} lta4 bf16 B={B:2d} n={n:3d} S={4 * n:3d} d={d} h={heads} L={L} {impl} out {err_o:.2e} grad {worst[1]:.2e} ({worst[0]})"
+          f"{' MISSING ' + str(missing) if missing else ''}", flush=True)
+    return ok
+
+
 def main():
-    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    wide = "--wide" in sys.argv
+    argv = [a for a in sys.argv[1:] if a != "--wide"]
+    secs = float(argv[0]) if len(argv) > 0 else 300.0
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 12345)
     cuda = torch.device("cuda", 0)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < secs:
         try:
-            ok = one_case(rng, cuda, n)
+            ok = (one_wide_case if wide else one_case)(rng, cuda, n)
         except Exception as e:      # noqa: BLE001  (an EgxError for an unsupported pairing is a finding too: print and go on)
             print(f"[{n:4d}] EXC  {type(e).__name__}: {str(e)[:300]}", flush=True)
             ok = False
