@@ -1,6 +1,6 @@
 """Randomised parity sweep of the d = 128 translators against the fp64 oracle (GPU box, repo root) — development aid.
 
-    python3 tools/fuzz_parity.py [--wide] [seconds, default 300] [rng seed]          (--wide: the bf16 wide path through the HOI LTA 4-task translator)
+    python3 tools/fuzz_parity.py [--wide] [seconds, default 300] [rng seed]          (--wide: the bf16 wide path through the HOI LTA 4-task translator; --pnr: the PNR / OSCC recipe)
 
 Draws (model, tasks, B, T, layers, compute mode, dropout, deterministic, env knobs) at random, lets the library pick its implementation
 (per-clip kernels with / without the cut at the FFN, sliced small batches, tiled long clips), runs forward + weighted CE + backward and
@@ -20,6 +20,24 @@ import torch
 from oracle import translator_ref as tr
 from tests import dropmask as dm
 from tests.util import hhi_args, rel_err, seeded_feats, seeded_state_dict
+
+class ReluSpy:
+    """Smallest |ReLU pre-activation| / rms the oracle's forward sees. A hidden unit whose pre-activation is within fp32 rounding of zero
+    (~1e-6 of the rms after a K = 128 dot product) can come out on the other side of the kink in fp32 arithmetic: its gradient contribution
+    flips, and on a batch of a hundred tokens that ONE unit is 1e-2 of a weight gradient's norm (case `--pnr 300 99` #70: exact fp32 2e-6, f32s
+    1.7e-2, smallest pre-activation 1.7e-6). Such cases are judged at 5e-2 and marked `kink`."""
+    def __enter__(self):
+        self.orig, self.ratio = torch.relu, float("inf")
+
+        def spy(x):
+            self.ratio = min(self.ratio, (x.detach().abs().min() / x.detach().pow(2).mean().sqrt().clamp(min=1e-30)).item())
+            return self.orig(x)
+        torch.relu = spy
+        return self
+
+    def __exit__(self, *a):
+        torch.relu = self.orig
+
 
 CE_W = [0.266, 0.734]
 TOL = {"f32": (1e-3, 1e-2), "f32s": (1e-3, 1e-2), "bf16": (1.5e-2, 1.2e-1)}
@@ -71,14 +89,16 @@ def one_case(rng, cuda, idx):
             gen = torch.Generator().manual_seed(idx)
             gout = torch.randn(out.shape, generator=gen)
             (out * gout.to(cuda)).sum().backward()
-            ref = tr.asd_forward(sd64, 4, *[f.double() for f in feats], masks=masks)
+            with ReluSpy() as spy:
+                ref = tr.asd_forward(sd64, 4, *[f.double() for f in feats], masks=masks)
             (ref * gout.double()).sum().backward()
             loss_err = 0.0
         else:
             target = torch.from_numpy(np.random.default_rng(idx).integers(0, 2, B)).long()
             loss = torch.nn.functional.cross_entropy(out, target.to(cuda), weight=torch.tensor(CE_W, device=cuda))
             loss.backward()
-            ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats], masks=masks)
+            with ReluSpy() as spy:
+                ref = tr.ttm_forward(sd64, 4, *[f.double() for f in feats], masks=masks)
             ref_loss = tr.weighted_ce(ref, target, CE_W)
             ref_loss.backward()
             loss_err = abs(loss.item() - ref_loss.item()) / max(1.0, abs(ref_loss.item()))
@@ -86,6 +106,9 @@ def one_case(rng, cuda, idx):
         tol_o, tol_g = TOL[compute]
         if L >= 3 and compute == "bf16":
             tol_g = 1.5e-1
+        kink = compute != "bf16" and spy.ratio < 4e-6
+        if kink:
+            tol_g = 5e-2
         if compute == "bf16" and p >= 0.5:
             tol_o = 2.5e-2                    # kept elements carry a factor 2: bf16 rounding noise of the logits doubles
         if kind == "asd" and compute == "bf16":
@@ -102,7 +125,7 @@ def one_case(rng, cuda, idx):
         ok = err_o < tol_o and loss_err < tol_o and worst[1] < tol_g and not missing and all(np.isfinite(v) for v in errs.values())
         print(f"[{idx:4d}] {'ok  ' if ok else 'FAIL'} {kind} {compute:4s} B={B:3d} T={T:3d} S={S:3d} L={L} p={p} det={int(det)} {impl}"
               f"{'/' + str(slices) if slices and slices > 1 else ''} {env} out {err_o:.2e} loss {loss_err:.2e} grad {worst[1]:.2e} ({worst[0]})"
-              f"{' MISSING ' + str(missing) if missing else ''}", flush=True)
+              f"{' kink %.1e' % spy.ratio if kink else ''}{' MISSING ' + str(missing) if missing else ''}", flush=True)
         return ok
     finally:
         for k in env:
@@ -150,16 +173,75 @@ def one_wide_case(rng, cuda, idx):
     return ok
 
 
+def one_pnr_case(rng, cuda, idx):
+    """The shipped PNR / OSCC EgoT2-s recipe on the per-clip kernels: S = 16 + 16 + 8 + 8, 8 heads of 16, d_ff = 256, 1-6 layers, feature dropout on the
+    projections, learned positions with their gradient, 8192-wide features; train mode under the oracle's masks."""
+    from types import SimpleNamespace as NS
+    from egot2_amd import functional as F_egx, hoi_pnr
+    compute = rng.choice(["f32s", "f32s", "bf16", "f32"])
+    L = int(rng.integers(1, 7))
+    p = float(rng.choice([0.0, 0.1, 0.3]))
+    p_feat = float(rng.choice([0.0, 0.2]))
+    B = int(rng.choice([rng.integers(1, 12), rng.integers(12, 80), rng.integers(80, 300)]))
+    det = bool(rng.random() < 0.2)
+    env = {}
+    if rng.random() < 0.4:
+        env["EGX_FFN_CUT"] = str(int(rng.integers(0, 2)))
+    if rng.random() < 0.3:
+        env["EGX_FFN_SLICES"] = str(int(rng.choice([1, 2, 4, 8])))
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        cfg = NS(DATA=NS(TASK="state_change_detection"),
+                 MODEL=NS(TRANSLATION_INPUT_FEATURES=128, TRANSLATION_LAYERS=L, FEAT_DROPOUT_RATE=p_feat, TRANSFORMER_DROPOUT_RATE=p))
+        m = hoi_pnr.TaskFusionMFTransformer3TaskDropout(cfg)
+        m.load_state_dict(seeded_state_dict(m, 5000 + idx))
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}       # `ln` is shared with linear_head.0
+        m = m.to(cuda).set_compute(compute).set_deterministic(det).train()
+        seed = 0xB0000 + 131 * idx
+        m._egx_seed = lambda: seed
+        feats = seeded_feats(6000 + idx, [(B, 16, 8192), (B, 16, 8192), (B, 8, 2048), (B, 8, 256)])
+        out = m.forward_features(*[f.to(cuda) for f in feats])
+        impl, slices = F_egx.last_encoder_impl(), F_egx.last_encoder_slices()
+        lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+        lin(out).backward()
+        torch.cuda.synchronize()
+        masks = dm.encoder_masks(seed, impl, B, [16, 16, 8, 8], 128, 8, 256, L, p, 0.0, p_feat) if (p > 0 or p_feat > 0) else None
+        sd64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        with ReluSpy() as spy:
+            ref = tr.pnr3_forward(sd64, 8, *[f.double() for f in feats], masks=masks).unsqueeze(2)
+        lin(ref).backward()
+        tol_o, tol_g = {"f32": (1e-3, 1e-2), "f32s": (1e-3, 1e-2), "bf16": (1.5e-2, 8e-2)}[compute]
+        if compute == "bf16" and L >= 4:
+            tol_g = 1.5e-1
+        kink = compute != "bf16" and spy.ratio < 4e-6
+        if kink:
+            tol_g = 5e-2
+        err_o = ((out.detach().double().cpu() - ref.detach()).abs() / ref.detach().abs().clamp(min=1.0)).max().item()
+        named = dict(m.named_parameters())
+        errs = {k: rel_err(named[k].grad, sd64[k].grad) for k in named if sd64[k].grad is not None and named[k].grad is not None}
+        missing = [k for k in named if sd64[k].grad is not None and sd64[k].grad.abs().max() > 0 and named[k].grad is None]
+        worst = max(errs.items(), key=lambda kv: kv[1])
+        ok = err_o < tol_o and worst[1] < tol_g and not missing and all(np.isfinite(v) for v in errs.values())
+        print(f"[{idx:4d}] {'ok  ' if ok else 'FAIL'} pnr3 {compute:4s} B={B:3d} L={L} p={p} p_feat={p_feat} det={int(det)} {impl}{'/' + str(slices) if slices > 1 else ''} {env} "
+              f"out {err_o:.2e} grad {worst[1]:.2e} ({worst[0]}){' kink %.1e' % spy.ratio if kink else ''}{' MISSING ' + str(missing) if missing else ''}", flush=True)
+        return ok
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
 def main():
     wide = "--wide" in sys.argv
-    argv = [a for a in sys.argv[1:] if a != "--wide"]
+    pnr = "--pnr" in sys.argv
+    argv = [a for a in sys.argv[1:] if a not in ("--wide", "--pnr")]
     secs = float(argv[0]) if len(argv) > 0 else 300.0
     rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 12345)
     cuda = torch.device("cuda", 0)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < secs:
         try:
-            ok = (one_wide_case if wide else one_case)(rng, cuda, n)
+            ok = (one_wide_case if wide else one_pnr_case if pnr else one_case)(rng, cuda, n)
         except Exception as e:      # noqa: BLE001  (an EgxError for an unsupported pairing is a finding too: print and go on)
             print(f"[{n:4d}] EXC  {type(e).__name__}: {str(e)[:300]}", flush=True)
             ok = False
