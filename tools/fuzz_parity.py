@@ -1,6 +1,6 @@
 """Randomised parity sweep of the d = 128 translators against the fp64 oracle (GPU box, repo root) — development aid.
 
-    python3 tools/fuzz_parity.py [--wide] [seconds, default 300] [rng seed]          (--wide: the bf16 wide path through the HOI LTA 4-task translator; --pnr: the PNR / OSCC recipe; --hhig: EgoT2-g HHI encoder + decoder)
+    python3 tools/fuzz_parity.py [--wide] [seconds, default 300] [rng seed]          (--wide: the bf16 wide path through the HOI LTA 4-task translator; --pnr: the PNR / OSCC recipe; --hhig: EgoT2-g HHI encoder + decoder; --hoig: EgoT2-g HOI encoder)
 
 Draws (model, tasks, B, T, layers, compute mode, dropout, deterministic, env knobs) at random, lets the library pick its implementation
 (per-clip kernels with / without the cut at the FFN, sliced small batches, tiled long clips), runs forward + weighted CE + backward and
@@ -277,18 +277,59 @@ def one_hhig_case(rng, cuda, idx):
     return ok
 
 
+def one_hoig_case(rng, cuda, idx):
+    """EgoT2-g HOI encoder (HOI/models/multitask/video_model_builder.py): both prompt layouts of encode() — 'pnr' (16 + 16 + 8 + 8 tokens, SlowFast pathways
+    projected separately) and 'lta_verb' (per-clip PNR / OSCC frames + action + LTA features, 4 n tokens) — in bf16 (wide path) or fp32 (generic kernels)."""
+    from egot2_amd import functional as F_egx
+    from tests.test_oracle_golden import build_ours, fixture_feats
+    compute = str(rng.choice(["bf16", "bf16", "f32"]))
+    d, h = [(512, 8), (256, 4), (256, 8), (512, 4)][int(rng.integers(0, 4))]
+    c = dict(kind="hoig", B=int(rng.integers(1, 9)), n=int(rng.integers(1, 13)), L=int(rng.choice([1, 2, 3])), d=d, h=h, wseed=9000 + idx, fseed=9500 + idx)
+    model = build_ours(c)
+    sd = seeded_state_dict(model, c["wseed"])
+    model.load_state_dict(sd)
+    model = model.to(cuda).set_compute(compute).train()
+    model.pos_embed.dropout.p = 0.0
+    feats = fixture_feats(c)
+    fd = [f.to(cuda) for f in feats]
+    lin = lambda t: (t * torch.linspace(-1, 1, t.numel(), device=t.device, dtype=t.dtype).view_as(t)).sum()  # noqa: E731
+    outs = [model.encode_features("pnr", *fd[:4])]
+    impl = F_egx.last_encoder_impl()
+    outs.append(model.encode_features("lta_verb", *fd[4:]))
+    (lin(outs[0]) + lin(outs[1])).backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    f64 = [f.double() for f in feats]
+    refs = [tr.hoi_g_encode(sd64, h, "pnr", *f64[:4]), tr.hoi_g_encode(sd64, h, "lta_verb", *f64[4:])]
+    (lin(refs[0]) + lin(refs[1])).backward()
+    err_o = max((o.detach().cpu().double() - r.detach()).abs().max().item() / max(1.0, r.abs().max().item()) for o, r in zip(outs, refs))
+    errs = {}
+    for k, q in model.named_parameters():
+        r = sd64[k].grad if k in sd64 else None
+        if r is not None and q.grad is not None:
+            errs[k] = (q.grad.detach().cpu().double() - r).norm().item() / (r.norm().item() + 1e-12)
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    tol_o, tol_g = (1e-3, 1e-2) if compute == "f32" else (1e-2, 6e-2 if c["L"] < 3 else 1e-1)
+    if compute == "bf16" and c["B"] * 48 < 150:
+        tol_g = max(tol_g, 9e-2)
+    ok = err_o < tol_o and worst[1] < tol_g and len(errs) >= 25 and all(np.isfinite(v) for v in errs.values())
+    print(f"[{idx:4d}] {'ok  ' if ok else 'FAIL'} hoig {compute:4s} B={c['B']} n={c['n']:2d} d={d} h={h} L={c['L']} {impl} out {err_o:.2e} grad {worst[1]:.2e} ({worst[0]}) [{len(errs)} grads]", flush=True)
+    return ok
+
+
 def main():
     wide = "--wide" in sys.argv
     pnr = "--pnr" in sys.argv
     hhig = "--hhig" in sys.argv
-    argv = [a for a in sys.argv[1:] if a not in ("--wide", "--pnr", "--hhig")]
+    hoig = "--hoig" in sys.argv
+    argv = [a for a in sys.argv[1:] if a not in ("--wide", "--pnr", "--hhig", "--hoig")]
     secs = float(argv[0]) if len(argv) > 0 else 300.0
     rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 12345)
     cuda = torch.device("cuda", 0)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < secs:
         try:
-            ok = (one_wide_case if wide else one_pnr_case if pnr else one_hhig_case if hhig else one_case)(rng, cuda, n)
+            ok = (one_wide_case if wide else one_pnr_case if pnr else one_hhig_case if hhig else one_hoig_case if hoig else one_case)(rng, cuda, n)
         except Exception as e:      # noqa: BLE001  (an EgxError for an unsupported pairing is a finding too: print and go on)
             print(f"[{n:4d}] EXC  {type(e).__name__}: {str(e)[:300]}", flush=True)
             ok = False
