@@ -128,3 +128,74 @@ class FusedAdam(torch.optim.Optimizer):
                                         ptr(self._step_dev), group["lr"], group["betas"][0], group["betas"][1],
                                         group["eps"], group["weight_decay"], int(group["adamw"]), 1.0, stream))
         return loss
+
+
+class GraphedStep:
+    """One training step — forward, loss, backward and (optionally) the optimizer update — captured ONCE as a hipGraph and replayed.
+
+    The library only enqueues kernels on the current stream and keeps what changes from step to step in device memory (the dropout seed after
+    `model.enable_device_seed()`, FusedAdam's step count), so a replay is exact training work with fresh masks; what the capture removes is the
+    host side of the step (Python, autograd, ~8 launches: 0.54 ms per step on the bench configuration against 0.39 ms of GPU time). This is the
+    loop `bench.py` times, packaged for a training script:
+
+        step = GraphedStep(lambda f, y: criterion(model.forward_features(*f), y), example_inputs=(feats, target),
+                           params=model.parameters(), optimizer=FusedAdam(model.parameters(), lr=1e-4))
+        for feats, target in loader:
+            loss = step(feats, target)          # copies the batch into the captured buffers, replays, returns the loss tensor (device)
+
+    `loss_fn(*inputs)` must be a pure function of its (possibly nested list / tuple of) tensor arguments with FIXED shapes and dtypes: a batch of
+    another shape needs another GraphedStep (the reference's length-bucketed TTM sampler yields a handful of shapes — keep one per shape).
+    Gradients stay in `.grad` after every replay (`optimizer=None`: update them yourself outside the graph)."""
+
+    def __init__(self, loss_fn, example_inputs, params, optimizer=None, warmup: int = 3):
+        self.loss_fn, self.optimizer = loss_fn, optimizer
+        self.params = [p for p in params if p.requires_grad]
+        self.static = self._clone_tree(example_inputs)
+        self._one = None
+        dev = self.params[0].device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):        # allocator, lazy initialisation, FusedAdam's flat buffers: all before the capture
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss = self._step()
+        torch.cuda.synchronize(dev)
+
+    def _clone_tree(self, t):
+        if isinstance(t, torch.Tensor):
+            return t.detach().clone()
+        if isinstance(t, (list, tuple)):
+            return type(t)(self._clone_tree(x) for x in t)
+        raise TypeError(f"GraphedStep: inputs must be tensors or nested lists / tuples of tensors, got {type(t).__name__}")
+
+    def _copy_tree(self, dst, src):
+        if isinstance(dst, torch.Tensor):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError(f"GraphedStep: input of shape {tuple(src.shape)} / {src.dtype} where the step was captured with "
+                                 f"{tuple(dst.shape)} / {dst.dtype} (one GraphedStep per batch shape)")
+            dst.copy_(src, non_blocking=True)
+        else:
+            if len(dst) != len(src):
+                raise ValueError("GraphedStep: input structure differs from the captured one")
+            for d, s in zip(dst, src):
+                self._copy_tree(d, s)
+
+    def _step(self):
+        for p in self.params:
+            p.grad = None
+        loss = self.loss_fn(*self.static)
+        if self._one is None:
+            self._one = torch.ones_like(loss)
+        loss.backward(gradient=self._one)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, *inputs):
+        self._copy_tree(self.static, type(self.static)(inputs) if isinstance(self.static, (list, tuple)) else inputs[0])
+        self.graph.replay()
+        return self.loss

@@ -154,6 +154,44 @@ def test_whole_training_step_in_one_graph(egx_lib, cuda, compute):
     assert int(opt._step_dev.item()) == 4 and torch.isfinite(loss).item()
 
 
+def test_graphed_step_helper_follows_the_eager_loop(egx_lib, cuda):
+    """train.GraphedStep (the bench's replayed step packaged for a training script): three DIFFERENT batches fed to the captured step must
+    leave the parameters where the eager loop over the same batches leaves them (p = 0: no masks to match), the returned loss must be the
+    current batch's, and a batch of another shape is refused with an error instead of being run on stale buffers."""
+    from egot2_amd.train import CrossEntropyLoss, FusedAdam, GraphedStep
+    crit = CrossEntropyLoss(torch.FloatTensor(CE_W)).to(cuda)
+    batches = [([f.to(cuda) for f in seeded_feats(300 + i, [(12, 15, 256)] * 3)],
+                torch.randint(0, 2, (12,), generator=torch.Generator().manual_seed(i)).to(cuda)) for i in range(4)]
+    warm = 2
+
+    def loss_of(model):
+        return lambda f, y: crit(model.forward_features(*f), y)
+
+    ref = _ttm(cuda, 3).set_compute("f32s")
+    opt_r = FusedAdam(ref.parameters(), lr=5e-4)
+    ref_losses = []
+    # the helper runs `warm` eager steps on the example batch and one more (the capture itself does not execute), then one per call
+    for f, y in [batches[0]] * warm + batches[1:]:
+        opt_r.zero_grad(set_to_none=True)
+        loss = loss_of(ref)(f, y)
+        loss.backward()
+        opt_r.step()
+        ref_losses.append(loss.item())
+
+    m = _ttm(cuda, 3).set_compute("f32s")
+    step = GraphedStep(loss_of(m), example_inputs=batches[0], params=list(m.parameters()), optimizer=FusedAdam(m.parameters(), lr=5e-4), warmup=warm)
+    got = [step(f, y).item() for f, y in batches[1:]]
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref_losses[warm:]):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (got, ref_losses)
+    for (n, pa), (_, pb) in zip(m.named_parameters(), ref.named_parameters()):
+        assert (pa - pb).abs().max().item() <= 2.0 * 5e-4 * (warm + 3), n
+        assert (pa - pb).abs().median().item() < 2e-5, n
+    assert all(p.grad is not None for p in m.parameters() if p.requires_grad)
+    with pytest.raises(ValueError, match="one GraphedStep per batch shape"):
+        step([f[:5] for f in batches[1][0]], batches[1][1][:5])
+
+
 def test_staged_backward_and_overlapped_allreduce_layout(egx_lib, cuda):
     """egx_defer_small: the backward stops before the grouped small weight gradients, run_deferred() finishes it, and the
     result equals the one-shot backward; the late gradients (dW_proj, dW_in, dW_o) sit first in the flat buffer so that
