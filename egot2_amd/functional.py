@@ -138,37 +138,45 @@ class _GradPacker:
         self.entries.append((t.shape, (t.numel() + 3) // 4 * 4, late, rank))
         return len(self.entries) - 1
 
+    _layouts: dict = {}          # entries signature -> (offsets, total, late_floats, rank_span, strides): a model's backward lays out the same buffer every step
+
     def materialise(self, device, zero: bool = True) -> List[Optional[torch.Tensor]]:
         """zero=False: the caller hands `self.flat` to the library, whose backward zero-fills it (egx_config.zero_buf)."""
-        offs, cur = {}, 0
-        self.rank_span = {}
-        order = sorted((i for i, e in enumerate(self.entries) if e is not None), key=lambda i: self.entries[i][3])
-        for want_late in (True, False):
-            for i in order:
-                e = self.entries[i]
-                if e[2] == want_late:
-                    offs[i] = cur
-                    lo, hi = self.rank_span.get(e[3], (cur, cur))
-                    self.rank_span[e[3]] = (min(lo, cur), cur + e[1])
-                    cur += e[1]
-            if want_late:
-                self.late_floats = cur
-        self.total = cur
-        n = max(cur, 4)
+        sig = tuple(self.entries)
+        lay = _GradPacker._layouts.get(sig)
+        if lay is None:
+            offs, cur, rank_span, late_floats = {}, 0, {}, 0
+            order = sorted((i for i, e in enumerate(self.entries) if e is not None), key=lambda i: self.entries[i][3])
+            for want_late in (True, False):
+                for i in order:
+                    e = self.entries[i]
+                    if e[2] == want_late:
+                        offs[i] = cur
+                        lo, hi = rank_span.get(e[3], (cur, cur))
+                        rank_span[e[3]] = (min(lo, cur), cur + e[1])
+                        cur += e[1]
+                if want_late:
+                    late_floats = cur
+            strides = {}
+            for i, e in enumerate(self.entries):
+                if e is not None:
+                    st, acc = [], 1
+                    for k in reversed(e[0]):
+                        st.append(acc)
+                        acc *= k
+                    strides[i] = tuple(reversed(st))
+            if len(_GradPacker._layouts) > 256:
+                _GradPacker._layouts.clear()
+            lay = _GradPacker._layouts[sig] = (offs, cur, late_floats, rank_span, strides)
+        offs, self.total, self.late_floats, rank_span, strides = lay
+        self.rank_span = dict(rank_span)
+        n = max(self.total, 4)
         flat = torch.zeros(n, dtype=torch.float32, device=device) if zero else torch.empty(n, dtype=torch.float32, device=device)
         if _POISON and not zero:
             flat.fill_(float("nan"))
         self.flat = flat
-        out = []
-        for i, e in enumerate(self.entries):
-            if e is None:
-                out.append(None)
-            else:
-                numel = 1
-                for k in e[0]:
-                    numel *= k
-                out.append(flat[offs[i]:offs[i] + numel].view(e[0]))
-        return out
+        # one as_strided per gradient (a slice + a view were two tensor constructions each: 50 per backward of the TTM translator)
+        return [None if e is None else flat.as_strided(e[0], strides[i], offs[i]) for i, e in enumerate(self.entries)]
 
 
 _deferred = []          # closures that finish a staged backward (EncoderSpec.defer_small)

@@ -109,8 +109,11 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
                     raise ValueError("FusedAdam needs contiguous fp32 gradients on the GPU")
-                base = F_egx.flat_storage_view(g)           # the flat buffer this gradient was carved out of
-                by_base.setdefault(base.data_ptr(), (base, []))[1].append((p, g.storage_offset()))
+                key = g.untyped_storage().data_ptr()        # the flat buffer this gradient was carved out of: one view per buffer,
+                ent = by_base.get(key)                       # not one per parameter (25 tensor constructions per step on the TTM translator)
+                if ent is None:
+                    ent = by_base[key] = (F_egx.flat_storage_view(g), [])
+                ent[1].append((p, g.storage_offset()))
             for base, members in by_base.values():
                 if self._step_dev is None:
                     self._step_dev = torch.full((), self._resume_step, dtype=torch.int64, device=base.device)
