@@ -138,7 +138,8 @@ class GraphedStep:
 
     The library only enqueues kernels on the current stream and keeps what changes from step to step in device memory (the dropout seed after
     `model.enable_device_seed()`, FusedAdam's step count), so a replay is exact training work with fresh masks; what the capture removes is the
-    host side of the step (Python, autograd, ~8 launches: 0.54 ms per step on the bench configuration against 0.39 ms of GPU time). This is the
+    host side of the step (Python, the autograd engine's worker thread, a dozen launches: 0.54 - 0.90 ms per step on the bench configuration with
+    FusedAdam against 0.41 ms of GPU time). This is the
     loop `bench.py` times, packaged for a training script:
 
         step = GraphedStep(lambda f, y: criterion(model.forward_features(*f), y), example_inputs=(feats, target),
