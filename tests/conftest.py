@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# No bytecode caches from the test runs: the CPU suite imports tests/host_paths.py (the host-side ASAN + UBSan harness, CPU container only), and a
+# stale tests/__pycache__/host_paths.*.pyc left behind by a CPU run is the same harness in another encoding — the GPU pool refuses sanitizer
+# builds, so it must not travel there (see .gpurunignore). Set before any test module is imported.
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
