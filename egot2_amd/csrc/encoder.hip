@@ -581,6 +581,15 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     EGX_CHECK(with_head ? (logits_out != nullptr) : (tokens_out != nullptr), "null output pointer");
     EGX_CHECK(!with_head || (head->ln_w && head->ln_b && head->b && head->n_out >= 1 && head->n_out <= FUSED_HEAD_MAX_OUT),
               "head needs ln_w, ln_b, W, b and 1 <= n_out <= %d", FUSED_HEAD_MAX_OUT);
+    // A HOST seed is baked into a captured graph: every replay would draw the SAME dropout masks — training that runs, converges worse and
+    // says nothing. Refused (as the decoder does, wide_decoder.hip refuse_captured_dropout); with egx_config.seed_ptr the seed lives in device
+    // memory and is advanced on the stream, so replays draw fresh masks (model.enable_device_seed(), train.GraphedStep).
+    if (training && !cfg->seed_ptr && (cfg->p_drop > 0.f || cfg->p_pos > 0.f || cfg->p_feat > 0.f)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        EGX_CHECK(cs == hipStreamCaptureStatusNone, "training-mode dropout (p > 0) with a host seed cannot be captured in a hipGraph: every replay would "
+                  "repeat the same masks; pass egx_config.seed_ptr (model.enable_device_seed()), capture with p = 0, or launch eagerly");
+    }
     bool ferr, terr = false;
     const bool fused = use_fused(cfg, segs, pl, &ferr);
     const bool tiled = !fused && !ferr && use_tiled(cfg, segs, pl, &terr);

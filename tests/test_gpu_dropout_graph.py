@@ -162,3 +162,33 @@ def test_wide_path_step_graph_replay_draws_fresh_masks(egx_lib, cuda):
     torch.cuda.synchronize()
     g2 = m.transformer.layers[0].linear1.weight.grad.clone()
     assert torch.isfinite(g2).all() and (g1 - g2).abs().max().item() > 0 and loss.item() != l1
+
+
+def test_capturing_training_dropout_with_a_host_seed_is_refused(egx_lib, cuda):
+    """A host seed is baked into a captured graph: every replay would repeat the same masks. The library refuses that capture (fused, tiled and
+    wide implementations alike) instead of training silently on one mask; with the device-resident seed the same capture goes through, and
+    p = 0 needs no seed at all."""
+    from egot2_amd import hhi_ttm, _lib
+    feats = [f.to(cuda) for f in seeded_feats(5, [(4, 15, 256)] * 3)]
+
+    def try_capture(model):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model.forward_features(*feats).sum().backward()        # eager warm-up: fine with any seed
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            model.forward_features(*feats).sum().backward()
+        g.replay()
+        torch.cuda.synchronize()
+
+    m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.3)).to(cuda).set_compute("f32s").train()
+    with pytest.raises(_lib.EgxError, match="cannot be captured in a hipGraph"):
+        try_capture(m)
+    torch.cuda.synchronize()
+    try_capture(m.enable_device_seed())                                    # device seed: allowed
+    m0 = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.0)).to(cuda).set_compute("f32s").train()
+    m0.pos_embed.dropout.p = 0.0
+    try_capture(m0)                                                        # no dropout: nothing to bake in
