@@ -1917,12 +1917,17 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                     mma<CM>(sN, ldq(qt), ldk(kt));    // S = Q K^T
                     mma<CM>(dN, ldo(qt), ldv(kt));    // dP = dO V^T
                     int key = kt * 16 + r;
+                    // the lane's four elements are four mask ROWS (queries) of one key: one hash per lane and tile, exchanged inside the quad
+                    // (common.h tile_keep_rows), instead of four
+                    uint32_t m4[4] = {0xFu, 0xFu, 0xFu, 0xFu};
+                    if (w.attn_thresh) tile_keep_rows(k_attn, (uint32_t)((clip * NHEAD + h) * 64 + qt * 16), (uint32_t)(kt * 4), r, q, w.attn_thresh, m4);
+                    const float kinv = w.attn_thresh ? w.drop_inv : 1.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         int query = qt * 16 + 4 * q + e;
                         bool ok = (key < S) && (query < S);
                         float pv = ok ? __expf(sN[e] * scale - mq[e]) * iq[e] : 0.f;
-                        float ks = keep(query, key);
+                        float ks = ((m4[e] >> (r & 3)) & 1u) ? kinv : 0.f;
                         pn[qt][kt][e] = pv * ks;
                         dsn[qt][kt][e] = pv * (ks * dN[e] - dq4[e]) * scale;
                     }
