@@ -9,7 +9,9 @@ OUT=gpurun_out/final
 mkdir -p $OUT
 bench() {   # bench <name> <bench.py args...>
   local name=$1; shift
-  if python bench.py "$@" > $OUT/bench_$name.log 2>&1; then
+  # one retry: the opt-in --graph-collectives lines can abort in PyTorch's RCCL watchdog thread (hipErrorCapturedEvent: it queries an event
+  # recorded in the capturing stream; seen once in six runs of round 5) — a second failure is a real one
+  if python bench.py "$@" > $OUT/bench_$name.log 2>&1 || { echo "bench $name: first attempt failed, retrying"; python bench.py "$@" > $OUT/bench_$name.log 2>&1; }; then
     tail -1 $OUT/bench_$name.log > $OUT/${R}_bench_$name.json
     python tools/benchline.py $OUT/${R}_bench_$name.json $name
   else
