@@ -192,6 +192,34 @@ def test_graphed_step_helper_follows_the_eager_loop(egx_lib, cuda):
         step([f[:5] for f in batches[1][0]], batches[1][1][:5])
 
 
+def test_graphed_step_draws_fresh_masks_and_refuses_a_host_seed(egx_lib, cuda):
+    """GraphedStep on a model WITH dropout: after enable_device_seed() every replay draws fresh masks (the same batch gives different losses from
+    replay to replay — no optimizer, so the weights stay put), and without the device-resident seed the capture is refused by the library instead
+    of baking one mask into the graph."""
+    from egot2_amd import hhi_ttm, _lib
+    from egot2_amd.train import CrossEntropyLoss, GraphedStep
+    crit = CrossEntropyLoss(torch.FloatTensor(CE_W)).to(cuda)
+    feats = [f.to(cuda) for f in seeded_feats(17, [(24, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (24,), generator=torch.Generator().manual_seed(3)).to(cuda)
+
+    def build():
+        m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5))
+        m.load_state_dict(seeded_state_dict(m, 21))
+        return m.to(cuda).set_compute("f32s").train()
+
+    m = build().enable_device_seed()
+    step = GraphedStep(lambda f, y: crit(m.forward_features(*f), y), (feats, target), list(m.parameters()))
+    losses = [step(feats, target).item() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert len({round(v, 6) for v in losses}) >= 5, losses                 # fresh masks: (almost surely) six different losses
+    assert all(abs(v) < 20 for v in losses)
+
+    m2 = build()                                                           # host seed
+    with pytest.raises(_lib.EgxError, match="cannot be captured in a hipGraph"):
+        GraphedStep(lambda f, y: crit(m2.forward_features(*f), y), (feats, target), list(m2.parameters()))
+    torch.cuda.synchronize()
+
+
 def test_staged_backward_and_overlapped_allreduce_layout(egx_lib, cuda):
     """egx_defer_small: the backward stops before the grouped small weight gradients, run_deferred() finishes it, and the
     result equals the one-shot backward; the late gradients (dW_proj, dW_in, dW_o) sit first in the flat buffer so that
