@@ -243,8 +243,12 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 // token-along-K operand tiles (fused_dev.h store_hid_tile), so a wave's A fragments are plain coalesced 1 KB loads
 // and only the two weight-gradient GEMMs remain. K-blocks are pairs of 16-token tiles of the clip-padded token
 // grid (FUSED_TOK_TILES per clip); x1 / g rows of padding tokens are staged as zeros.
-template <int CM, int OCC>
-__global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) {
+// PART (round 5, f32s): 0 = both weight gradients in one workgroup (the kernel of rounds 3-4); 1 = dW1 (+ db1) only, 2 = dW2 only. A PART workgroup
+// keeps one accumulator set, stages one operand image (x1 or g: 27 KB of planes) and reads one of the H / dH tile streams: about half the
+// registers and half the LDS, so FOUR workgroups share a CU where two did. ffn_dw_split2_kernel launches both parts as one grid (blockIdx.z).
+template <int CM, int OCC, int PART>
+__device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
+    constexpr bool W1 = PART != 2, W2 = PART != 1;
     constexpr bool BF16 = CM == CM_BF16;
     constexpr bool SPLIT = CM == CM_SPLIT;
     // OCC 3: single LDS buffer, no register prefetch, three workgroups per CU. CM_SPLIT: single buffer of three bf16
@@ -297,6 +301,7 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const int tp = i >> 1, tensor = tp / 3, part = tp - tensor * 3;
+                if ((tensor == 0 && !W1) || (tensor == 1 && !W2)) continue;
                 const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
                 int tile = kb * 2 + (row >> 4);
                 const unsigned short* src = reinterpret_cast<const unsigned short*>(tensor ? p.g : p.x1) + part * plane +
@@ -323,18 +328,24 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             nD.a = reinterpret_cast<const uint2*>((const char*)p.dhs + oa)[lane];
             nD.b = reinterpret_cast<const uint2*>((const char*)p.dhs + ob)[lane];
         } else {
-            nH.a = reinterpret_cast<const float4*>((const char*)p.hs + oa)[lane];
-            nH.b = reinterpret_cast<const float4*>((const char*)p.hs + ob)[lane];
-            nD.a = reinterpret_cast<const float4*>((const char*)p.dhs + oa)[lane];
-            nD.b = reinterpret_cast<const float4*>((const char*)p.dhs + ob)[lane];
+            if constexpr (W2) {
+                nH.a = reinterpret_cast<const float4*>((const char*)p.hs + oa)[lane];
+                nH.b = reinterpret_cast<const float4*>((const char*)p.hs + ob)[lane];
+            }
+            if constexpr (W1) {
+                nD.a = reinterpret_cast<const float4*>((const char*)p.dhs + oa)[lane];
+                nD.b = reinterpret_cast<const float4*>((const char*)p.dhs + ob)[lane];
+            }
         }
     };
     auto lstore = [&](int buf_idx) {
         if constexpr (SPLIT) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
+                if ((i < 6 && !W1) || (i >= 6 && !W2)) continue;
                 const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
-                *reinterpret_cast<uint4*>(ldsh + (i >> 1) * TILEH + row * LDB + c8 * 8) = prs[i];
+                // (a PART workgroup has ONE operand image: it sits where tensor 0's would)
+                *reinterpret_cast<uint4*>(ldsh + ((i >> 1) - (PART == 2 ? 3 : 0)) * TILEH + row * LDB + c8 * 8) = prs[i];
             }
             return;
         }
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
             return f;
         } else if constexpr (SPLIT) {
             const int i = lane & 15;
-            const unsigned short* b = ldsh + tensor * 3 * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
+            const unsigned short* b = ldsh + (PART == 2 ? 0 : tensor) * 3 * TILEH + (4 * q + (i >> 2)) * LDB + jt * 16 + 4 * (i & 3);
             Frag<CM_SPLIT> f;
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -402,10 +413,12 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
         Frag<CM> aH, aD;
         if constexpr (!BF16) {
-            float s0 = (nD.a.x + nD.a.y) + (nD.a.z + nD.a.w), s1 = (nD.b.x + nD.b.y) + (nD.b.z + nD.b.w);
-            accB1 += s0 + (has_b ? s1 : 0.f);
-            aH = make_frag<CM>(nH.a, nH.b);
-            aD = make_frag<CM>(nD.a, nD.b);
+            if constexpr (W1) {
+                float s0 = (nD.a.x + nD.a.y) + (nD.a.z + nD.a.w), s1 = (nD.b.x + nD.b.y) + (nD.b.z + nD.b.w);
+                accB1 += s0 + (has_b ? s1 : 0.f);
+                aD = make_frag<CM>(nD.a, nD.b);
+            }
+            if constexpr (W2) aH = make_frag<CM>(nH.a, nH.b);
         } else {
             // CM_BF16: tiles arrive in accumulator layout (lane = token r, 4 hidden units 4q..4q+3). Stage this wave's two
             // K-blocks ([32 tokens][16 hidden] bf16, unpadded 32-byte rows: writes and transposed reads are conflict-free) and
@@ -457,10 +470,8 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         if ((PF || PF1) && kb + 1 < kb_end) gload(kb + 1);
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            Frag<CM> bx = tok_frag(cur, 0, jt);
-            Frag<CM> bg = tok_frag(cur, 1, jt);
-            mma<CM>(accW1[jt], aD, bx);
-            mma<CM>(accW2[jt], aH, bg);
+            if constexpr (W1) { Frag<CM> bx = tok_frag(cur, 0, jt); mma<CM>(accW1[jt], aD, bx); }
+            if constexpr (W2) { Frag<CM> bg = tok_frag(cur, 1, jt); mma<CM>(accW2[jt], aH, bg); }
         }
         if constexpr (PF) cur ^= 1;
     }
@@ -470,16 +481,21 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
     const int hrow = htile * 16 + 4 * q;
 #pragma unroll
     for (int jt = 0; jt < 8; ++jt) {
+        if constexpr (W1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[jt][e];
-        *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
-            make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
+            for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[jt][e];
+        }
+        if constexpr (W2)
+            *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
+                make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
     }
     if constexpr (!BF16) {
-        float bs = accB1;
-        bs += __shfl_xor(bs, 16, 64);
-        bs += __shfl_xor(bs, 32, 64);
-        if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+        if constexpr (W1) {
+            float bs = accB1;
+            bs += __shfl_xor(bs, 16, 64);
+            bs += __shfl_xor(bs, 32, 64);
+            if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -489,6 +505,14 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
         }
         if (r == 0) *reinterpret_cast<float4*>(p.slab_b1 + (size_t)split * p.d_ff + htile * 16 + 4 * q) = make_float4(accB4[0], accB4[1], accB4[2], accB4[3]);
     }
+}
+
+template <int CM, int OCC>
+__global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) { ffn_dw_stored_body<CM, OCC, 0>(p); }
+// f32s: dW1 (+ db1) workgroups (blockIdx.z = 0) and dW2 workgroups (z = 1) in one grid, four per CU
+__global__ __launch_bounds__(256, 4) void ffn_dw_split2_kernel(FfnDwParams p) {
+    if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1>(p);
+    else ffn_dw_stored_body<CM_SPLIT, 2, 2>(p);
 }
 
 // bf16 stored-operand kernel with everything staged by LDS-DMA. ffn_dw_stored_kernel<CM_BF16> spends a K-block's time on
@@ -700,15 +724,30 @@ static bool ffn_dw_ring() {
     return v == 1;
 }
 bool ffn_dw_bf16_planes() { return ffn_dw_ring(); }
-static int ffn_dw_splits(int nkb, int occ) {
+// most token splits any variant uses for a hidden width: a narrow FFN (the PNR / OSCC recipe's d_ff = 256: four hidden groups) needs more of them
+// to fill the chip; its slabs are small
+static int ffn_dw_max_splits(int d_ff) { return d_ff <= 512 ? 48 : 24; }
+// EGX_FFN_DW_SPLIT2=0: the one-workgroup-for-both-gradients kernel of rounds 3-4 in f32s (tuning aid)
+static bool ffn_dw_split2() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("EGX_FFN_DW_SPLIT2"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+static int ffn_dw_splits(int nkb, int occ, int d_ff, bool split2) {
     static int env = -1;
     if (env < 0) { const char* e = getenv("EGX_FFN_DW_SPLITS"); env = e ? atoi(e) : 0; }     // tuning aid
-    if (env > 0) return min(nkb, min(env, 24));
-    return min(nkb, occ == 3 ? 24 : 16);
+    const int cap = ffn_dw_max_splits(d_ff);
+    if (env > 0) return min(nkb, min(env, cap));
+    int sp = occ == 3 ? 24 : 16;
+    // f32s (one grid of dW1 and dW2 workgroups, four per CU): aim at ~1024 workgroups. d_ff = 256: 1663 -> 1595 us per PNR step at 24 splits,
+    // measured; 2048-wide FFNs keep 16 (12 and 24 both slower on C2)
+    // (the other variants: one workgroup per (group, split), two or three per CU: ~512)
+    { const int groups = d_ff / 64, per = split2 ? 2 : 1, want = split2 ? 1024 : 512; while (sp < cap && per * groups * sp < want) sp += 8; }
+    return min(nkb, min(sp, cap));
 }
 size_t ffn_dw_scratch_bytes(int N, int d_ff, int* splits_out) {
     int nkb = (N + 31) / 32;
-    int splits = min(nkb, 24);           // sized for the largest split count any variant uses
+    int splits = min(nkb, ffn_dw_max_splits(d_ff));           // sized for the largest split count any variant uses
     if (splits_out) *splits_out = splits;
     return (size_t)splits * ((size_t)2 * d_ff * FD + d_ff) * sizeof(float);
 }
@@ -748,7 +787,14 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + tstage_bytes)));
             attr2_set = true;
         }
-        if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2 + tstage_bytes, st, p);
+        if (CM == CM_SPLIT && ffn_dw_split2()) {
+            static bool attr4_set = false;
+            if (!attr4_set) {
+                EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
+                attr4_set = true;
+            }
+            hipLaunchKernelGGL(ffn_dw_split2_kernel, dim3(grid.x, grid.y, 2), dim3(256), lds / 2, st, p);
+        } else if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2 + tstage_bytes, st, p);
         else hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 2>), grid, dim3(256), lds + tstage_bytes, st, p);
     } else {
         hipLaunchKernelGGL((ffn_dw_kernel<CM, HT>), grid, dim3(256), lds, st, p);
@@ -764,7 +810,8 @@ int ffn_dw(FfnDwParams p, int compute, float* dW1, float* db1, float* dW2, void*
     EGX_CHECK(p.d_ff % 128 == 0, "ffn_dw: d_ff=%d must be a multiple of 128", p.d_ff);
     EGX_CHECK(!p.hs == !p.dhs, "ffn_dw: H and dH tiles must be given together");
     int nkb = p.hs ? (p.B * FUSED_TOK_TILES + 1) / 2 : (p.N + 31) / 32;
-    int splits = ffn_dw_splits((p.N + 31) / 32, (compute == CM_SPLIT && p.hs) ? 2 : ffn_dw_occ(p.hs != nullptr, compute == CM_BF16));
+    int splits = ffn_dw_splits((p.N + 31) / 32, (compute == CM_SPLIT && p.hs) ? 2 : ffn_dw_occ(p.hs != nullptr, compute == CM_BF16), p.d_ff,
+                               compute == CM_SPLIT && p.hs && p.xg_planes && ffn_dw_split2());
     p.splits = splits;
     p.kb_per_split = cdiv(nkb, splits);
     p.splits = cdiv(nkb, p.kb_per_split);
