@@ -659,9 +659,10 @@ def measure_roofline(torch, lib, step, wl, dtype):
     flops = {
         "fused_bwd_kernel": L * (2.0 * N * d * 3 * d + 2.0 * N * d * d + 8.0 * B * S * S * d) + ffn,
         "fused_fwd_kernel": attn_fwd + ffn,
-        "ffn_dw_kernel": ffn,
-        "ffn_fwd_kernel": ffn,
-        "ffn_bwd_kernel": ffn,
+        # one launch PER LAYER (until round 5 these carried the whole step's FFN FLOPs against the average LAUNCH: L x too high on C3 / PNR; C2 has L = 1)
+        "ffn_dw_kernel": ffn / L,
+        "ffn_fwd_kernel": ffn / L,
+        "ffn_bwd_kernel": ffn / L,
         "wide_gemm_kernel": 3.0 * (proj + L * (2.0 * N * d * 3 * d + 2.0 * N * d * d) + ffn) - 2.0 * proj + proj,
         "wide_attn_fwd_kernel": L * 4.0 * B * S * S * d,
         "wide_attn_bwd_kernel": L * 8.0 * B * S * S * d,
@@ -687,10 +688,11 @@ def measure_roofline(torch, lib, step, wl, dtype):
         flops["fused_bwd_kernel"] -= L * 8.0 * B * S * S * d
         flops["fused_fwd_kernel"] -= L * 4.0 * B * S * S * d
     # split mode: the FFN halves run as their own launches; the per-clip kernels then hold only the attention halves
+    # (cut mode launches the attention-side kernels once per layer as well)
     if "ffn_fwd_kernel" in res:
-        flops["fused_fwd_kernel"] -= ffn
+        flops["fused_fwd_kernel"] = (flops["fused_fwd_kernel"] - ffn) / L
     if "ffn_bwd_kernel" in res:
-        flops["fused_bwd_kernel"] -= ffn
+        flops["fused_bwd_kernel"] = (flops["fused_bwd_kernel"] - ffn) / L
     lib.egx_timing_enable(0)
     peak = PEAK_TFLOPS[dtype]
     cnt, cnt_src = committed_counters(wl["name"], dtype, wl.get("batch_arg", B), wl.get("frames"), wl.get("layers_arg"), wl.get("encoder_only", False))
