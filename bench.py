@@ -687,6 +687,8 @@ def measure_roofline(torch, lib, step, wl, dtype):
             res[k] = tot_ms[k] * 1e-3 / reps
         flops["fused_bwd_kernel"] -= L * 8.0 * B * S * S * d
         flops["fused_fwd_kernel"] -= L * 4.0 * B * S * S * d
+        for k in ("ffn_dw_kernel", "ffn_fwd_kernel", "ffn_bwd_kernel"):
+            flops[k] = ffn          # per-step sums here: every layer's launch
     # split mode: the FFN halves run as their own launches; the per-clip kernels then hold only the attention halves
     # (cut mode launches the attention-side kernels once per layer as well)
     if "ffn_fwd_kernel" in res:
