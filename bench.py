@@ -90,6 +90,10 @@ def parse_args(argv=None):
                          "and read by the translator as packed bf16 in place; the producer kernel is timed separately (`producer`)")
     ap.add_argument("--feat-frames", type=int, default=1, help="c4: per-frame PNR / OSCC features, this many frames per clip, temporal mean fused into the hand-off")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--no-weight-cache", action="store_true",
+                    help="per-clip kernels: pack the weights into MFMA-fragment order inside every step (rounds 1-5) instead of once, outside the timed "
+                         "loop (forward + backward only: the weights do not change between steps; the with_optimizer line always re-packs)")
+    ap.add_argument("--no-fused-ce", action="store_true", help="c1 / c2: the weighted cross entropy as a launch of its own (rounds 1-5) instead of in the forward's head epilogue")
     return ap.parse_args(argv)
 
 
@@ -226,9 +230,16 @@ def run(args) -> int:
         local_batch = args.batch
     wl = synth.make_workload(args.config, dev, batch=local_batch, frames=args.frames, layers=args.layers or None,
                              dtype=run_dtype, impl=args.impl, dropout=args.dropout, seed=1234 + rank, encoder_only=args.encoder_only,
-                             feat_dtype=args.feat_dtype, feat_frames=args.feat_frames, feat_source=args.feat_source)
+                             feat_dtype=args.feat_dtype, feat_frames=args.feat_frames, feat_source=args.feat_source,
+                             fused_ce=not args.no_fused_ce)
     model, params, B = wl["model"], wl["params"], wl["B"]
     dtype = wl["compute"]
+    # forward + backward only: the weights are the same in every step, so their MFMA-fragment-packed copies are made ONCE (a persistent
+    # cache, model.enable_weight_cache(frozen=True)) instead of by a 6 us launch in front of every forward; a step with the optimizer inside
+    # re-packs after every update (frozen = False below)
+    wcache_on = hasattr(model, "enable_weight_cache") and not args.no_weight_cache
+    if wcache_on:
+        model.enable_weight_cache(frozen=not args.optimizer)
     if args.deterministic:
         model.set_deterministic(True)
     ddp.broadcast_parameters(model)
@@ -496,7 +507,11 @@ def run(args) -> int:
                                                                  " in per-layer buckets overlapped with the backward" if bucketed else "")) if multi else ""),
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl, "workgroups_per_clip": F_egx.last_encoder_slices(),
                    "launch": "one hipGraph replay per step" if (use_graph and not (bucketed and not args.graph_collectives)) else "eager",
-                   "deterministic": bool(args.deterministic)},
+                   "deterministic": bool(args.deterministic),
+                   "weights_packed": ("once, outside the timed loop (forward + backward only: the weights do not change between steps; "
+                                      "with_optimizer re-packs every step)" if (wcache_on and not args.optimizer) else "every step"),
+                   "loss": ("weighted CE in the forward's head epilogue (egx_ce)" if (wl["name"] in ("c1", "c2") and not args.no_fused_ce)
+                            else "separate launch(es)")},
         "library_launches_per_step": launches_per_step,
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,
         "step_frac_of_mfma_peak": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12 / PEAK_TFLOPS[dtype],
@@ -524,11 +539,16 @@ def run(args) -> int:
     if not args.optimizer and not args.no_optimizer_line:
         # "+ optimizer step reported separately" (SURVEY.md 8d): the same step with the Adam update inside
         opt2 = FusedAdam(params, lr=5e-4)
+        if wcache_on:
+            model.enable_weight_cache(frozen=False)      # the update changes the weights: the packing launch is part of this step
         step2 = make_step(opt2)
         d2 = time_trials(step2, max(3, args.warmup // 2), args.steps, max(3, trials // 2))
         m2 = percentile(d2, 0.5) / args.steps * 1e3
-        out["with_optimizer"] = {"optimizer": "FusedAdam(lr=5e-4), one launch over the flat parameter buffer",
+        out["with_optimizer"] = {"optimizer": "FusedAdam(lr=5e-4), one launch over the flat parameter buffer; the weights are re-packed every step",
                                  "ms_per_step": m2, "value": B * world / (m2 * 1e-3), "unit": "clips/s"}
+        if wcache_on:
+            F_egx.note_weights_changed()                 # (the replayed updates wrote the parameters behind torch's back)
+            model.enable_weight_cache(frozen=True)
     if dtype == "f32s" and not multi and not args.no_native_line:
         # the same step on the exact fp32 MFMA path (v_mfma_f32_16x16x4_f32), for reference
         model.set_compute("f32", args.impl)

@@ -162,6 +162,10 @@ static FusedPackLayout fused_pack_layout(const egx_config* cfg, const egx_segmen
     L.bytes = cur;
     return L;
 }
+// where the packed copies live: the caller's persistent weight cache (egx_config.weight_cache, ABI v15) or behind the saved activations
+static char* fused_pack_base(const egx_config* cfg, const void* saved, const Plan& vp) {
+    return cfg->weight_cache ? (char*)cfg->weight_cache : (char*)const_cast<void*>(saved) + fused_act_bytes(vp);
+}
 // The FFN hidden activation H (forward) and its gradient dH (backward) are handed to the weight-gradient kernel as
 // operand tiles instead of being recomputed there (ffn_dw_kernel, the recompute variant, is kept as the egx_ffn_dw unit hook).
 static bool store_hidden() { return true; }     // (the recompute variant of the clip kernels was dropped in round 3: their FFN loops store unconditionally)
@@ -536,6 +540,18 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     return 0;
 }
 
+// Bytes of the persistent packed-weight cache (egx_config.weight_cache): the fragment-packed copies of the per-clip / tiled kernels. The layout
+// is a function of the model dimensions and the compute mode only (fused_pack_layout), so one buffer serves every batch size.
+size_t egx_weight_cache_bytes(const egx_config* cfg, const egx_segment* segs) {
+    if (!cfg || !segs) return 0;
+    Plan pl;
+    if (make_plan(cfg, segs, 1, pl)) return 0;
+    if (pl.d != 128 || pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1 || pl.dff % 128 != 0) return 0;
+    for (int i = 0; i < pl.nseg; ++i)
+        if (!segs[i].proj_w || segs[i].d_in % 128 != 0) return 0;
+    return align_up(fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
+}
+
 int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B) {
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 0;
@@ -579,6 +595,10 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     const int N = (int)pl.N;
     const bool with_head = head && head->W;
     EGX_CHECK(with_head ? (logits_out != nullptr) : (tokens_out != nullptr), "null output pointer");
+    const egx_ce* ce = cfg->ce;
+    EGX_CHECK(!ce || with_head, "egx_config.ce: the fused cross entropy needs the pooled head (egx_translator_fwd)");
+    EGX_CHECK(!ce || (ce->target && ce->loss && ce->d_logits), "egx_config.ce: target, loss and d_logits must be set");
+    EGX_CHECK(!cfg->weight_cache_valid || cfg->weight_cache, "weight_cache_valid without a weight_cache");
     EGX_CHECK(!with_head || (head->ln_w && head->ln_b && head->b && head->n_out >= 1 && head->n_out <= FUSED_HEAD_MAX_OUT),
               "head needs ln_w, ln_b, W, b and 1 <= n_out <= %d", FUSED_HEAD_MAX_OUT);
     // A HOST seed is baked into a captured graph: every replay would draw the SAME dropout masks — training that runs, converges worse and
@@ -602,9 +622,12 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         PackParams pk;
         memset(&pk, 0, sizeof(pk));
         pk.mode = comp;
-        pk.seed_advance = (cfg->advance_seed && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
-        FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, (char*)saved + fused_act_bytes(vp));
+        pk.seed_advance = (cfg->advance_seed == 1 && cfg->seed_ptr && training) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
+        FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, fused_pack_base(cfg, saved, vp));
+        // weight cache valid (egx_config.weight_cache_valid): the packed copies of exactly these weights are in place, nothing is packed
+        const bool cache_hit = cfg->weight_cache && cfg->weight_cache_valid;
         auto add_pack = [&](const float* src, void* dst, int R, int K, int ld, int transpose, float scale = 1.f) -> const void* {
+            if (cache_hit) return dst;
             PackDesc& dsc = pk.d[pk.n++];
             dsc.src = src; dsc.dst = dst; dsc.R = R; dsc.K = K; dsc.ld = ld; dsc.transpose = transpose; dsc.scale = scale;
             return dst;
@@ -672,18 +695,46 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fp.slice_drop = slice_drop_mask(fp.n_slices);
         }
         fp.x1f_out = tiled ? nullptr : (float*)((char*)saved + fused_x1f_offset(cfg, segs, vp));
+        const bool cut = use_cut(pl, fp.n_slices, tiled, comp);
+        // fused weighted cross entropy (egx_ce): in the epilogue of the launch that writes the logits; every clip adds its term into *loss,
+        // which the packing launch zeroes when there is one, else the first launch of a cut-mode forward, else a memset node
+        const bool ce_fused = ce && with_head && !tiled && !cfg->deterministic;
+        if (ce_fused) {
+            fp.ce_target = ce->target; fp.ce_weight = ce->class_weight; fp.ce_loss = ce->loss; fp.ce_dlogits = ce->d_logits; fp.ce_B = B;
+            if (pk.n || pk.seed_advance || pk.zero_words) pk.zero_word2 = ce->loss;
+            else if (cut) fp.zero_word = ce->loss;
+            else EGX_HIP(hipMemsetAsync(ce->loss, 0, sizeof(float), st));
+        }
         if (pack_weights(pk, st)) return 1;
-        if (use_cut(pl, fp.n_slices, tiled, comp)) {
+        // With a persistent weight cache nothing has just written the packed copies: every launch brings the streams its successor reads
+        // first into the Infinity Cache (TouchList, fused.h)
+        const bool touch = cfg->weight_cache != nullptr && !tiled;
+        const size_t ffn_pb = packed_bytes(pl.dff, d, comp), in_pb = packed_bytes(3 * d, d, comp), out_pb = packed_bytes(d, d, comp);
+        if (cut) {
             // cut mode: per layer [token preparation | layer input .. LayerNorm1] (4 waves per clip) + [FFN .. LayerNorm2 (+ pooled head)] (8 waves)
             fp.mode = FUSED_MODE_ATTN;
             for (int l = 0; l < pl.L; ++l) {
                 fp.l0 = l;
+                memset(&fp.touch, 0, sizeof(fp.touch));
+                if (touch) { touch_add(fp.touch, PL.layer[l].lin1_w, ffn_pb); touch_add(fp.touch, PL.layer[l].lin2_w, ffn_pb); }
                 if (fused_forward(fp, comp, st)) return 1;
+                fp.zero_word = nullptr;
+                memset(&fp.touch, 0, sizeof(fp.touch));
+                if (touch && l + 1 < pl.L) { touch_add(fp.touch, PL.layer[l + 1].in_w, in_pb); touch_add(fp.touch, PL.layer[l + 1].out_w, out_pb); }
+                else if (touch && training) { touch_add(fp.touch, PL.layer[l].lin2_wt, ffn_pb); touch_add(fp.touch, PL.layer[l].lin1_wt, ffn_pb); }
                 if (ffn_cut_forward(fp, l, comp, st)) return 1;
             }
             return 0;
         }
-        if (!tiled) return fused_forward(fp, comp, st);
+        if (!tiled) {
+            if (touch) {        // one launch: its own FFN streams (read ~25 us in) and, in training, the backward's first
+                touch_add(fp.touch, PL.layer[0].lin1_w, ffn_pb); touch_add(fp.touch, PL.layer[0].lin2_w, ffn_pb);
+                if (training) { touch_add(fp.touch, PL.layer[pl.L - 1].lin2_wt, ffn_pb); touch_add(fp.touch, PL.layer[pl.L - 1].lin1_wt, ffn_pb); }
+            }
+            if (fused_forward(fp, comp, st)) return 1;
+            if (ce && with_head && !ce_fused) return weighted_ce(logits_out, ce->target, ce->class_weight, B, head->n_out, ce->loss, ce->d_logits, st);
+            return 0;
+        }
         // tiled mode: token preparation + Q | K | V of layer 0, then per layer [attention of every clip] [out-projection .. LayerNorm2
         // + Q | K | V of the next layer] (2 L + 1 launches), then the pooled head on the output tokens
         float* attn = (float*)((char*)saved + tiled_attn_offset(cfg, segs, vp));
@@ -706,8 +757,10 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fp.mode = FUSED_MODE_POST; fp.l0 = l;
             if (fused_forward(fp, comp, st)) return 1;
         }
-        if (with_head)
-            return pool_head_fwd(fp.tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, extra + (size_t)N * d, logits_out, st);
+        if (with_head) {
+            if (pool_head_fwd(fp.tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, extra + (size_t)N * d, logits_out, st)) return 1;
+            if (ce) return weighted_ce(logits_out, ce->target, ce->class_weight, B, head->n_out, ce->loss, ce->d_logits, st);
+        }
         return 0;
     }
     if (ferr || terr) return 1;
@@ -725,8 +778,10 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 if (!tk) tk = extra;
             }
             if (wide_encoder_fwd(cfg, segs, ln_w, ln_b, layers, B, tk, saved, training, seed, st)) return 1;
-            if (with_head)
-                return pool_head_fwd(tk, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, pooled, logits_out, st);
+            if (with_head) {
+                if (pool_head_fwd(tk, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out, pooled, logits_out, st)) return 1;
+                if (ce) return weighted_ce(logits_out, ce->target, ce->class_weight, B, head->n_out, ce->loss, ce->d_logits, st);
+            }
             return 0;
         }
         if (werr) return 1;
@@ -789,9 +844,11 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         l2.stats = fptr(saved, o.stats2); l2.y = x_out; l2.rows = N; l2.d = d;
         if (layernorm_fwd(l2, st)) return 1;
     }
-    if (with_head)
-        return pool_head_fwd(tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out,
-                             head_pooled, logits_out, st);
+    if (with_head) {
+        if (pool_head_fwd(tokens_out, B, S, d, head->ln_w, head->ln_b, cfg->ln_eps, head->W, head->b, head->n_out,
+                          head_pooled, logits_out, st)) return 1;
+        if (ce) return weighted_ce(logits_out, ce->target, ce->class_weight, B, head->n_out, ce->loss, ce->d_logits, st);
+    }
     return 0;
 }
 
@@ -815,10 +872,12 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             const int N = (int)pl.N;
             Plan vp = pl;
             if (tiled) plan_tiled(vp);
-            FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, (char*)saved + fused_act_bytes(vp));
+            FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, fused_pack_base(cfg, saved, vp));
             FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, with_head ? head->n_out : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
+            const bool touch = cfg->weight_cache != nullptr && !tiled;      // (see the forward)
+            const size_t ffn_pb = packed_bytes(pl.dff, d, comp), in_pb = packed_bytes(3 * d, d, comp), out_pb = packed_bytes(d, d, comp);
             for (int i = 0; i < pl.nseg; ++i) {
                 FusedSeg& fs = bp.seg[i];
                 fs.add_vec = segs[i].add_vec; fs.pos = segs[i].pos; fs.T = segs[i].T; fs.d_in = segs[i].d_in;
@@ -858,6 +917,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             if (with_head) {        // (tiled mode since round 5 too: the first tile launch runs the head backward from the saved token means)
                 bp.head.ln_w = head->ln_w; bp.head.ln_b = head->ln_b; bp.head.W = head->W; bp.head.b = head->b; bp.head.n_out = head->n_out;
                 bp.d_logits = d_logits;
+                bp.d_logits_scale = cfg->d_logits_scale;
                 bp.head_off = fused_partial_len(pl.L, pl.nseg);
                 if (tiled) bp.pooled = (const float*)((const char*)saved + tiled_tokens_offset(cfg, segs, vp)) + (size_t)N * d;
             }
@@ -890,12 +950,19 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 bp.cut = 1; bp.dy1 = fptr(scratch, SC.dy1); bp.dxin = fptr(scratch, SC.dxin);
                 for (int l = pl.L - 1; l >= 0; --l) {
                     bp.cut_layer = l;
+                    memset(&bp.touch, 0, sizeof(bp.touch));
+                    if (touch) { touch_add(bp.touch, PL.layer[l].out_wt, out_pb); touch_add(bp.touch, PL.layer[l].in_wt, in_pb); }
                     if (ffn_cut_backward(bp, l, comp, st)) return 1;
                     bp.zero_buf = nullptr;
+                    memset(&bp.touch, 0, sizeof(bp.touch));
+                    if (touch && l > 0) { touch_add(bp.touch, PL.layer[l - 1].lin2_wt, ffn_pb); touch_add(bp.touch, PL.layer[l - 1].lin1_wt, ffn_pb); }
                     if (fused_backward(bp, comp, st)) return 1;
                 }
             } else
-            if (stage != 2 && !tiled && fused_backward(bp, comp, st)) return 1;
+            if (stage != 2 && !tiled) {
+                if (touch) { touch_add(bp.touch, PL.layer[pl.L - 1].out_wt, out_pb); touch_add(bp.touch, PL.layer[pl.L - 1].in_wt, in_pb); }
+                if (fused_backward(bp, comp, st)) return 1;
+            }
             if (stage != 2 && tiled) {
                 // L + 1 launches of the tile kernel with the attention backward of every clip between them
                 bp.datt = fptr(scratch, SC.datt); bp.dres = fptr(scratch, SC.dres);
@@ -985,8 +1052,15 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             for (int i = 0; i < pl.nseg && seg_grads; ++i) any_small = any_small || seg_grads[i].proj_w;
             SmallDwTail tail;
             const bool ride = stage == 0 && !cfg->deterministic && any_small && (red.narr || rp_pending) && reduce_rides();
+            // egx_config.advance_seed == 2: the backward advances the device seed behind its last reader (the last launch that can run here)
+            uint64_t* adv = (cfg->advance_seed == 2 && cfg->seed_ptr && training && stage != 1) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
             if (ride) {
                 small_dw_tail_init(tail, red, rp_pending ? &rp : nullptr);
+                tail.seed_advance = adv; adv = nullptr;
+                if (touch) {    // the next forward starts with the projections and layer 0's in-projection (one contiguous run of the cache) and out-projection
+                    touch_add(tail.touch, PL.proj[0], (size_t)((const char*)PL.layer[0].in_wt - (const char*)PL.proj[0]));
+                    touch_add(tail.touch, PL.layer[0].out_w, out_pb);
+                }
                 rp_pending = false;
             } else if (red.narr) {
                 if (ffn_dw_reduce(red, rp_pending ? &rp : nullptr, cfg->deterministic != 0, st)) return 1;
@@ -1020,6 +1094,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                     if (seg_grads && add(bp.dseg_out[i], d, segs[i].feat, segs[i].d_in, seg_grads[i].proj_w, d, segs[i].d_in, B * segs[i].T)) return 1;
                 if (flush()) return 1;
             }
+            if (adv && seed_advance(adv, st)) return 1;
             return 0;
         }
         if (ferr || terr) return 1;

@@ -211,6 +211,9 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
     const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
 
     ASTAMP(16);
+    // weight streams of the next launch -> Infinity Cache (TouchList): the oldest loads of this launch, consumed behind the prologue's barrier
+    Touched tch = {{0, 0, 0, 0}};
+    if (p.touch.n) tch = touch_lines<CT>(p.touch, blockIdx.x, gridDim.x, tid);
     const int nhb = p.d_ff / 32;
     int j_begin_, n_mine_;
     cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_);
@@ -304,6 +307,7 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
             }
         }
         __syncthreads();
+        touch_sink(tch);
         if (CM != CM_F32 && !have_planes) {     // no planes handed over (EGX_FFN_DW_PLANES=0): build them from the fp32 rows
             if constexpr (CM == CM_SPLIT) block_to_split_planes(XP, X1);
             else if constexpr (CM == CM_BF16) block_to_plane(XP, X1);
@@ -468,7 +472,12 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
     // ---- optional pooled head: logits = Linear(LN(mean_s tokens)) (as fused_fwd_kernel)
     if (p.head.n_out > 0) {
         float* pooled = X1;
+        // fused weighted cross entropy (egx_ce): the labels and their class weights are requested here, under the pooling
+        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B};
+        CeReq rq;
+        if (ce.target) { ce_request_labels<CT>(ce, tid, rq); ce_request_weights(ce, p.head.n_out, rq); }
         if (tid < FD) pooled[tid] = colsum_lds(Y, 0, S, tid) * (1.f / (float)S);
+        if (ce.target) ce_weight_partials<CT>(ce, p.head.n_out, tid, rq, pooled + 256);
         __syncthreads();
         if (wave == 0) {
             float2 x = *reinterpret_cast<float2*>(pooled + 2 * lane);
@@ -479,11 +488,14 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
             float2 lb = *reinterpret_cast<const float2*>(CP + 4 * FD + 2 * lane);
             float y0 = dx * rstd * lw.x + lb.x, y1 = dy * rstd * lw.y + lb.y;
             const bool w_lds = p.head.n_out <= CP_HEAD_ROWS;
+            float zmine = 0.f;
             for (int o = 0; o < p.head.n_out; ++o) {
                 float2 wv = w_lds ? *reinterpret_cast<const float2*>(CP + 1024 + o * FD + 2 * lane) : *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
-                float sdot = wsum(y0 * wv.x + y1 * wv.y);
-                if (lane == 0) p.logits_out[(size_t)clip * p.head.n_out + o] = sdot + CP[5 * FD + o];
+                float sdot = wsum(y0 * wv.x + y1 * wv.y) + CP[5 * FD + o];
+                if (lane == 0) p.logits_out[(size_t)clip * p.head.n_out + o] = sdot;
+                zmine = lane == o ? sdot : zmine;
             }
+            if (ce.target) ce_clip<CT>(ce, p.head.n_out, clip, lane, zmine, pooled + 256, true);
         }
     }
     ASTAMP(23);
@@ -510,6 +522,8 @@ __global__ __launch_bounds__(CT) void ffn_bwd_kernel(FusedBwdParams p, int l) {
     const bool last = l + 1 == p.n_layers;
 
     ASTAMP(24);
+    Touched tch = {{0, 0, 0, 0}};        // (see ffn_fwd_kernel)
+    if (p.touch.n) tch = touch_lines<CT>(p.touch, blockIdx.x, gridDim.x, tid);
     if (p.zero_buf) {       // the caller's flat gradient buffer (first launch of the backward only): accumulated into by later launches
         const size_t n4 = p.zero_n / 4, per = (n4 + gridDim.x - 1) / gridDim.x;
         const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n4 ? b0 + per : n4;
@@ -536,6 +550,7 @@ __global__ __launch_bounds__(CT) void ffn_bwd_kernel(FusedBwdParams p, int l) {
         cp_v = *reinterpret_cast<const f32x4*>(src + cp_c4);
         const int nb = cp_hd ? p.head.n_out : 0, nw = cp_hd && p.head.n_out <= CP_HEAD_ROWS ? p.head.n_out * 32 : 0;
         cp_b = nb ? p.d_logits[(size_t)clip * p.head.n_out + min(max(tid - 160, 0), nb - 1)] : 0.f;
+        if (nb && p.d_logits_scale) cp_b *= *p.d_logits_scale;
         cp_w = *reinterpret_cast<const f32x4*>(nw ? p.head.W + (size_t)min(max(tid - 256, 0), nw - 1) * 4 : w.norm2_w);
     }
     auto cp_store = [&] {
@@ -587,6 +602,7 @@ __global__ __launch_bounds__(CT) void ffn_bwd_kernel(FusedBwdParams p, int l) {
             }
             if (i < nd) *reinterpret_cast<f32x4*>(Gs + row * LDX + c) = dr[k];      // rows >= out_T carry no upstream gradient (LDS is zero there)
         }
+        touch_sink(tch);
     }
     ASTAMP(25);
     if (head_bwd) {

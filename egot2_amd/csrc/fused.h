@@ -7,6 +7,18 @@ namespace egx {
 constexpr int FUSED_MAX_SEG = 4;
 constexpr int FUSED_MAX_LAYERS = 6;      // the shipped PNR / OSCC recipe stacks 6 (HOI/configs/pnr/ts_pnr.yaml:28-34)
 
+// Weight-stream prefetch for a LATER launch (round 6). The packed weights of a launch are read by every workgroup; when they are not in
+// the Infinity Cache (a step moves ~0.9 GB through its 256 MiB, so a weight read a step ago is gone) the first readers fetch from HBM under
+// load and the weight rings run dry: without the packing launch in front of the forward — whose stores left the copies cache-resident —
+// ffn_fwd_kernel ran 6 us and ffn_bwd_kernel 5 us longer (profiles/r06_weight_cache.txt). So every launch touches ONE dword of every
+// 128-byte line of the streams its successor reads first, spread over its workgroups (a few hundred lines each: one load per thread),
+// as the oldest loads of its own prologue.
+constexpr int TOUCH_MAX = 4;
+struct TouchList { const void* base[TOUCH_MAX]; unsigned lines[TOUCH_MAX]; int n; };
+static inline void touch_add(TouchList& t, const void* base, size_t bytes) {
+    if (base && bytes >= 128 && t.n < TOUCH_MAX) { t.base[t.n] = base; t.lines[t.n] = (unsigned)(bytes >> 7); ++t.n; }
+}
+
 struct FusedSeg {
     const float* feat;      // (B, T, d_in)
     const void* proj_wp;    // [128, d_in] packed in fragment order (pack_weights)
@@ -86,6 +98,10 @@ struct FusedFwdParams {
     // saved layer input (xin_out, layer l0 > 0)] .. LayerNorm1 of layer l0 and leaves x1 (fp32 rows in x1f_out + the bf16 operand planes
     // in x1p_out); ffn_fwd_kernel (512 threads: two waves per SIMD) runs the FFN, the second residual, LayerNorm2 and the pooled head.
     float* x1f_out;         // (L, Ntok, 128) fp32: the FFN input x1 = LayerNorm1 output of every layer
+    // ---- fused weighted cross entropy on the pooled head's logits (egx_ce, round 6; fused_dev.h FusedCe): evaluated by the launch that writes the logits
+    const int64_t* ce_target; const float* ce_weight; float* ce_loss; float* ce_dlogits; int ce_B;
+    float* zero_word;       // optional: one float the FIRST launch of a cut-mode forward zeroes (ce_loss: the FFN launch then adds into it)
+    TouchList touch;        // weight streams of a later launch to bring into the Infinity Cache (see TouchList)
 };
 enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2, FUSED_MODE_ATTN = 3 };
 
@@ -101,6 +117,7 @@ struct PackParams {
     int n, mode;                // CM_F32 / CM_BF16 / CM_SPLIT (fused_dev.h): element format of the packed fragments
     uint64_t* seed_advance;     // optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed)
     unsigned* zero_words; int n_zero;   // optional: words to zero (the arrival counters of the sliced mode)
+    float* zero_word2;                  // optional: one more word to zero (the fused cross entropy's loss accumulator)
 };
 int pack_weights(PackParams& pp, hipStream_t st);
 static inline size_t packed_bytes(int R, int K, int mode) { return (size_t)R * K * (mode == 1 ? 2 : mode == 2 ? 6 : 4); }
@@ -204,6 +221,8 @@ struct FusedBwdParams {
     int cut, cut_layer;
     float* dy1;             // (Ntok, 128) gradient reaching LayerNorm1's output (FFN path + residual path)
     float* dxin;            // (Ntok, 128) gradient w.r.t. the input of layer cut_layer (= LayerNorm2 output of the layer below)
+    const float* d_logits_scale;    // optional device scalar multiplied into d_logits (egx_config.d_logits_scale)
+    TouchList touch;        // weight streams of a later launch to bring into the Infinity Cache (see TouchList)
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);
 // cut mode (ffn_cut.hip): the FFN of layer l as launches of their own, eight waves per clip
@@ -238,7 +257,7 @@ struct ReducePartialsParams {
     const float* partials;
 };
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool deterministic = false);
-struct SmallDwTail { SlabReduce red; ReducePartialsParams rp; unsigned slab_blocks; int rp_units, chunks; };
+struct SmallDwTail { SlabReduce red; ReducePartialsParams rp; unsigned slab_blocks; int rp_units, chunks; uint64_t* seed_advance; /* optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed == 2) */ TouchList touch; /* the next forward's first weight streams */ };
 void small_dw_tail_init(SmallDwTail& t, const SlabReduce& red, const ReducePartialsParams* rp);
 
 // Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.

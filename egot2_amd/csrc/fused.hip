@@ -30,6 +30,8 @@ __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
         *pp.seed_advance = *pp.seed_advance * 6364136223846793005ull + 1442695040888963407ull;
     if (pp.zero_words)
         for (int i = blk * 64 + threadIdx.x; i < pp.n_zero; i += gridDim.x * 64) pp.zero_words[i] = 0u;
+    if (pp.zero_word2 && blk == 0 && threadIdx.x == 0) *pp.zero_word2 = 0.f;
+    if (pp.n == 0) return;      // nothing to pack (weight cache valid): the launch only carries the side jobs above
     int di = 0;
     while (di + 1 < pp.n && blk >= pp.d[di + 1].first_block) ++di;
     const PackDesc& d = pp.d[di];
@@ -71,7 +73,8 @@ int pack_weights(PackParams& pp, hipStream_t st) {
         pp.d[i].first_block = blocks;
         blocks += (pp.d[i].R / 16) * (pp.d[i].K / 32);
     }
-    if (!blocks) return 0;
+    if (!blocks && !pp.seed_advance && !pp.zero_words && !pp.zero_word2) return 0;
+    if (!blocks) blocks = 1;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(64), 0, st, pp);
     EGX_LAUNCH_CHECK();
     return 0;
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     } while (0)
 
     STAMP(0);
+    if constexpr (CUT) { if (p.zero_word && blockIdx.x == 0 && tid == 0) *p.zero_word = 0.f; }
+    // weight streams of a later launch (or of this launch's later phases) -> Infinity Cache (TouchList): the oldest loads of this launch
+    Touched tch = {{0, 0, 0, 0}};
+    if constexpr (!TILED) { if (p.touch.n) tch = touch_lines<256>(p.touch, blockIdx.x, gridDim.x, tid); }
     const bool dev_seed = p.seed_ptr != nullptr;
     const uint64_t seed_dev = dev_seed ? *p.seed_ptr : 0ull;
     const uint64_t pos_key = dev_seed ? site_key(seed_dev, 0, SITE_POS) : p.pos_key;
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         LSTAMP_FLUSH();
     }
     __syncthreads();
+    touch_sink(tch);
     STAMP(1);
     // save pre-LN projections (token order) and apply the shared LN + embeddings. The task-embedding and positional rows of the
     // lane's token are requested unconditionally behind the LayerNorm weights (a missing table reads the LayerNorm weights and
@@ -961,7 +969,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     // ---- optional pooled head: logits = Linear(LN(mean_s tokens)); tokens of the last layer are in Xs
     if (!TILED && p.head.n_out > 0) {
         float* pooled = X1;                      // 128 floats of scratch (X1 is dead)
+        // fused weighted cross entropy (egx_ce): the labels and their class weights are requested here, under the pooling
+        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B};
+        CeReq rq;
+        if (ce.target) { ce_request_labels<256>(ce, tid, rq); ce_request_weights(ce, p.head.n_out, rq); }
         if (tid < FD) pooled[tid] = colsum_lds(Xs, 0, S, tid) * (1.f / (float)S);
+        if (ce.target) ce_weight_partials<256>(ce, p.head.n_out, tid, rq, pooled + 256);
         __syncthreads();
         if (wave == 0) {
             float2 x = *reinterpret_cast<float2*>(pooled + 2 * lane);
@@ -971,11 +984,14 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             float2 lw = *reinterpret_cast<const float2*>(p.head.ln_w + 2 * lane);
             float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
             float y0 = dx * rstd * lw.x + lb.x, y1 = dy * rstd * lw.y + lb.y;
+            float zmine = 0.f;
             for (int o = 0; o < p.head.n_out; ++o) {
                 float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
-                float sdot = wsum(y0 * wv.x + y1 * wv.y);
-                if (lane == 0) p.logits_out[(size_t)clip * p.head.n_out + o] = sdot + p.head.b[o];
+                float sdot = wsum(y0 * wv.x + y1 * wv.y) + p.head.b[o];
+                if (lane == 0) p.logits_out[(size_t)clip * p.head.n_out + o] = sdot;
+                zmine = lane == o ? sdot : zmine;
             }
+            if (ce.target) ce_clip<256>(ce, p.head.n_out, clip, lane, zmine, pooled + 256, slice == 0);
         }
     }
 }

@@ -907,6 +907,11 @@ __global__ __launch_bounds__(256) void small_dw_kernel(SmallDwParams p, SmallDwT
     __shared__ __attribute__((aligned(16))) float lds[2 * (32 * LDG + 32 * LDXS)];
     SSTAMP(0);
     if constexpr (TAIL) {
+        // egx_config.advance_seed == 2: this is the backward's last launch and reads no dropout key: the step's seed advances here
+        if (tl.seed_advance && blockIdx.x == 0 && threadIdx.x == 0)
+            *tl.seed_advance = *tl.seed_advance * 6364136223846793005ull + 1442695040888963407ull;
+        // the next forward's first weight streams -> Infinity Cache (TouchList); consumed right away: this launch starts with reductions anyway
+        if (tl.touch.n) touch_sink(touch_lines<256>(tl.touch, blockIdx.x, gridDim.x, threadIdx.x));
         // The FFN weight-gradient slabs and the per-clip partial rows are summed here, 1 / grid of the units per workgroup, before
         // the workgroup's own GEMM work: the reduction launch of its own cost 14 us of mostly exposed latency. (As EXTRA
         // workgroups of this launch the same units were limited to three per CU by its LDS footprint: +60 us.)
@@ -1252,6 +1257,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     };
     const int l_first = CUT ? p.cut_layer : TILED ? p.l_back : p.n_layers - 1;      // the layer whose P1 - P7 this launch runs first (TILED: < 0 = none)
     // (CUT: dy1 in place of res2 — it goes to Gs, the sum LayerNorm1's backward starts from)
+    // weight streams of a later launch -> Infinity Cache (TouchList): the oldest loads of this launch, consumed with the blocks below
+    Touched tch = {{0, 0, 0, 0}};
+    if constexpr (!TILED) { if (p.touch.n) tch = touch_lines<256>(p.touch, blockIdx.x, gridDim.x, tid); }
     blk_request(pf_a, CUT ? p.dy1 + tok0 * FD : l_first >= 0 ? res_ptr(2 * l_first + 1) : p.saved_pre + tok0 * FD);
     blk_request(pf_b, l_first >= 0 ? res_ptr(2 * l_first) : p.saved_pre + tok0 * FD);
     static_assert((6 * BLK) % 4 == 0, "the blocks are zeroed in 16-byte pieces");
@@ -1332,8 +1340,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
                 float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
                 float y0 = xh0 * lw.x + lb.x, y1 = xh1 * lw.y + lb.y;
                 float d0 = 0.f, d1 = 0.f;
+                const float dl_scale = p.d_logits_scale ? *p.d_logits_scale : 1.f;
                 for (int o = 0; o < p.head.n_out; ++o) {
-                    float go = p.d_logits[(size_t)c_real * p.head.n_out + o];
+                    float go = p.d_logits[(size_t)c_real * p.head.n_out + o] * dl_scale;
                     float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
                     d0 += go * wv.x; d1 += go * wv.y;
                     *reinterpret_cast<float2*>(hp + 256 + FUSED_HEAD_MAX_OUT + o * FD + 2 * lane) = make_float2(first * go * y0, first * go * y1);
@@ -1369,6 +1378,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     if constexpr (CUT) {        // dy1 -> Gs (B1 .. B4 stay zero: P5 adds them), res1 -> B5
         blk_store(pf_a, Gs, nullptr);
         blk_store(pf_b, B5, nullptr);
+        touch_sink(tch);
         // x1 = LayerNorm1(res1) is an operand of the FFN weight gradient; without operand planes from the forward (exact-fp32 mode) it is
         // rebuilt here, as P3 of the one-launch kernel does
         if (!(CM != CM_F32 && p.xg_planes)) {
@@ -1383,6 +1393,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     if constexpr (!TILED && !CUT) {
     blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);
     blk_store(pf_b, B5, nullptr);
+    touch_sink(tch);
     if (p.head.n_out > 0) {
         // Fused pooled head backward: rebuild the last layer's output tokens y = LN2(res2), pool them, run the head
         // forward/backward for this clip (wave 0) and broadcast d(tokens) = d(pooled) / S into Gs.
@@ -1406,8 +1417,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             float2 lb = *reinterpret_cast<const float2*>(p.head.ln_b + 2 * lane);
             float y0 = xh0 * lw.x + lb.x, y1 = xh1 * lw.y + lb.y;
             float d0 = 0.f, d1 = 0.f;
+            const float dl_scale = p.d_logits_scale ? *p.d_logits_scale : 1.f;
             for (int o = 0; o < p.head.n_out; ++o) {
-                float go = p.d_logits[(size_t)clip * p.head.n_out + o];
+                float go = p.d_logits[(size_t)clip * p.head.n_out + o] * dl_scale;
                 float2 wv = *reinterpret_cast<const float2*>(p.head.W + (size_t)o * FD + 2 * lane);
                 d0 += go * wv.x; d1 += go * wv.y;
                 *reinterpret_cast<float2*>(hp + 256 + FUSED_HEAD_MAX_OUT + o * FD + 2 * lane) = make_float2(go * y0, go * y1);

@@ -328,6 +328,99 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// TouchList (fused.h): this workgroup's share of the lines, ONE load per thread and stream, every load unconditional (unused streams repeat
+// stream 0; threads beyond the share re-read its last line; a share larger than the workgroup is cut short: this is a hint). The caller keeps
+// the values alive up to a point where every younger load of its prologue has been waited for anyway (touch_sink): no extra wait.
+struct Touched { uint32_t v[TOUCH_MAX]; };
+template <int NTHREADS>
+__device__ __forceinline__ Touched touch_lines(const TouchList& tl, int block, int nblocks, int tid) {
+    Touched t;
+#pragma unroll
+    for (int k = 0; k < TOUCH_MAX; ++k) {
+        const int kk = k < tl.n ? k : 0;
+        const unsigned nl = tl.lines[kk], per = (nl + (unsigned)nblocks - 1) / (unsigned)nblocks;
+        unsigned i = (unsigned)block * per + (unsigned)tid;
+        i = (i < nl && (unsigned)tid < per) ? i : nl - 1;
+        t.v[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(tl.base[kk]) + ((size_t)i << 7));
+    }
+    return t;
+}
+__device__ __forceinline__ void touch_sink(const Touched& t) {
+#pragma unroll
+    for (int k = 0; k < TOUCH_MAX; ++k) asm volatile("" :: "v"(t.v[k]));
+}
+
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- weighted cross entropy fused into the pooled head (egx_ce, round 6) --------------------------------------------------------
+// loss = sum_i w[y_i] nll_i / sum_i w[y_i] (nn.CrossEntropyLoss(weight), HHI/tasks/ttm/video_task_2loader.py:21-22,34; the arithmetic of
+// weighted_ce_kernel, train.hip). The normaliser depends on the labels only, so every clip's workgroup sums it itself (same order in every
+// workgroup: identical bits) and its loss term and d loss / d logits are final in the launch that produced the logits.
+struct FusedCe {
+    const int64_t* target;      // (B) or null = no fused loss
+    const float* class_weight;  // (n_out) or null
+    float* loss;                // scalar: zero when the launch starts, every clip adds its term
+    float* d_logits;            // (B, n_out)
+    int B;                      // clips of the BATCH (the normaliser's range)
+};
+// all NTHREADS threads: per-wave partial sums of the normaliser -> red[wave]; the caller puts a barrier behind it. `y` / `wy` are requested by
+// ce_request() ahead of a phase that hides the two dependent round trips (label, then its class weight).
+struct CeReq { int64_t y[2]; float w[2]; };
+template <int NTHREADS>
+__device__ __forceinline__ void ce_request_labels(const FusedCe& ce, int tid, CeReq& rq) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int i = tid + k * NTHREADS; rq.y[k] = ce.target[i < ce.B ? i : ce.B - 1]; }
+}
+__device__ __forceinline__ void ce_request_weights(const FusedCe& ce, int n_out, CeReq& rq) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t y = rq.y[k];
+        const int yc = (y >= 0 && y < n_out) ? (int)y : 0;
+        rq.w[k] = ce.class_weight ? ce.class_weight[yc] : 1.f;
+    }
+}
+template <int NTHREADS>
+__device__ __forceinline__ void ce_weight_partials(const FusedCe& ce, int n_out, int tid, const CeReq& rq, float* red) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * NTHREADS;
+        s += (i < ce.B && rq.y[k] >= 0 && rq.y[k] < n_out) ? rq.w[k] : 0.f;
+    }
+    for (int i = tid + 2 * NTHREADS; i < ce.B; i += NTHREADS) {     // batches beyond 2 x NTHREADS clips: plain dependent loads
+        const int64_t y = ce.target[i];
+        if (y >= 0 && y < n_out) s += ce.class_weight ? ce.class_weight[y] : 1.f;
+    }
+    s = wsum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+}
+// wave 0 of the clip's workgroup: lane o < n_out holds logit o in `z`. Writes d_logits of the clip and adds the clip's loss term.
+template <int NTHREADS>
+__device__ __forceinline__ void ce_clip(const FusedCe& ce, int n_out, int clip, int lane, float z, const float* red, bool add_loss) {
+    float wtot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NTHREADS / 64; ++w) wtot += red[w];
+    const int64_t y = ce.target[clip];
+    const bool valid = y >= 0 && y < n_out;
+    const float wy = valid ? (ce.class_weight ? ce.class_weight[y] : 1.f) : 0.f;
+    const float zl = lane < n_out ? z : -INFINITY;
+    const float m = wmax(zl);
+    const float e = lane < n_out ? __expf(zl - m) : 0.f;
+    const float s = wsum(e);
+    const float zy = __shfl(zl, valid ? (int)y : 0, 64);
+    const float k = wy / wtot;
+    if (lane < n_out) ce.d_logits[(size_t)clip * n_out + lane] = valid ? k * (e / s - (lane == (int)y ? 1.f : 0.f)) : 0.f;
+    if (lane == 0 && add_loss) {
+        float term = valid ? k * (m + __logf(s) - zy) : 0.f;
+        if (wtot == 0.f && clip == 0) term = __builtin_nanf("");    // no valid label in the batch: 0 / 0 like the reference
+        atomicAdd(ce.loss, term);
+    }
+}
+
 
 // Row-parallel LayerNorm over a token-major LDS block: 4 adjacent lanes own one row (32 features each), so up
 // to 64 rows are normalised in one pass with quad (DPP) reductions. `fn(row, c0, x[32] pre-LN, y[32] post-LN)`

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
+from ._lib import (Ce, Config, Head, HeadGrads, Layer, LayerGrads, Segment, SegmentGrads, check, ptr, _LAYER_FIELDS,
                    EGX_F32, EGX_BF16, EGX_F32_SPLIT, EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED)
 
 # "f32s": fp32 operands split exactly into three bf16 parts, six bf16 MFMAs per K-block (fp32-grade results, fused d = 128
@@ -29,6 +29,34 @@ class SegmentSpec:
     add_row: Optional[int] = None      # row of the (1, K, d) task-embedding table, or None
     pos_row0: Optional[int] = None     # first row of the positional table used by this segment, or None
     pool: int = 1                      # > 1: the feature tensor holds T * pool frames, token t = mean of frames [t pool, (t+1) pool)
+
+
+_weights_epoch = [0]
+
+
+def note_weights_changed():
+    """Tell the packed-weight caches (WeightCache) that parameters were written behind torch's back (raw-pointer kernels: FusedAdam, a
+    replayed hipGraph that contains an optimizer update). In-place torch ops on the parameters are seen through their version counters."""
+    _weights_epoch[0] += 1
+
+
+class WeightCache:
+    """Persistent device buffer for the MFMA-fragment-packed weight copies of the per-clip / tiled kernels (egx_config.weight_cache).
+    A forward whose weights did not change since the forward that filled it skips the packing launch (6 us of the 0.38 ms TTM step).
+    "Did not change" is decided on the host: storage address + version counter of every packed weight, the compute mode, the FFN keep-scale
+    and note_weights_changed()'s epoch. Writes that bypass all of those (`p.data.add_()` bumps no counter) need invalidate().
+    frozen=True is the caller's promise that the weights do not change while it is set (inference, a forward + backward benchmark): only
+    then is the packing launch also left out of a CAPTURED step — a replay cannot re-check anything."""
+
+    def __init__(self, frozen: bool = False):
+        self.buf: Optional[torch.Tensor] = None
+        self.sig = None
+        self.frozen = bool(frozen)
+        self.hits = 0
+        self.packs = 0
+
+    def invalidate(self):
+        self.sig = None
 
 
 @dataclass
@@ -48,15 +76,19 @@ class EncoderSpec:
     seed: int = 0
     seed_ptr: int = 0      # device address of a uint64 seed (hipGraph-replayable dropout), 0 = use `seed`
     head_n_out: int = 0    # > 0: pooled head (mean -> LN -> Linear) evaluated with the encoder; output = logits
-    advance_seed: bool = False   # with seed_ptr: the training forward advances the device seed in its first kernel
+    advance_seed: int = 0        # with seed_ptr: 1 = the training forward advances the device seed in its first kernel; 2 = the backward
+                                 # advances it behind its last reader (egx_config.advance_seed)
     defer_small: bool = False    # backward: leave the grouped small weight gradients to run_deferred() (all-reduce overlap)
     deterministic: bool = False  # backward: fixed-order reductions instead of fp32 atomics (bit-identical gradients run to run)
     out_tokens: int = 0          # > 0: return (and take the gradient of) only the first `out_tokens` tokens of every clip
+    wcache: Optional[WeightCache] = None     # persistent packed-weight cache (None: packed into `saved` every forward)
+    ce: bool = False             # with head_n_out: the forward also evaluates the weighted cross entropy of the logits (egx_ce); EncoderFn then
+                                 # takes (target, class_weight | None) behind the head parameters and returns (logits, loss)
 
     def config(self) -> Config:
         return Config(self.d_model, self.n_heads, self.d_ff, self.n_layers, len(self.segments), float(self.ln_eps),
                       COMPUTE[self.compute], IMPL[self.impl], float(self.p_drop), float(self.p_pos), float(self.p_feat),
-                      self.seed_ptr or None, int(bool(self.advance_seed and self.seed_ptr)), None, 0, 0,
+                      self.seed_ptr or None, int(self.advance_seed) if self.seed_ptr else 0, None, 0, 0,
                       int(bool(self.deterministic)), int(self.out_tokens))
 
 
@@ -215,6 +247,12 @@ class EncoderFn(torch.autograd.Function):
         nproj = sum(1 for s in spec.segments if s.has_proj)
         proj = [_dev_f32(t, "projection weight") for t in rest[nseg:nseg + 2 * nproj]]
         nhead = 4 if spec.head_n_out else 0
+        ce_target = ce_weight = None
+        if spec.ce:
+            if not nhead:
+                raise _lib.EgxError("EncoderSpec.ce needs the pooled head (head_n_out > 0)")
+            ce_target, ce_weight = rest[-2], rest[-1]
+            rest = rest[:-2]
         layer_t = [_dev_f32(t, "layer weight") for t in rest[nseg + 2 * nproj:len(rest) - nhead]]
         head_t = [_dev_f32(t, "head parameter") for t in rest[len(rest) - nhead:]] if nhead else []
         assert len(layer_t) == 12 * spec.n_layers, "layer parameter count mismatch"
@@ -299,17 +337,52 @@ class EncoderFn(torch.autograd.Function):
             saved = _workspace("saved", device, sv.value)
         scratch = _workspace("scratch", device, sc.value)
         seed = C.c_uint64(spec.seed & (2**64 - 1))
+        # persistent packed-weight cache: valid when nothing that goes into the packed copies changed since the forward that filled it
+        wc, wc_sig = spec.wcache, None
+        if wc is not None:
+            nbytes = lib.egx_weight_cache_bytes(C.byref(cfg), segs)
+            if nbytes:
+                packed = proj[0::2] + [layer_t[12 * l + k] for l in range(spec.n_layers) for k in (0, 2, 4, 6)]
+                keep = (1.0 / (1.0 - spec.p_drop)) if (spec.training and 0.0 < spec.p_drop < 1.0) else 1.0
+                wc_sig = (spec.compute, keep, _weights_epoch[0], nbytes) + tuple((t.data_ptr(), t._version) for t in packed)
+                if wc.buf is None or wc.buf.numel() < nbytes or wc.buf.device != device:
+                    wc.buf, wc.sig = torch.empty(nbytes, dtype=torch.uint8, device=device), None
+                capturing = torch.cuda.is_current_stream_capturing()
+                valid = wc.sig == wc_sig and (wc.frozen or not capturing)
+                cfg.weight_cache, cfg.weight_cache_valid = wc.buf.data_ptr(), int(valid)
+                wc.hits += int(valid)
+                wc.packs += int(not valid)
+                wc.sig = None       # (set again once the call has succeeded)
+            else:
+                wc = None
+        ce_keep = None
+        if spec.ce:
+            if ce_target.dtype != torch.int64 or tuple(ce_target.shape) != (B,) or ce_target.device != device:
+                raise ValueError("target must be an int64 tensor of shape (B,) on the features' device")
+            tgt = ce_target.contiguous()
+            cw = None if ce_weight is None else _dev_f32(ce_weight, "class weight")
+            if cw is not None and cw.numel() != spec.head_n_out:
+                raise ValueError("class weight must have one entry per class")
+            loss = torch.empty((), dtype=torch.float32, device=device)
+            dl = torch.empty((B, spec.head_n_out), dtype=torch.float32, device=device)
+            ce_struct = Ce(ptr(tgt), ptr(cw), ptr(loss), ptr(dl))
+            cfg.ce = C.cast(C.pointer(ce_struct), C.c_void_p)
+            ce_keep = (tgt, cw, ce_struct)
         if nhead:
             head = Head(ptr(head_t[0]), ptr(head_t[1]), ptr(head_t[2]), ptr(head_t[3]), spec.head_n_out)
             tokens = torch.empty((B, spec.head_n_out), dtype=torch.float32, device=device)   # logits
             check(lib.egx_translator_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, C.byref(head), B, ptr(tokens),
                                          None, ptr(saved), ptr(scratch), int(spec.training), seed, _stream()))
+            del ce_keep
         else:
             tokens = torch.empty((B, spec.out_tokens or S, d), dtype=torch.float32, device=device)
             check(lib.egx_encoder_fwd(C.byref(cfg), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(tokens), ptr(saved),
                                       ptr(scratch), int(spec.training), seed, _stream()))
             if py_slice:
                 tokens = tokens[:, :py_slice].contiguous()
+        if wc is not None:
+            wc.sig = wc_sig
+        ctx.wcache_buf = wc.buf if wc is not None else None     # the backward reads the packed copies from the same buffer
         ctx.py_slice, ctx.S = py_slice, S
         ctx.spec = spec
         ctx.impl = lib.egx_encoder_impl(C.byref(cfg), segs, B)       # EGX_IMPL_FUSED / EGX_IMPL_TILED / EGX_IMPL_WIDE / EGX_IMPL_GENERIC
@@ -323,10 +396,27 @@ class EncoderFn(torch.autograd.Function):
         ctx.has_te = task_embed is not None
         ctx.has_pos = pos_table is not None
         ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t + head_t))
+        if spec.ce:
+            ctx.ce_dl = dl
+            ctx.set_materialize_grads(False)
+            return tokens, loss
         return tokens
 
     @staticmethod
-    def backward(ctx, d_tokens):
+    def backward(ctx, d_tokens, d_loss=None):
+        spec0: EncoderSpec = ctx.spec
+        dl_scale = None
+        if spec0.ce:
+            # (logits, loss) outputs: the loss's d_logits was left by the forward; its upstream gradient (loss.backward()'s ones, a loss
+            # scale) goes to the kernels as a device scalar. A gradient reaching the logits directly as well is the rare case: torch ops.
+            if d_loss is None and d_tokens is None:
+                return (None,) * len(ctx.needs_input_grad)
+            if d_loss is not None:
+                g = d_loss if (d_loss.dtype == torch.float32 and d_loss.is_contiguous()) else d_loss.float().contiguous()
+                if d_tokens is None:
+                    d_tokens, dl_scale = ctx.ce_dl, g
+                else:
+                    d_tokens = d_tokens + ctx.ce_dl * g
         if ctx.py_slice:        # gradient of the python-side slice: zeros behind the first tokens
             full = torch.zeros((d_tokens.shape[0], ctx.S, d_tokens.shape[2]), dtype=torch.float32, device=d_tokens.device)
             full[:, :ctx.py_slice] = d_tokens
@@ -404,6 +494,10 @@ class EncoderFn(torch.autograd.Function):
 
         cfg = spec.config()
         cfg.zero_buf, cfg.zero_bytes = ptr(pk.flat), pk.flat.numel() * 4
+        if ctx.wcache_buf is not None:
+            cfg.weight_cache = ctx.wcache_buf.data_ptr()
+        if dl_scale is not None:
+            cfg.d_logits_scale = dl_scale.data_ptr()
         announced = set()
         cb_keep = None
         if hook is not None and ctx.impl == EGX_IMPL_WIDE:
@@ -468,6 +562,8 @@ class EncoderFn(torch.autograd.Function):
             # workspace must not be reused by another encoder call before run_deferred()
             cfg2 = spec.config()
             cfg2.bwd_stage = 2
+            if ctx.wcache_buf is not None:
+                cfg2.weight_cache = ctx.wcache_buf.data_ptr()
             keep = (flat_buf, sv, dtok, scratch, saved_buf)   # noqa: F841  (referenced by `finish`: keeps the buffers alive)
 
             def finish(_keep=keep):
@@ -475,13 +571,18 @@ class EncoderFn(torch.autograd.Function):
             _deferred.append(finish)
         out = [None, g(i_te), g(i_pos), g(i_lnw), g(i_lnb)]
         out += feat_grads + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
+        if spec.ce:
+            out += [None, None]     # target, class weight
         return tuple(out)
 
 
 def encoder(spec: EncoderSpec, feats: Sequence[torch.Tensor], task_embed, pos_table, ln_w, ln_b,
             proj: Sequence[torch.Tensor], layer_params: Sequence[torch.Tensor],
-            head_params: Sequence[torch.Tensor] = ()) -> torch.Tensor:
-    """head_params = (head_ln_w, head_ln_b, head_W, head_b) with spec.head_n_out = head_W.shape[0] -> logits."""
+            head_params: Sequence[torch.Tensor] = (), ce=None):
+    """head_params = (head_ln_w, head_ln_b, head_W, head_b) with spec.head_n_out = head_W.shape[0] -> logits.
+    ce = (target (B,) int64, class_weight | None) with spec.ce: -> (logits, loss), the weighted cross entropy evaluated by the forward."""
+    if spec.ce:
+        return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, *head_params, ce[0], ce[1])
     return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, *head_params)
 
 

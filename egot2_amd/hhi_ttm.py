@@ -69,13 +69,13 @@ class _TTMTranslator(TaskFusion3Task, TranslatorMixin):
             nn.Linear(self.dim, 2)
         )
 
-    def _tokens(self, feats, projs, task_ids, with_head=False):
+    def _tokens(self, feats, projs, task_ids, with_head=False, ce=None):
         segs = [SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=True, add_row=k, pos_row0=0)
                 for f, k in zip(feats, task_ids)]
         head = (self.linear_head[0], self.linear_head[1]) if with_head else None
         return self._egx_encode(feats, segs, encoder=self.transformer_encoder, ln=self.ln, projs=projs,
                                 task_embed=self.task_embed, pos_table=self.pos_embed.pe,
-                                p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p, head=head)
+                                p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p, head=head, ce=ce)
 
     def _head(self, tokens):
         ln, fc = self.linear_head[0], self.linear_head[1]
@@ -94,9 +94,12 @@ class TaskFusionMFTransformer2Task(_TTMTranslator):
         self.proj_ttm = nn.Linear(256, self.dim)
         self._finish()
 
-    def forward_features(self, ttm_out, lam_out):
-        """ttm_out, lam_out: (B, T, 256) backbone features -> (B, 2) logits. Token order ttm, lam (task ids 0, 1)."""
-        return self._tokens([ttm_out, lam_out], [self.proj_ttm, self.proj_lam], [0, 1], with_head=True)
+    def forward_features(self, ttm_out, lam_out, target=None, class_weight=None):
+        """ttm_out, lam_out: (B, T, 256) backbone features -> (B, 2) logits. Token order ttm, lam (task ids 0, 1).
+        target (B,) int64 [, class_weight (2,)]: -> (logits, loss) with loss = nn.CrossEntropyLoss(weight=class_weight)(logits, target)
+        evaluated inside the forward (HHI/tasks/ttm/video_task_2loader.py:21-22,34; one launch less per step)."""
+        return self._tokens([ttm_out, lam_out], [self.proj_ttm, self.proj_lam], [0, 1], with_head=True,
+                            ce=None if target is None else (target, class_weight))
 
     def forward(self, video, audio):
         lam_out = self.lam_model(video, middle=True)  # (bs, T, 256)
@@ -117,10 +120,12 @@ class TaskFusionMFTransformer3Task(_TTMTranslator):
         self.proj_asd = nn.Linear(256, self.dim)
         self._finish()
 
-    def forward_features(self, ttm_out, lam_out, asd_out):
-        """(B, T, 256) features of the three backbones -> (B, 2) logits. Token order ttm, lam, asd = task ids 0, 1, 2."""
+    def forward_features(self, ttm_out, lam_out, asd_out, target=None, class_weight=None):
+        """(B, T, 256) features of the three backbones -> (B, 2) logits. Token order ttm, lam, asd = task ids 0, 1, 2.
+        target (B,) int64 [, class_weight (2,)]: -> (logits, loss) with loss = nn.CrossEntropyLoss(weight=class_weight)(logits, target)
+        evaluated inside the forward (HHI/tasks/ttm/video_task_2loader.py:21-22,34; one launch less per step)."""
         return self._tokens([ttm_out, lam_out, asd_out], [self.proj_ttm, self.proj_lam, self.proj_asd], [0, 1, 2],
-                            with_head=True)
+                            with_head=True, ce=None if target is None else (target, class_weight))
 
     def forward(self, video, video_asd, audio, audio_asd):
         N, D, H, W = video_asd.shape

@@ -57,7 +57,8 @@ def _randn(gen, shape, device):
 
 def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, layers: int | None = None,
                   dtype: str | None = None, impl: str = "auto", dropout: float | None = None, seed: int = 1234,
-                  encoder_only: bool = False, feat_dtype: str = "f32", feat_frames: int = 1, feat_source: str = "tensor") -> Dict:
+                  encoder_only: bool = False, feat_dtype: str = "f32", feat_frames: int = 1, feat_source: str = "tensor",
+                  fused_ce: bool = True) -> Dict:
     from . import functional as F_egx
     from .train import CrossEntropyLoss
     name = name.lower()
@@ -77,11 +78,16 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
         feats = [_randn(gen, (B, T, 256), device) for _ in range(K)]
         target = torch.randint(0, 2, (B,), generator=gen).to(device)
         crit = CrossEntropyLoss(torch.FloatTensor([0.266, 0.734])).to(device)     # video_task_2loader.py:21-22
-        loss_fn = lambda: crit(model.forward_features(*feats), target)   # noqa: E731
+        if fused_ce:        # the criterion evaluated inside the forward (egx_ce: the head epilogue of the launch that writes the logits)
+            cw = crit.weight
+            loss_fn = lambda: model.forward_features(*feats, target=target, class_weight=cw)[1]   # noqa: E731
+        else:
+            loss_fn = lambda: crit(model.forward_features(*feats), target)   # noqa: E731
         segs = [(T, 256, True)] * K
         fl = encoder_flops(B, segs, 128, 2048, L, extra_fwd=2.0 * B * 128 * 2)
         desc = (f"configs[{1 if K == 3 else 0}]: TTM {K}-task translator, {L} layer d=128 h=4 d_ff=2048, B={B}/GPU T={T} "
-                f"S={K * T}, synthetic N(0,1) features, random-init weights, train mode dropout={p} (+0.1 on PE), weighted CE")
+                f"S={K * T}, synthetic N(0,1) features, random-init weights, train mode dropout={p} (+0.1 on PE), weighted CE"
+                + (" (evaluated in the forward's head epilogue)" if fused_ce else ""))
         d, S = 128, K * T
     elif name == "c3":
         from . import hhi_asd

@@ -127,6 +127,7 @@ class FusedAdam(torch.optim.Optimizer):
                 if b is None:
                     b = self._buckets[sig] = self._make_bucket(sig, base.reshape(-1), members)
                 gflat = base.reshape(-1)
+                F_egx.note_weights_changed()       # (raw-pointer update: no version counter moves; packed-weight caches re-pack)
                 check(lib.egx_adam_step(ptr(b.param), ptr(gflat), ptr(b.exp_avg), ptr(b.exp_avg_sq), b.numel,
                                         ptr(self._step_dev), group["lr"], group["betas"][0], group["betas"][1],
                                         group["eps"], group["weight_decay"], int(group["adamw"]), 1.0, stream))
@@ -202,4 +203,6 @@ class GraphedStep:
     def __call__(self, *inputs):
         self._copy_tree(self.static, type(self.static)(inputs) if isinstance(self.static, (list, tuple)) else inputs[0])
         self.graph.replay()
+        if self.optimizer is not None:
+            F_egx.note_weights_changed()           # the replayed update wrote the parameters behind torch's back
         return self.loss

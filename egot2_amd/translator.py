@@ -74,6 +74,26 @@ class TranslatorMixin:
         self.egx_deterministic = bool(on)
         return self
 
+    def enable_weight_cache(self, frozen: bool = False):
+        """Keep the MFMA-fragment-packed weight copies of the per-clip / tiled kernels in a persistent buffer and skip the packing launch
+        of every forward whose weights did not change since the previous one (functional.WeightCache: decided on storage addresses,
+        version counters and functional.note_weights_changed(); FusedAdam and GraphedStep call the latter). Writes that bypass those
+        (`p.data.add_()`) need invalidate_weight_cache(). frozen=True additionally promises that the weights stay as they are while it is
+        set (inference, a forward + backward benchmark): only then is the packing launch left out of a captured hipGraph as well, and the
+        device-resident dropout seed is advanced by the backward (no launch in front of the forward at all)."""
+        self._egx_wcache = F_egx.WeightCache(frozen=frozen)
+        return self
+
+    def disable_weight_cache(self):
+        self._egx_wcache = None
+        return self
+
+    def invalidate_weight_cache(self):
+        wc = getattr(self, "_egx_wcache", None)
+        if wc is not None:
+            wc.invalidate()
+        return self
+
     def enable_device_seed(self, device=None):
         """Keep the dropout seed in device memory and advance it on the stream every training forward, so that a
         captured hipGraph (torch.cuda.graph around forward+backward) draws fresh masks on every replay."""
@@ -89,12 +109,18 @@ class TranslatorMixin:
     def _egx_encode(self, feats: Sequence[torch.Tensor], segments: List[SegmentSpec], *, encoder: nn.TransformerEncoder,
                     ln: nn.LayerNorm, projs: Sequence[Optional[nn.Linear]], task_embed: Optional[torch.Tensor],
                     pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0,
-                    head=None, out_tokens: int = 0) -> torch.Tensor:
+                    head=None, out_tokens: int = 0, ce=None) -> torch.Tensor:
         """head = (nn.LayerNorm, nn.Linear): evaluate the pooled head with the encoder and return logits (B, n_out).
-        out_tokens = T > 0: return only the first T tokens of every clip, (B, T, d) (in-kernel on the fused path)."""
+        out_tokens = T > 0: return only the first T tokens of every clip, (B, T, d) (in-kernel on the fused path).
+        ce = (target, class_weight | None) with a head: also evaluate nn.CrossEntropyLoss(weight)(logits, target) inside the forward
+        (egx_ce) and return (logits, loss)."""
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
+        wcache = getattr(self, "_egx_wcache", None)
+        # device seed: advanced by the forward's first launch (1) or, with a frozen weight cache (no launch in front of the forward), by the
+        # backward behind its last reader (2)
+        adv = 0 if (seed_dev is None or not self.training) else (2 if (wcache is not None and wcache.frozen and torch.is_grad_enabled()) else 1)
         impl = self.egx_impl    # "auto": functional.EncoderFn steers around the fused kernels when a learned `pe` needs a gradient
         spec = EncoderSpec(d_model=d, n_heads=layer0.self_attn.num_heads, d_ff=layer0.linear1.out_features,
                            n_layers=len(encoder.layers), segments=segments, ln_eps=ln.eps,
@@ -103,13 +129,15 @@ class TranslatorMixin:
                            training=bool(self.training), seed=self._egx_seed() if self.training else 0,
                            seed_ptr=seed_dev.data_ptr() if seed_dev is not None else 0,
                            head_n_out=head[1].out_features if head is not None else 0,
-                           advance_seed=seed_dev is not None and bool(self.training),   # fresh masks per (replayed) step
+                           advance_seed=adv,   # fresh masks per (replayed) step
                            defer_small=bool(self.egx_defer_small), deterministic=bool(self.egx_deterministic),
-                           out_tokens=int(out_tokens))
+                           out_tokens=int(out_tokens), wcache=wcache, ce=ce is not None)
         proj_t = []
         for s, p in zip(segments, projs):
             if s.has_proj:
                 proj_t += [p.weight, p.bias]
         head_t = (head[0].weight, head[0].bias, head[1].weight, head[1].bias) if head is not None else ()
+        if ce is not None and head is None:
+            raise ValueError("the fused cross entropy needs the pooled head")
         return F_egx.encoder(spec, list(feats), task_embed, pos_table, ln.weight, ln.bias, proj_t,
-                             encoder_layer_tensors(encoder), head_t)
+                             encoder_layer_tensors(encoder), head_t, ce=ce)

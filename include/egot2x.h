@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 14
+#define EGX_ABI_VERSION 15
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -118,6 +118,7 @@ typedef struct egx_layer_grads {
     float* norm2_b;
 } egx_layer_grads;
 
+struct egx_ce;
 typedef struct egx_config {
     int d_model;
     int n_heads;
@@ -134,9 +135,12 @@ typedef struct egx_config {
                                  from *seed_ptr instead of the host `seed` argument, so a captured hipGraph draws fresh
                                  masks on every replay (advance it with egx_seed_advance inside the graph, or set
                                  advance_seed). */
-    int advance_seed;         /* != 0 with seed_ptr: a training-mode forward advances *seed_ptr by one LCG step before
+    int advance_seed;         /* 1 with seed_ptr: a training-mode forward advances *seed_ptr by one LCG step before
                                  using it (folded into its first kernel), the backward of that forward reads the
-                                 advanced value. */
+                                 advanced value. 2 (ABI v15): the forward uses *seed_ptr as it is and the BACKWARD advances it
+                                 behind its last reader (folded into its last launch): a forward + backward step needs no launch
+                                 in front of the forward even when the packing launch is skipped (weight_cache_valid); a training
+                                 forward that is never followed by its backward repeats the masks of the previous one. */
     void* zero_buf;           /* optional: a device buffer the BACKWARD zero-fills before any gradient is accumulated */
     size_t zero_bytes;        /* (the caller's flat gradient buffer: saves a separate fill launch); multiple of 16 */
     int bwd_stage;            /* backward only: 0 = everything; 1 = all but the grouped small weight gradients (dW_proj,
@@ -164,9 +168,38 @@ typedef struct egx_config {
                                  HOI/scripts/multitask/run.py:41-50). With a callback every split-K slab reduction runs right
                                  behind its GEMM (no deferred batch). Other implementations ignore it. */
     void* bucket_user;
+    /* ---- ABI v15 (round 6) ---- */
+    void* weight_cache;       /* optional PERSISTENT device buffer of egx_weight_cache_bytes() bytes (per-clip / tiled kernels): the
+                                 MFMA-fragment-packed copies of the weights live there instead of in `saved`, so that a forward whose
+                                 weights did not change since the forward that filled it can skip the packing launch
+                                 (weight_cache_valid). The backward must be given the same buffer. NULL: packed into `saved` every forward. */
+    int weight_cache_valid;   /* forward, with weight_cache: != 0 = the cache holds the packed copies of EXACTLY these weights in this
+                                 compute mode with this FFN keep-scale (training, p_drop): nothing is packed. The caller owns that
+                                 promise (egot2_amd/translator.py keys it on the parameters' storage and version counters). */
+    const float* d_logits_scale; /* backward, optional DEVICE scalar: the pooled head's backward multiplies d_logits by it (the upstream
+                                 gradient of a loss the forward computed itself, egx_ce; lets loss.backward() hand its ones / loss-scale
+                                 tensor over without a launch). Per-clip kernels only; NULL = 1. */
+    const struct egx_ce* ce;  /* forward, optional (egx_translator_fwd with a head): weighted cross entropy on the logits, see egx_ce */
 } egx_config;
 
+/* Weighted cross entropy ON the pooled head's logits, evaluated by the translator forward itself
+ * (nn.CrossEntropyLoss(weight=[0.266, 0.734])(model(...), target), HHI/tasks/ttm/video_task_2loader.py:21-22,34 — the same arithmetic as
+ * egx_weighted_ce, labels outside [0, n_out) contribute neither loss, weight nor gradient). On the per-clip kernels it runs in the epilogue of
+ * the launch that produces the logits (the normaliser sum_i w[y_i] depends on the labels only: every workgroup sums it itself), so
+ * d loss / d logits is in place when the backward starts and the step has one launch less; elsewhere (tiled / wide / generic kernels,
+ * deterministic mode) the library appends the egx_weighted_ce launch. Pass `d_logits` as egx_translator_bwd's d_logits (scaled by
+ * egx_config.d_logits_scale when the loss itself has an upstream gradient other than 1). */
+typedef struct egx_ce {
+    const int64_t* target;      /* (B) class indices */
+    const float* class_weight;  /* (n_out) or NULL (= 1) */
+    float* loss;                /* scalar, written */
+    float* d_logits;            /* (B, n_out), written */
+} egx_ce;
+
 int egx_abi_version(void);
+/* Bytes of egx_config.weight_cache for this configuration (0: this configuration does not run on kernels that pack weights). Depends on
+ * the model dimensions and the compute mode, not on the batch. */
+size_t egx_weight_cache_bytes(const egx_config* cfg, const egx_segment* segs);
 /* Kernel launches (and memsets) the library has enqueued on this thread's behalf since the last reset: the bench reports
  * launches per step with it. reset != 0 zeroes the counter after reading. Not thread-safe (a diagnostic). */
 long long egx_launch_count(int reset);

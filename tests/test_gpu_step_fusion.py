@@ -1,0 +1,272 @@
+"""-m gpu: round-6 step fusions of the per-clip path — the weighted cross entropy evaluated in the forward's head epilogue (egx_ce), the
+persistent packed-weight cache (egx_config.weight_cache) and the device seed advanced by the backward (egx_config.advance_seed = 2).
+Each is checked against the path it replaces (separate CE launch, packing launch in every forward, seed advanced by the forward) and, for
+the loss, against the fp64 oracle (HHI/tasks/ttm/video_task_2loader.py:21-22,34 = nn.CrossEntropyLoss(weight=[0.266, 0.734]))."""
+import os
+
+import pytest
+import torch
+
+from tests.util import hhi_args, max_err, rel_err, seeded_feats, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+CE_W = [0.266, 0.734]
+
+
+def _model(cuda, compute="f32s", p=0.0, tasks=3, layers=1):
+    from egot2_amd import hhi_ttm
+    cls = hhi_ttm.TaskFusionMFTransformer3Task if tasks == 3 else hhi_ttm.TaskFusionMFTransformer2Task
+    m = cls(hhi_args(dropout=p, num_layers=layers))
+    m.load_state_dict(seeded_state_dict(m, 21))
+    m = m.to(cuda).set_compute(compute).train()
+    m.pos_embed.dropout.p = 0.0 if p == 0.0 else m.pos_embed.dropout.p
+    return m
+
+
+def _grads(m):
+    return {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("compute,B,cut", [("f32s", 256, None), ("f32s", 7, "1"), ("f32s", 7, "0"), ("f32", 33, None), ("bf16", 256, None),
+                                           ("bf16", 5, "1")])
+def test_fused_cross_entropy_equals_separate_launch_and_oracle(egx_lib, cuda, compute, B, cut):
+    """(logits, loss) from one forward call: same logits and gradients as forward + egx_weighted_ce, loss within 1e-6, and the loss against
+    the fp64 oracle. Labels outside [0, C) (ignore_index = -100) carry neither loss, weight nor gradient. EGX_FFN_SLICES=1: one workgroup
+    per clip, so that EGX_FFN_CUT picks the launch whose epilogue is under test (ffn_fwd_kernel / fused_fwd_kernel)."""
+    from egot2_amd import functional as F_egx
+    from oracle import translator_ref as tr
+    m = _model(cuda, compute)
+    feats = [f.to(cuda) for f in seeded_feats(31, [(B, 15, 256)] * 3)]
+    g = torch.Generator().manual_seed(5)
+    target = torch.randint(0, 2, (B,), generator=g)
+    with_oracle = compute != "bf16" and B <= 33
+    if not with_oracle:
+        target[B // 2] = -100           # (the oracle's weighted_ce has no ignore_index)
+    target = target.to(cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    with _Env(EGX_FFN_CUT=cut, EGX_FFN_SLICES="1" if cut is not None else None):
+        m.zero_grad()
+        logits_a = m.forward_features(*feats)
+        loss_a = F_egx.weighted_cross_entropy(logits_a, target, w)
+        loss_a.backward()
+        ga = _grads(m)
+        m.zero_grad()
+        logits_b, loss_b = m.forward_features(*feats, target=target, class_weight=w)
+        loss_b.backward()
+        gb = _grads(m)
+    torch.cuda.synchronize()
+    assert torch.equal(logits_a, logits_b)
+    assert abs(loss_a.item() - loss_b.item()) < 2e-6 * max(1.0, abs(loss_a.item()))
+    # (atomic accumulation order differs run to run; bf16: d_logits differing in the last bit flips roundings of bf16 operands downstream)
+    for k in ga:
+        assert rel_err(gb[k], ga[k]) < (5e-3 if compute == "bf16" else 2e-5), k
+    ref = torch.nn.functional.cross_entropy(logits_b.double().cpu(), target.cpu(), weight=torch.tensor(CE_W, dtype=torch.float64))
+    assert abs(ref.item() - loss_b.item()) < 1e-5
+    if with_oracle:
+        sd64 = {k: v.detach().double().cpu().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in m.state_dict().items()}
+        out = tr.ttm_forward(sd64, 4, *[f.double().cpu() for f in feats])
+        tr.weighted_ce(out, target.cpu(), CE_W).backward()
+        assert max_err(logits_b, out.detach()) < 1e-3
+        name = "transformer_encoder.layers.0.linear1.weight"
+        assert rel_err(gb[name], sd64[name].grad) < 1e-2
+
+
+def test_fused_cross_entropy_upstream_gradients(egx_lib, cuda):
+    """The loss's upstream gradient reaches the kernels as a device scalar (3 * loss), a gradient into the logits themselves is added by
+    torch ops, an unused loss leaves the plain logits path; no class weights = plain mean cross entropy."""
+    m = _model(cuda, "f32s")
+    B = 9
+    feats = [f.to(cuda) for f in seeded_feats(32, [(B, 15, 256)] * 3)]
+    target = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1, 1], device=cuda)
+
+    def run(fused, fn):
+        m.zero_grad()
+        if fused:
+            logits, loss = m.forward_features(*feats, target=target)
+        else:
+            logits = m.forward_features(*feats)
+            loss = torch.nn.functional.cross_entropy(logits, target)
+        fn(logits, loss).backward()
+        return _grads(m)
+
+    for fn in (lambda z, l: 3.0 * l, lambda z, l: l + (z * z).sum() * 0.1, lambda z, l: (z * z).sum()):
+        a, b = run(False, fn), run(True, fn)
+        for k in a:
+            assert rel_err(b[k], a[k]) < 2e-5, k
+
+
+def test_fused_cross_entropy_without_valid_label_is_nan_like_torch(egx_lib, cuda):
+    m = _model(cuda, "f32s")
+    feats = [f.to(cuda) for f in seeded_feats(33, [(3, 15, 256)] * 3)]
+    target = torch.full((3,), -100, dtype=torch.int64, device=cuda)
+    with torch.no_grad():
+        _, loss = m.forward_features(*feats, target=target, class_weight=torch.tensor(CE_W, device=cuda))
+    assert torch.isnan(loss).item()
+
+
+def test_fused_cross_entropy_on_other_implementations(egx_lib, cuda):
+    """Tiled kernels (S > 48) and the deterministic mode append the egx_weighted_ce launch inside the library call: same API, same numbers."""
+    from egot2_amd import functional as F_egx
+    m = _model(cuda, "f32s")
+    B = 4
+    feats = [f.to(cuda) for f in seeded_feats(34, [(B, 20, 256)] * 3)]      # S = 60: tiled
+    target = torch.tensor([1, 0, 0, 1], device=cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    for det in (False, True):
+        m.set_deterministic(det)
+        m.zero_grad()
+        z = m.forward_features(*feats)
+        F_egx.weighted_cross_entropy(z, target, w).backward()
+        ga = _grads(m)
+        m.zero_grad()
+        z2, loss = m.forward_features(*feats, target=target, class_weight=w)
+        loss.backward()
+        gb = _grads(m)
+        assert torch.equal(z, z2)
+        for k in ga:
+            assert rel_err(gb[k], ga[k]) < 2e-5, k
+    m.set_deterministic(False)
+    assert F_egx.last_encoder_impl() == "tiled"
+
+
+@pytest.mark.parametrize("compute", ["f32s", "bf16", "f32"])
+def test_weight_cache_skips_the_packing_launch_and_follows_the_weights(egx_lib, cuda, compute):
+    """Second forward with unchanged weights: a cache hit, one library launch less, bit-identical logits. An in-place torch update, a change of
+    the dropout probability (the FFN keep-scale rides on the packed W1) and note_weights_changed() each force a re-pack; the results follow
+    a model without the cache."""
+    from egot2_amd import functional as F_egx
+    m = _model(cuda, compute, p=0.0)
+    ref = _model(cuda, compute, p=0.0)
+    nb = 130        # (above the sliced mode of small batches, whose flag words the packing launch zeroes: that launch then stays)
+    feats = [f.to(cuda) for f in seeded_feats(35, [(nb, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (nb,), generator=torch.Generator().manual_seed(1)).to(cuda)
+    m.enable_weight_cache()
+    wc = m._egx_wcache
+
+    def step(mm):
+        mm.zero_grad()
+        z = mm.forward_features(*feats)
+        torch.nn.functional.cross_entropy(z, target).backward()
+        return z.detach().clone(), _grads(mm)
+
+    egx_lib.egx_launch_count(1)
+    z1, g1 = step(m)
+    n1 = egx_lib.egx_launch_count(1)
+    z2, g2 = step(m)
+    n2 = egx_lib.egx_launch_count(1)
+    assert (wc.packs, wc.hits) == (1, 1) and n2 == n1 - 1
+    zr, gr = step(ref)
+    assert torch.equal(z1, z2) and torch.equal(z1, zr)
+    for k in gr:
+        assert rel_err(g2[k], gr[k]) < 2e-5, k
+    # in-place update through torch: version counters move
+    with torch.no_grad():
+        for mm in (m, ref):
+            mm.transformer_encoder.layers[0].linear1.weight.mul_(1.25)
+            mm.proj_lam.weight.add_(0.01)
+    z3, _ = step(m)
+    zr3, _ = step(ref)
+    assert wc.packs == 2 and torch.equal(z3, zr3) and not torch.equal(z3, z1)
+    # raw-pointer style update (what FusedAdam does): invisible to torch, announced by note_weights_changed()
+    with torch.no_grad():
+        for mm in (m, ref):
+            mm.transformer_encoder.layers[0].linear2.weight.data.mul_(0.5)       # .data: no version bump
+    F_egx.note_weights_changed()
+    z4, _ = step(m)
+    zr4, _ = step(ref)
+    assert wc.packs == 3 and torch.equal(z4, zr4)
+    # the FFN dropout keep-scale is part of the packed W1 / W2^T
+    m.dp_rate = ref.dp_rate = 0.25
+    m.enable_device_seed(); ref.enable_device_seed()
+    m._egx_seed_dev.fill_(77); ref._egx_seed_dev.fill_(77)
+    z5, _ = step(m)
+    zr5, _ = step(ref)
+    assert wc.packs == 4 and torch.equal(z5, zr5)
+    m.eval(); ref.eval()
+    with torch.no_grad():
+        assert torch.equal(m.forward_features(*feats), ref.forward_features(*feats))
+    assert wc.packs == 5                                    # eval: keep-scale 1 again
+
+
+def test_frozen_cache_graph_step_has_no_launch_in_front_of_the_forward(egx_lib, cuda):
+    """bench.py's step: frozen weight cache + fused cross entropy + device seed advanced by the backward, captured as one hipGraph. The graph
+    holds two launches less than the round-5 step (packing, cross entropy), every replay draws fresh masks (the seed moves exactly one LCG
+    step per replay), and a replay from a pinned seed equals the eager round-5 step from the same seed."""
+    from egot2_amd import functional as F_egx
+    B = 64
+    feats = [f.to(cuda) for f in seeded_feats(36, [(B, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(2)).to(cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    one = F_egx.unit_grad(cuda)
+    lcg = lambda s: (s * 6364136223846793005 + 1442695040888963407) % (1 << 64)      # noqa: E731
+    s64 = lambda x: x - (1 << 64) if x >= (1 << 63) else x                           # noqa: E731  (the seed tensor is int64)
+
+    with _Env(EGX_FFN_SLICES="1"):
+        old = _model(cuda, "f32s", p=0.5).enable_device_seed()
+        new = _model(cuda, "f32s", p=0.5).enable_device_seed().enable_weight_cache(frozen=True)
+
+        def step_old():
+            old.zero_grad()
+            loss = F_egx.weighted_cross_entropy(old.forward_features(*feats), target, w)
+            loss.backward(gradient=one)
+            return loss
+
+        def step_new():
+            for p in new.parameters():
+                p.grad = None
+            loss = new.forward_features(*feats, target=target, class_weight=w)[1]
+            loss.backward(gradient=one)
+            return loss
+
+        egx_lib.egx_launch_count(1)
+        step_old()
+        n_old = egx_lib.egx_launch_count(1)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step_new()
+            step_new()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        egx_lib.egx_launch_count(1)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            loss_new = step_new()
+        n_new = egx_lib.egx_launch_count(1)
+        assert n_new == n_old - 2, (n_old, n_new)
+
+        s0 = 4242
+        new._egx_seed_dev.fill_(s64(lcg(s0)))        # the round-5 forward advances BEFORE it uses the seed; the new step uses it as it is
+        old._egx_seed_dev.fill_(s0)
+        gr.replay()
+        l_old = step_old()
+        torch.cuda.synchronize()
+        assert new._egx_seed_dev.item() % (1 << 64) == lcg(lcg(s0)) and old._egx_seed_dev.item() % (1 << 64) == lcg(s0)
+        assert abs(loss_new.item() - l_old.item()) < 1e-5
+        g_old, g_new = _grads(old), _grads(new)
+        for k in g_old:
+            assert rel_err(g_new[k], g_old[k]) < 2e-5, k
+        a = loss_new.item()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert loss_new.item() != a, "a replay must draw fresh dropout masks"
