@@ -944,6 +944,33 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 EGX_HIP(hipMemsetAsync(bp.xflags, 0, sliced_flag_words(pl) * 4, st));
                 bp.slice_drop = slice_drop_mask(bp.n_slices);
             }
+            // FFN weight gradient of layer l (dW1, db1, dW2 from the stored H / dH tiles and the x1 / g2 planes); every layer's slabs are summed by ONE
+            // launch behind the last one. (Round 6 tried it right behind ffn_bwd_kernel of the same layer, while dH and g2 are still in the Infinity
+            // Cache: three same-box pairs 372.1 / 374.9 / 371.9 vs 372.2 / 370.3 / 376.1 us, no difference; and the exact-fp32 mode needs x1 from the
+            // attention-side launch first. It stays behind the whole backward.)
+            SlabReduce red;
+            red.narr = 0; red.nslab = 0;
+            auto launch_ffn_dw = [&](int l) -> int {
+                const egx_layer& w = layers[l];
+                const egx_layer_grads& gw = layer_grads[l];
+                if (!(gw.lin1_w || gw.lin1_b || gw.lin2_w)) return 0;
+                FfnDwParams fp;
+                memset(&fp, 0, sizeof(fp));
+                fp.x1 = bp.layer[l].x1_out; fp.g = bp.layer[l].g2_out;
+                fp.w1p = PL.layer[l].lin1_w; fp.w2tp = PL.layer[l].lin2_wt; fp.b1 = w.lin1_b;
+                fp.N = N; fp.S = S; fp.d_ff = pl.dff;
+                fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
+                fp.seed_ptr = cfg->seed_ptr; fp.layer = l;
+                if (store_hidden()) {
+                    size_t lo = (size_t)l * fused_hid_bytes(vp.vB, pl.dff, comp == EGX_BF16);
+                    fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, vp) + lo;
+                    fp.dhs = (const char*)scratch + SC.dhid + lo;
+                    fp.B = vp.vB;
+                    fp.xg_planes = bp.xg_planes;
+                    if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, vp) + (size_t)l * vp.vB * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
+                }
+                return ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, (char*)scratch + SC.ffn_slab[l], st, nullptr, cfg->deterministic != 0, &red);
+            };
             if (stage != 2 && use_cut(pl, bp.n_slices, tiled, comp)) {
                 // cut mode: per layer, top down, [LayerNorm2 backward + FFN input gradient] (8 waves per clip) + [LayerNorm1 backward .. the layer
                 // input's gradient, or the token-preparation backward] (4 waves)
@@ -1019,31 +1046,8 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             // the partial-row reduction rides in the slab-reduction launch of the first FFN weight gradient
             bool rp_pending = stage != 2;
             void* slab = (char*)scratch + SC.slabs;
-            SlabReduce red;
-            red.narr = 0; red.nslab = 0;
-            for (int l = 0; l < pl.L && stage != 2; ++l) {
-                const egx_layer& w = layers[l];
-                const egx_layer_grads& gw = layer_grads[l];
-                if (gw.lin1_w || gw.lin1_b || gw.lin2_w) {
-                    FfnDwParams fp;
-                    memset(&fp, 0, sizeof(fp));
-                    fp.x1 = bp.layer[l].x1_out; fp.g = bp.layer[l].g2_out;
-                    fp.w1p = PL.layer[l].lin1_w; fp.w2tp = PL.layer[l].lin2_wt; fp.b1 = w.lin1_b;
-                    fp.N = N; fp.S = S; fp.d_ff = pl.dff;
-                    fp.drop_key = bp.layer[l].ffn_key; fp.drop_thresh = bp.layer[l].ffn_thresh; fp.drop_inv = bp.layer[l].drop_inv;
-                    fp.seed_ptr = cfg->seed_ptr; fp.layer = l;
-                    if (store_hidden()) {
-                        size_t lo = (size_t)l * fused_hid_bytes(vp.vB, pl.dff, comp == EGX_BF16);
-                        fp.hs = (const char*)saved + fused_hid_offset(cfg, segs, vp) + lo;
-                        fp.dhs = (const char*)scratch + SC.dhid + lo;
-                        fp.B = vp.vB;
-                        fp.xg_planes = bp.xg_planes;
-                        if (fp.xg_planes) fp.x1 = (const float*)((const char*)saved + fused_x1p_offset(cfg, segs, vp) + (size_t)l * vp.vB * FUSED_TOK_PAD * d * plane_elem_bytes(cfg));
-                    }
-                    // every layer's slabs (and the partial rows) are summed by ONE launch behind the last layer's kernel
-                    if (ffn_dw(fp, comp, gw.lin1_w, gw.lin1_b, gw.lin2_w, (char*)scratch + SC.ffn_slab[l], st, nullptr, cfg->deterministic != 0, &red)) return 1;
-                }
-            }
+            for (int l = 0; l < pl.L && stage != 2; ++l)
+                if (launch_ffn_dw(l)) return 1;
             // One-stage backward outside the deterministic mode: the reductions ride in the grouped small-gradient launch below
             // (its workgroups each sum 1 / grid of the slabs and partial rows first). Otherwise (two-stage backward: the late
             // region must be complete when the exchange starts; deterministic: fixed single-adder order) they get their own launch.

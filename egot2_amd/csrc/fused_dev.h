@@ -2,6 +2,7 @@
 // the MFMA operand convention, fragment loads, packed-weight access and the row-parallel LayerNorm.
 #pragma once
 #include "common.h"
+#include "fused.h"       // TouchList
 
 namespace egx {
 
