@@ -687,6 +687,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
         fp.pos_key = dpz.key; fp.pos_thresh = dpz.thresh; fp.pos_inv = dpz.inv_keep;
         fp.seed_ptr = cfg->seed_ptr;
         fp.rot_mode = ffn_rot_mode();
+        { static const int sh = [] { const char* e = getenv("EGX_CUT_SHIFT_F"); return e ? atoi(e) + 1 : 0; }(); fp.rot_mode |= sh << 8; }    // tuning aid: older : younger wave split of ffn_fwd_kernel
         fp.n_slices = tiled ? 1 : fused_slices(pl, comp);
         if (fp.n_slices > 1) {
             fp.xchg = (float*)((char*)saved + fused_core_bytes(cfg, segs, vp));
@@ -934,6 +935,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             bp.pos_key = dpz.key; bp.pos_thresh = dpz.thresh; bp.pos_inv = dpz.inv_keep;
             bp.seed_ptr = cfg->seed_ptr;
             bp.rot_mode = ffn_rot_mode();
+            { static const int sh = [] { const char* e = getenv("EGX_CUT_SHIFT_B"); return e ? atoi(e) + 1 : 0; }(); bp.rot_mode |= sh << 8; }    // tuning aid: ffn_bwd_kernel
             const int stage = cfg->bwd_stage;
             EGX_CHECK(stage >= 0 && stage <= 2, "bwd_stage=%d", stage);
             if (stage == 2) bp.zero_buf = nullptr;

@@ -150,8 +150,8 @@ __device__ __forceinline__ void block_to_split_planes(unsigned short* planes, co
 // one (107k; stamps, profiles/r05_cut_stamps.txt). So the older wave takes nit / 8 blocks more, the younger as many fewer (9 : 7 at
 // d_ff = 2048) — a STATIC split: sums stay in a fixed order. bf16's short blocks are 12 % apart and keep the even split.
 template <int CM>
-__device__ __forceinline__ void cut_walk(int wave, int nit, int& j_begin, int& n_mine) {
-    const int shift = CM == CM_BF16 ? 0 : nit / 8;
+__device__ __forceinline__ void cut_walk(int wave, int nit, int& j_begin, int& n_mine, int shift_code = 0) {
+    const int shift = shift_code ? shift_code - 1 : (CM == CM_BF16 ? 0 : nit / 8);
     const int n_old = nit + shift;
     j_begin = wave < 4 ? 0 : n_old;
     n_mine = wave < 4 ? n_old : 2 * nit - n_old;
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
     if (p.touch.n) tch = touch_lines<CT>(p.touch, blockIdx.x, gridDim.x, tid);
     const int nhb = p.d_ff / 32;
     int j_begin_, n_mine_;
-    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_);
+    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
     const int nit = __builtin_amdgcn_readfirstlane(n_mine_), j_begin = __builtin_amdgcn_readfirstlane(j_begin_);
     const int pair_s = __builtin_amdgcn_readfirstlane(wave & 3);
-    const int rot = cut_rot(p.rot_mode, clip, nit);
+    const int rot = cut_rot(p.rot_mode & 255, clip, nit);
     auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return pair_s + 4 * (j_begin + j); };
     float* CP = lds + 5 * CBLK;
     // LayerNorm2 / bias / head parameters -> LDS: requested here with everything else (unconditional, clamped), stored in front of the first barrier
@@ -534,10 +534,10 @@ __global__ __launch_bounds__(CT) void ffn_bwd_kernel(FusedBwdParams p, int l) {
 
     const int nhb = p.d_ff / 32;
     int j_begin_, n_mine_;
-    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_);
+    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
     const int nit = __builtin_amdgcn_readfirstlane(n_mine_), j_begin = __builtin_amdgcn_readfirstlane(j_begin_);
     const int pair_s = __builtin_amdgcn_readfirstlane(wave & 3);
-    const int rot = cut_rot(p.rot_mode, clip, nit);
+    const int rot = cut_rot(p.rot_mode & 255, clip, nit);
     auto hb_of = [&](int it) { int j = it + rot; if (j >= nit) j -= nit; return pair_s + 4 * (j_begin + j); };
     float* CP = lds + 5 * CBLK;
     // LayerNorm2 weights and the head's parameters -> LDS (see ffn_fwd_kernel): requested here, stored in front of the first barrier

@@ -135,6 +135,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     // segment (advance / source / store touch ~10 fields per step: 2.5-3k cycles per step, 15-18k of the 35-40k cycles of the
     // token preparation by the stamps); one ds_read burst + v_readfirstlane per step instead
     FusedSeg* segtab = reinterpret_cast<FusedSeg*>(X1 + SP * LDX);
+    // small parameter vectors staged in LDS (round 6, see ln_rows_lds): rows of 128 floats behind the segment table
+    //   0 ln_w, 1 ln_b, 2..5 task-embedding row of segment 0..3 | per layer: 6 norm1_w, 7 norm1_b, 8 out_proj_b, 9 norm2_w, 10 norm2_b, 11 lin2_b
+    float* PS = reinterpret_cast<float*>(reinterpret_cast<char*>(segtab) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16);
+    static_assert((FUSED_MAX_SEG * sizeof(FusedSeg)) % 16 == 0, "the parameter rows are read in 16-byte pieces");
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -186,6 +190,14 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         }
     } else {
         if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
+    }
+    const int ps_g = tid >> 5, ps_c = (tid & 31) << 2;      // staging: thread (row group, 4 columns)
+    {   // shared LayerNorm + task-embedding rows (a missing one repeats ln_w: never read)
+        const int sg_i = ps_g - 2;
+        const float* av = sg_i == 0 ? p.seg[0].add_vec : sg_i == 1 ? p.seg[1].add_vec : sg_i == 2 ? p.seg[2].add_vec : sg_i == 3 ? p.seg[3].add_vec : nullptr;
+        const float* src = ps_g == 1 ? p.ln_b : (av && sg_i < p.nseg) ? av : p.ln_w;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + ps_c);
+        if (ps_g < 6) *reinterpret_cast<f32x4*>(PS + ps_g * FD + ps_c) = v;
     }
     __syncthreads();
     const int nseg_t = TILED ? *nseg_slot : p.nseg;
@@ -334,8 +346,10 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         Step cur{0, 0, 0};
         {
             const Step n1 = clamped(advance(cur), cur);
+            STAMP(12);
             issue_all(SA{}, cur);
             issue_all(SB{}, n1);
+            STAMP(13);
         }
         // zero the padded rows once so that padded tokens stay finite everywhere: 16-byte writes, under the first steps' loads
         static_assert((SP * LDX) % 4 == 0, "blocks are zeroed in 16-byte pieces");
@@ -343,7 +357,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             reinterpret_cast<f32x4*>(Xs)[i] = f32x4{0, 0, 0, 0};
             reinterpret_cast<f32x4*>(X1)[i] = f32x4{0, 0, 0, 0};
         }
+        STAMP(14);
         __syncthreads();
+        STAMP(15);
         for (;;) {
             if (!valid(cur)) break;
             {
@@ -367,13 +383,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     // lane's token are requested unconditionally behind the LayerNorm weights (a missing table reads the LayerNorm weights and
     // is scaled by zero), the save follows them: nothing in this phase waits for a store or for a load under a branch.
     {
-        f32x4 av[8], pv[8];
+        f32x4 pv[8];
         float a_on = 0.f, p_on = 0.f;
-        ln_rows(Xs, S, p.ln_w, p.ln_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+        const float* a_row = PS;        // the lane's task-embedding row in LDS (set by the hook)
+        ln_rows_lds(Xs, S, PS, PS + FD, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 avj = *reinterpret_cast<const f32x4*>(a_row + c0 + 4 * j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[4 * j + e] = __builtin_fmaf(p_on, pv[j][e], __builtin_fmaf(a_on, av[j][e], y[4 * j + e]));     // (y + emb) + pos
+                for (int e = 0; e < 4; ++e) y[4 * j + e] = __builtin_fmaf(p_on, pv[j][e], __builtin_fmaf(a_on, avj[e], y[4 * j + e]));     // (y + emb) + pos
+            }
             if (p.pos_thresh) {
                 uint32_t orow = (uint32_t)(tokbase + row);
 #pragma unroll
@@ -389,15 +408,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             int sgi = 0;
             while (sgi + 1 < nseg_t && row >= segtab[sgi + 1].off) ++sgi;
             const FusedSeg sg = segtab[sgi];
-            const float* ap = sg.add_vec ? sg.add_vec + c0 : p.ln_w + c0;
             const float* pp = sg.pos ? sg.pos + (size_t)(row - sg.off + (TILED ? sg.row0 : 0)) * sg.pos_stride + c0 : p.ln_w + c0;
+            a_row = PS + (2 + sg.seg_id) * FD;
             a_on = sg.add_vec ? 1.f : 0.f;
             p_on = sg.pos ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                av[j] = *reinterpret_cast<const f32x4*>(ap + 4 * j);
-                pv[j] = *reinterpret_cast<const f32x4*>(pp + 4 * j);
-            }
+            for (int j = 0; j < 8; ++j) pv[j] = *reinterpret_cast<const f32x4*>(pp + 4 * j);
             store_block(p.saved_pre + tokbase * FD, Xs, S);
             __syncthreads();        // the LayerNorm below writes Xs in place
         });
@@ -413,6 +429,12 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         const uint64_t k_res2 = dev_seed ? site_key(seed_dev, l, SITE_RES2) : w.res2_key;
         float* sv_res1 = TILED ? p.saved_res + ((size_t)(2 * l) * p.Ntok + tokbase) * FD : p.saved_res + ((size_t)(2 * l) * p.B + clip) * S * FD;
         float* sv_res2 = TILED ? p.saved_res + ((size_t)(2 * l + 1) * p.Ntok + tokbase) * FD : p.saved_res + ((size_t)(2 * l + 1) * p.B + clip) * S * FD;
+        // this layer's small parameter vectors: requested here, stored into LDS rows 6..11 in front of the out-projection
+        f32x4 pl_v;
+        {
+            const float* src = ps_g == 1 ? w.norm1_b : ps_g == 2 ? w.out_proj_b : ps_g == 3 ? w.norm2_w : ps_g == 4 ? w.norm2_b : ps_g == 5 ? w.lin2_b : w.norm1_w;
+            pl_v = *reinterpret_cast<const f32x4*>(src + ps_c);
+        }
 
         if (!TILED || !skip_front) {
         STAMP(2);
@@ -595,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
         STAMP(4);
         EGX_PHASE();
+        if (ps_g < 6) *reinterpret_cast<f32x4*>(PS + (6 + ps_g) * FD + ps_c) = pl_v;
         // ---- out-projection + residual -> res1 (X1 region), 2 feature tiles per wave
         {
             f32x4 acc[2][NT];
@@ -622,10 +645,11 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     for (int t = 0; t < NT; ++t) mma<CM>(acc[i][t], a, b[t]);
                 }
             }
+            __syncthreads();        // the staged rows 6..11 are visible (the epilogue reads out_proj_b from them)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int f0 = (wave * 2 + i) * 16 + 4 * q;
-                float4 bb = *reinterpret_cast<const float4*>(w.out_proj_b + f0);
+                float4 bb = *reinterpret_cast<const float4*>(PS + 8 * FD + f0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     int tok = t * 16 + r;
@@ -648,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         // CM_SPLIT: x1 is also split into bf16 operand planes for the FFN loop (over Q / K, dead since the out-projection)
         unsigned short* XP = reinterpret_cast<unsigned short*>(Qs);
         constexpr int XPS = SP * LDXH;
-        ln_rows(X1, S, w.norm1_w, w.norm1_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+        ln_rows_lds(X1, S, PS + 6 * FD, PS + 7 * FD, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
             store32(X1 + row * LDX + c0, y);
             if constexpr (CM == CM_SPLIT) {
                 uint32_t h[16], m[16], lo[16];
@@ -688,6 +712,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
         if constexpr (CUT) {        // x1 as fp32 rows: ffn_fwd_kernel's residual (and, in exact-fp32 mode, its operand; the weight-gradient kernel's too)
             store_block(p.x1f_out + ((size_t)l * p.Ntok + tokbase) * FD, X1, S);
+            STAMP(6);
             return;
         }
         STAMP(6);
@@ -938,7 +963,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                         a3 = *reinterpret_cast<const float4*>(Part + 2 * SP * LDX + o);
                     }
                     float4 x1 = *reinterpret_cast<const float4*>(X1 + o);
-                    float4 b2 = *reinterpret_cast<const float4*>(w.lin2_b + c0 + 4 * j);
+                    float4 b2 = *reinterpret_cast<const float4*>(PS + 11 * FD + c0 + 4 * j);
                     float f[4] = {a0.x + a1.x + a2.x + a3.x + b2.x, a0.y + a1.y + a2.y + a3.y + b2.y,
                                   a0.z + a1.z + a2.z + a3.z + b2.z, a0.w + a1.w + a2.w + a3.w + b2.w};
                     if (w.res_thresh) {
@@ -953,7 +978,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         __syncthreads();
         {
             bool last = (l + 1 == p.n_layers);
-            ln_rows(X1, S, w.norm2_w, w.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            ln_rows_lds(X1, S, PS + 9 * FD, PS + 10 * FD, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 if (last && p.tokens_out && (TILED || row < p.out_T)) store32(p.tokens_out + (TILED ? tokbase + row : (size_t)clip * p.out_T + row) * FD + c0, y);
                 if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
             }, [&] { store_block(sv_res2, X1, S); });        // (the LayerNorm leaves X1 alone)
@@ -1040,7 +1065,7 @@ int timing_read(int which, double* total_ms, int* count) {
 
 size_t fused_lds_bytes(int NT) {
     int SP = NT * 16;
-    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16;
+    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16 + 12 * FD * sizeof(float);     // + the staged parameter rows
 }
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {

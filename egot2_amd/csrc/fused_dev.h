@@ -476,6 +476,43 @@ __device__ __forceinline__ void ln_rows(const float* buf, int S, const float* __
                                         float eps, Fn&& fn) {
     ln_rows(buf, S, w, b, eps, fn, [] {});
 }
+// The same with the weight and bias vectors staged in LDS (round 6). From global memory every 4-lane row group requests the same 2 x 512
+// bytes: 16 load instructions per thread, 64 KB per LayerNorm through the CU's one address path for 1 KB of parameters - 3 - 4k of a
+// phase's 11k cycles (stamps: profiles/r06_attn_stamps.txt); here they are ds_read broadcasts taken where they are used. `hook()` runs
+// first (the saves / prefetches the global variant issued behind its weight request).
+template <class Fn, class Hook>
+__device__ __forceinline__ void ln_rows_lds(const float* buf, int S, const float* wl, const float* bl, float eps, Fn&& fn, Hook&& hook) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int c0 = part * 32;
+    hook();
+    if (row < S) {
+        float x[32], y[32];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float4 v = *reinterpret_cast<const float4*>(buf + row * LDX + c0 + 4 * j);
+            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        float mean = quad_sum4(s) * (1.f / FD);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { float t = x[j] - mean; ss += t * t; }
+        float rstd = rsqrtf(quad_sum4(ss) * (1.f / FD) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 wq = *reinterpret_cast<const float4*>(wl + c0 + 4 * j), bq = *reinterpret_cast<const float4*>(bl + c0 + 4 * j);
+            y[4 * j + 0] = (x[4 * j + 0] - mean) * rstd * wq.x + bq.x;
+            y[4 * j + 1] = (x[4 * j + 1] - mean) * rstd * wq.y + bq.y;
+            y[4 * j + 2] = (x[4 * j + 2] - mean) * rstd * wq.z + bq.z;
+            y[4 * j + 3] = (x[4 * j + 3] - mean) * rstd * wq.w + bq.w;
+        }
+        fn(row, c0, x, y);
+    } else {
+        (void)quad_sum4(0.f);
+        (void)quad_sum4(0.f);
+    }
+}
 __device__ __forceinline__ void store32(float* dst, const float (&v)[32]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(dst + 4 * j) = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);

@@ -1,0 +1,31 @@
+"""Phase stamps of the attention-side forward launch of the cut mode (fused_fwd_kernel<..., CUT>; needs a -DEGX_STAMPS build, EGX_LIB=egot2_amd/_variants/lib_stamps.so):
+workgroup 0, thread 0, s_memtime cycles."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["EGX_FFN_CUT"] = "1"
+import torch
+from egot2_amd import hhi_ttm, _lib
+from egot2_amd.synth import hhi_args
+lib = _lib.load()
+dev = torch.device("cuda:0")
+m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.5)).to(dev).train()
+feats = [torch.randn(256, 15, 256, device=dev) for _ in range(3)]
+lib.egx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for comp in ("f32s", "bf16", "f32"):
+    m.set_compute(comp, "fused")
+    with torch.no_grad():
+        for _ in range(3):
+            m.forward_features(*feats)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.egx_debug_stamps(buf, 32)
+    b = list(buf)
+    order = [(0, "start"), (10, "segtab"), (1, "token-prep GEMM"), (2, "LN0+emb"), (3, "QKV"), (4, "attention"), (5, "out-proj"), (6, "LN1+stores")]
+    prev = b[0]
+    parts = []
+    for idx, name in order[1:]:
+        parts.append(f"{name}={b[idx] - prev}")
+        prev = b[idx]
+    print(comp, "fused_fwd<CUT> to LN1:", b[6] - b[0], " ".join(parts))
+    print("    cold start: kernel entry -> segtab barrier %d -> issue begins %d -> 28 loads issued %d -> LDS zero fill %d -> barrier %d" % (b[10] - b[0], b[12] - b[10], b[13] - b[12], b[14] - b[13], b[15] - b[14]))
+    print("    token prep (wave 0): setup(before first step)=%d first-fragment-wait=%d mfma+refill=%d" % (b[21], b[22], b[23]))
