@@ -149,9 +149,10 @@ __device__ __forceinline__ void block_to_split_planes(unsigned short* planes, co
 // split the older wave (w < 4) ran its 8 blocks of the f32s loop in 83k cycles and then waited 24k at the barrier for the younger
 // one (107k; stamps, profiles/r05_cut_stamps.txt). So the older wave takes nit / 8 blocks more, the younger as many fewer (9 : 7 at
 // d_ff = 2048) — a STATIC split: sums stay in a fixed order. bf16's short blocks are 12 % apart and keep the even split.
-template <int CM>
+// (round 6: the forward's split moved to 10 : 6 — three same-box pairs -2.5 us on the step; the backward's stays, 10 : 6 and 11 : 5 measured equal)
+template <int CM, bool FWD>
 __device__ __forceinline__ void cut_walk(int wave, int nit, int& j_begin, int& n_mine, int shift_code = 0) {
-    const int shift = shift_code ? shift_code - 1 : (CM == CM_BF16 ? 0 : nit / 8);
+    const int shift = shift_code ? shift_code - 1 : (CM == CM_BF16 ? 0 : (FWD ? nit / 4 : nit / 8));
     const int n_old = nit + shift;
     j_begin = wave < 4 ? 0 : n_old;
     n_mine = wave < 4 ? n_old : 2 * nit - n_old;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
     if (p.touch.n) tch = touch_lines<CT>(p.touch, blockIdx.x, gridDim.x, tid);
     const int nhb = p.d_ff / 32;
     int j_begin_, n_mine_;
-    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
+    cut_walk<CM, true>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
     const int nit = __builtin_amdgcn_readfirstlane(n_mine_), j_begin = __builtin_amdgcn_readfirstlane(j_begin_);
     const int pair_s = __builtin_amdgcn_readfirstlane(wave & 3);
     const int rot = cut_rot(p.rot_mode & 255, clip, nit);
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(CT) void ffn_bwd_kernel(FusedBwdParams p, int l) {
 
     const int nhb = p.d_ff / 32;
     int j_begin_, n_mine_;
-    cut_walk<CM>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
+    cut_walk<CM, false>(wave, nhb / 8, j_begin_, n_mine_, p.rot_mode >> 8);
     const int nit = __builtin_amdgcn_readfirstlane(n_mine_), j_begin = __builtin_amdgcn_readfirstlane(j_begin_);
     const int pair_s = __builtin_amdgcn_readfirstlane(wave & 3);
     const int rot = cut_rot(p.rot_mode & 255, clip, nit);

@@ -248,6 +248,20 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             }
         }
     }
+    // In-projection weights of a layer's first half (3 feature tiles per wave, K = 128) and its biases: requested one phase ahead of the
+    // Q | K | V GEMM (round 6: under the token preparation's LayerNorm for the first layer: the request + round trip was 5k of the phase's 24k cycles)
+    WRaw<CM> wa[3][FD / 32];
+    float4 bbn[3];
+    auto request_qkv = [&](const FusedLayer& wl, int half) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int kb = 0; kb < FD / 32; ++kb)
+                wa[i][kb] = load_w<CM>(wl.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
+            bbn[i] = *reinterpret_cast<const float4*>(wl.in_proj_b + (wave * 6 + half * 3 + i) * 16 + 4 * q);
+        }
+    };
+    bool qkv_requested = false;
     if ((!TILED || !skip_front) && !(CUT && p.l0 > 0)) {
     // ---- token preparation: proj GEMM (feature-major) -> LDS token-major -> LN + task embedding + position.
     // Steps = (segment, 16-row tile, 128-wide K chunk), two register sets. ROLLING REFILL as in the FFN loop: a fragment's
@@ -378,6 +392,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     }
     __syncthreads();
     touch_sink(tch);
+    if constexpr (CUT) { request_qkv(p.layer[l_begin], 0); qkv_requested = true; }      // (one layer per launch: nothing is carried around a layer loop)
     STAMP(1);
     // save pre-LN projections (token order) and apply the shared LN + embeddings. The task-embedding and positional rows of the
     // lane's token are requested unconditionally behind the LayerNorm weights (a missing table reads the LayerNorm weights and
@@ -436,6 +451,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             pl_v = *reinterpret_cast<const f32x4*>(src + ps_c);
         }
 
+        WRaw<CM> wo[2][FD / 32];        // out-projection weights, 2 feature tiles per wave
+        auto request_wo = [&] {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kb = 0; kb < FD / 32; ++kb)
+                    wo[i][kb] = load_w<CM>(w.out_proj_wp, wave * 2 + i, FD / 32, kb, lane);
+        };
+        const bool skip_front_wo = TILED && skip_front;
+        if (skip_front_wo) request_wo();
         if (!TILED || !skip_front) {
         STAMP(2);
         EGX_PHASE();
@@ -446,18 +471,8 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         float* qkv_g = p.qkv_out + ((size_t)l * p.B + clip) * SP * (3 * FD);       // all 48 rows of the clip grid: unconditional stores
         // ---- QKV projection: 24 feature tiles, 6 per wave, K = 128
         {
-            WRaw<CM> wa[3][FD / 32];
-            float4 bbn[3];
-            auto request = [&](int half) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                    for (int kb = 0; kb < FD / 32; ++kb)
-                        wa[i][kb] = load_w<CM>(w.in_proj_wp, wave * 6 + half * 3 + i, FD / 32, kb, lane);
-                    bbn[i] = *reinterpret_cast<const float4*>(w.in_proj_b + (wave * 6 + half * 3 + i) * 16 + 4 * q);
-                }
-            };
-            request(0);
+            auto request = [&](int half) { request_qkv(w, half); };
+            if (!(CUT && qkv_requested)) request(0);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 f32x4 acc[3][NT];
@@ -491,7 +506,9 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                     for (int t = 0; t < NT; ++t) {
                         int tok = t * 16 + r;
                         float4 o = make_float4(acc[i][t][0] + bb.x, acc[i][t][1] + bb.y, acc[i][t][2] + bb.z, acc[i][t][3] + bb.w);
+#ifndef EGX_DIAG_NOQKVSTORE
                         *reinterpret_cast<float4*>(qkv_g + (size_t)tok * (3 * FD) + f0) = o;
+#endif
                         if (f0 < FD) {
                             *reinterpret_cast<float4*>(Qs + tok * LDX + f0) = o;
                         } else if (f0 < 2 * FD) {
@@ -521,6 +538,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
 
         STAMP(3);
         EGX_PHASE();
+        if constexpr (CUT) request_wo();       // the out-projection's weights arrive under the attention (round 6)
         // ---- attention: wave = head. S^T = K Q^T (key rows, query columns), softmax over rows, O^T = V^T P^T
         if constexpr (!TILED) {
 #pragma unroll
@@ -625,12 +643,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-            WRaw<CM> wo[2][FD / 32];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int kb = 0; kb < FD / 32; ++kb)
-                    wo[i][kb] = load_w<CM>(w.out_proj_wp, wave * 2 + i, FD / 32, kb, lane);
+            if constexpr (!CUT) { if (!(TILED && skip_front_wo)) request_wo(); }
             __builtin_amdgcn_sched_barrier(0);
             pin_all(wo);
 #pragma unroll

@@ -15,6 +15,10 @@
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
+#ifdef EGX_STAMPS
+namespace egx { extern __device__ unsigned long long g_bstamps[32]; }
+#define LNB_STAMP(base, k) do { if ((base) >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); egx::g_bstamps[(base) + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#endif
 #include "fused_dev.h"
 
 namespace egx {
@@ -1187,6 +1191,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     float* B4 = lds + 4 * BLK;
     float* B5 = lds + 5 * BLK;
     float* stat = lds + 6 * BLK;     // [FH][3][SP] softmax max / 1/sum / delta per query
+    float* PSB = stat + NHEAD * 3 * SP;     // LayerNorm weight vectors staged in LDS (round 6, ln_bwd_rows_lds): row 0 ln_w, row 1 norm1_w of the current layer
 
     const int tid = threadIdx.x, wave = tid >> 6;
     int lane = tid & 63, r = lane & 15, q = lane >> 4;
@@ -1211,6 +1216,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     }
     if constexpr (SLICED) { if (clip >= p.B || ((p.slice_drop >> slice) & 1)) return; }        // (the grid is round_up(B, 8) * n_slices)
 
+    BSTAMP(12);
     float* part = p.partials + (size_t)clip * p.P;
     // hipcc hoists every lane-constant fragment address of every phase to kernel entry and then spills them around
     // the phases (1 KB of scratch per lane). Re-deriving the lane indices behind an opaque asm at each phase start
@@ -1262,8 +1268,12 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     if constexpr (!TILED) { if (p.touch.n) tch = touch_lines<256>(p.touch, blockIdx.x, gridDim.x, tid); }
     blk_request(pf_a, CUT ? p.dy1 + tok0 * FD : l_first >= 0 ? res_ptr(2 * l_first + 1) : p.saved_pre + tok0 * FD);
     blk_request(pf_b, l_first >= 0 ? res_ptr(2 * l_first) : p.saved_pre + tok0 * FD);
+    const int ps_g = tid >> 5, ps_c = (tid & 31) << 2;
+    const f32x4 ln0_v = *reinterpret_cast<const f32x4*>(p.ln_w + ps_c);
+    f32x4 n1_v = *reinterpret_cast<const f32x4*>(p.layer[l_first >= 0 ? l_first : 0].norm1_w + ps_c);
     static_assert((6 * BLK) % 4 == 0, "the blocks are zeroed in 16-byte pieces");
     for (int i = tid; i < 6 * BLK / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0, 0, 0, 0};
+    if (ps_g == 0) *reinterpret_cast<f32x4*>(PSB + ps_c) = ln0_v;
     __syncthreads();
     if constexpr (TILED) {
         if (p.l_front >= 0) {
@@ -1456,6 +1466,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         float* pl = part + l * FUSED_P_LAYER;
 
         BSTAMP(0);
+        if (l != l_first) n1_v = *reinterpret_cast<const f32x4*>(w.norm1_w + ps_c);     // (the first layer's was requested at kernel entry)
         // P1: res2 -> B1, res1 -> B5: requested during the previous layer's P11 / P12 (the last layer's before the LDS zero fill)
         if (!TILED && !CUT && l != p.n_layers - 1) {
             blk_store(pf_a, B1, nullptr);
@@ -1744,8 +1755,9 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         const f32x4* qsrc = reinterpret_cast<const f32x4*>(p.saved_qkv + ((size_t)l * p.B + clip) * SP * (3 * FD));   // (L, B, 48, 384)
         f32x4 qv[QKV_PF];
         // P5: LayerNorm1 backward with dy = dX1 (four wave partials in Gs, B2, B3, B4) + d_res2 (B1); x = res1 (B5, from P3).
+        if (ps_g == 0) *reinterpret_cast<f32x4*>(PSB + FD + ps_c) = n1_v;
         __syncthreads();
-        ln_bwd_rows(S, w.norm1_w, p.eps,
+        ln_bwd_rows_lds(S, PSB + FD, p.eps,
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
                 float t[32];
                 load32(Gs + row * LDX + c0, dy);
@@ -1781,7 +1793,8 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                     for (int k = 0; k < QKV_PF; ++k) qv[k] = qsrc[t_ + 256 * k];
                 }
-            });
+            }, 16);
+        BSTAMP(21);
         __syncthreads();
         store_block(w.g1_out + tok0 * FD, B2, S);
         BSTAMP(5);
@@ -2097,7 +2110,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         float* pg = part + p.n_layers * FUSED_P_LAYER;
         blk_store(pf_a, B1, nullptr);       // `pre`, requested before the last P11
         __syncthreads();
-        ln_bwd_rows(S, p.ln_w, p.eps,
+        ln_bwd_rows_lds(S, PSB, p.eps,
             [&](int row, int c0, float (&dy)[32], float (&x)[32]) {
                 load32(Gs + row * LDX + c0, dy);
                 if (p.pos_thresh) {
@@ -2110,20 +2123,33 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
             [&](int row, int c0, float (&dy)[32], float (&dx)[32], float (&dyx)[32]) {
                 store32(Gs + row * LDX + c0, dy);
                 store32(B3 + row * LDX + c0, dyx);
+                if (p.feat_thresh) {        // d(projection output) = d(LayerNorm input) .* feature-dropout mask (the forward's keying)
 #pragma unroll
-                for (int si = 0; si < FUSED_MAX_SEG; ++si)
-                    if (si < p.nseg && t0 + row >= p.seg[si].off && t0 + row < p.seg[si].off + p.seg[si].T) {
-                        const size_t frow = (size_t)c_real * p.seg[si].T + (t0 + row - p.seg[si].off);
-                        if (p.feat_thresh) {    // d(projection output) = d(LayerNorm input) .* feature-dropout mask (the forward's keying)
+                    for (int si = 0; si < FUSED_MAX_SEG; ++si)
+                        if (si < p.nseg && t0 + row >= p.seg[si].off && t0 + row < p.seg[si].off + p.seg[si].T) {
+                            const size_t frow = (size_t)c_real * p.seg[si].T + (t0 + row - p.seg[si].off);
                             const uint64_t fk = dev_seed ? site_key(seed_dev, (uint32_t)si, SITE_FEAT) : p.feat_key[si];
 #pragma unroll
                             for (int j = 0; j < 32; ++j) dx[j] *= drop_scale(fk, (uint32_t)frow, (uint32_t)(c0 + j), p.feat_thresh, p.feat_inv);
                         }
-                        store32(p.dseg_out[si] + frow * FD + c0, dx);
-                    }
-                store32(B1 + row * LDX + c0, dx);       // (masked) gradient of the projection output: proj_b partials below
-            });
+                }
+                store32(B1 + row * LDX + c0, dx);       // (masked) gradient of the projection output: proj_b partials and d(seg) rows below
+            }, [] {}, 22);
+        BSTAMP(27);
         __syncthreads();
+        // d(seg): the rows of every segment out of B1, 16 bytes per lane in lane order (round 6: stored from the LayerNorm lanes each store
+        // instruction touched 64 different 128-byte lines: 8.5k of this phase's 19k cycles, profiles/r06_attn_stamps.txt)
+#pragma unroll
+        for (int si = 0; si < FUSED_MAX_SEG; ++si)
+            if (si < p.nseg) {
+                int r0 = p.seg[si].off - t0, r1 = r0 + p.seg[si].T;        // the segment's rows within this tile
+                const int lo = max(r0, 0), hi = min(r1, S);
+                float* dst = p.dseg_out[si] + ((size_t)c_real * p.seg[si].T + (lo - r0)) * FD;
+                for (int i = tid; i < (hi - lo) * (FD / 4); i += 256) {
+                    const int row = lo + (i >> 5), c4 = i & 31;
+                    *reinterpret_cast<float4*>(dst + (size_t)i * 4) = *reinterpret_cast<const float4*>(B1 + row * LDX + c4 * 4);
+                }
+            }
         if (p.dx0_out) store_block(p.dx0_out + tok0 * FD, Gs, S);      // d(token-prep output) behind its dropout mask: learned-position gradient
         if (tid < 128) pg[tid] = colsum_lds(B3, 0, S, tid);
         else pg[128 + (tid - 128)] = colsum_lds(Gs, 0, S, tid - 128);
@@ -2149,7 +2175,7 @@ int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool determi
 
 template <int CM, bool TILED, int DH>
 static int launch_bwd(const FusedBwdParams& p, hipStream_t st) {
-    size_t lds = (size_t)(6 * 48 * LDX + (FH * FDH / DH) * 3 * 48) * sizeof(float);
+    size_t lds = (size_t)(6 * 48 * LDX + (FH * FDH / DH) * 3 * 48 + 2 * FD) * sizeof(float);        // + the staged LayerNorm weight rows
     static bool attr_set = false;
     if (!attr_set) {
         EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<CM, TILED, DH>),

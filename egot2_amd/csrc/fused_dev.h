@@ -557,17 +557,23 @@ __device__ __forceinline__ void load32(const float* src, float (&v)[32]) {
 // The lane's 32 weights are requested first and unconditionally; `after_w()` runs right behind that request, outside any branch:
 // global loads issued there (prefetches for a later phase) are YOUNGER than the weights, so the wait for the weights leaves
 // them in flight (a load issued before them, or under the row < S branch, would be waited for here).
+#ifndef LNB_STAMP
+#define LNB_STAMP(base, k) do { } while (0)
+#endif
 template <class Get, class Put, class Hook>
-__device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put, Hook&& after_w) {
+__device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put, Hook&& after_w, int stamp_base = -1) {
     const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int c0 = part * 32;
     f32x4 wq[8];
+    LNB_STAMP(stamp_base, 0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) wq[j] = *reinterpret_cast<const f32x4*>(w + c0 + 4 * j);
     after_w();
+    LNB_STAMP(stamp_base, 1);
     if (row < S) {
         float dy[32], x[32], dx[32];
         get(row, c0, dy, x);
+        LNB_STAMP(stamp_base, 2);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 32; ++j) s += x[j];
@@ -597,7 +603,9 @@ __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, 
             dx[i] = rstd * (dx[i] - s1 - x[i] * s2);
             x[i] *= dy[i];                    // dy * xhat
         }
+        LNB_STAMP(stamp_base, 3);
         put(row, c0, dy, dx, x);
+        LNB_STAMP(stamp_base, 4);
     } else {
         (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f);
     }
@@ -606,6 +614,55 @@ __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, 
 template <class Get, class Put>
 __device__ __forceinline__ void ln_bwd_rows(int S, const float* __restrict__ w, float eps, Get&& get, Put&& put) {
     ln_bwd_rows(S, w, eps, get, put, [] {});
+}
+// The same with the weight vector staged in LDS (round 6, see ln_rows_lds): `hook()` runs first.
+template <class Get, class Put, class Hook>
+__device__ __forceinline__ void ln_bwd_rows_lds(int S, const float* wl, float eps, Get&& get, Put&& put, Hook&& hook, int stamp_base = -1) {
+    const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int c0 = part * 32;
+    LNB_STAMP(stamp_base, 0);
+    hook();
+    LNB_STAMP(stamp_base, 1);
+    if (row < S) {
+        float dy[32], x[32], dx[32];
+        get(row, c0, dy, x);
+        LNB_STAMP(stamp_base, 2);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) s += x[j];
+        float mean = quad_sum4(s) * (1.f / FD);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { x[j] -= mean; ss += x[j] * x[j]; }
+        float rstd = rsqrtf(quad_sum4(ss) * (1.f / FD) + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(wl + c0 + 4 * j);
+            float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int i = 4 * j + e;
+                x[i] *= rstd;                 // xhat
+                float g = dy[i] * wj[e];
+                dx[i] = g;
+                s1 += g;
+                s2 += g * x[i];
+            }
+        }
+        s1 = quad_sum4(s1) * (1.f / FD);
+        s2 = quad_sum4(s2) * (1.f / FD);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            dx[i] = rstd * (dx[i] - s1 - x[i] * s2);
+            x[i] *= dy[i];                    // dy * xhat
+        }
+        LNB_STAMP(stamp_base, 3);
+        put(row, c0, dy, dx, x);
+        LNB_STAMP(stamp_base, 4);
+    } else {
+        (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f); (void)quad_sum4(0.f);
+    }
 }
 
 // Column sums of a token-major LDS block over rows [r0, r1): four independent accumulators so the LDS reads

@@ -29,3 +29,27 @@ for comp in ("f32s", "bf16", "f32"):
     print(comp, "fused_fwd<CUT> to LN1:", b[6] - b[0], " ".join(parts))
     print("    cold start: kernel entry -> segtab barrier %d -> issue begins %d -> 28 loads issued %d -> LDS zero fill %d -> barrier %d" % (b[10] - b[0], b[12] - b[10], b[13] - b[12], b[14] - b[13], b[15] - b[14]))
     print("    token prep (wave 0): setup(before first step)=%d first-fragment-wait=%d mfma+refill=%d" % (b[21], b[22], b[23]))
+
+# ---- attention-side backward launch of the cut mode (fused_bwd_kernel<..., CUT>)
+for comp in ("f32s", "bf16", "f32"):
+    m.set_compute(comp, "fused")
+    for _ in range(3):
+        for q_ in m.parameters():
+            q_.grad = None
+        m.forward_features(*feats).sum().backward()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.egx_debug_stamps(buf, -32)
+    b = list(buf)
+    order = [(12, "entry"), (4, "blocks in LDS"), (5, "LN1 bwd + g1 store"), (6, "colsums + out-proj dX"), (7, "QKV rows -> LDS"), (9, "attention bwd"),
+             (10, "colsums + in-proj dX"), (11, "token-prep bwd")]
+    prev = b[12]
+    parts = []
+    for idx, name in order[1:]:
+        parts.append(f"{name}={b[idx] - prev}")
+        prev = b[idx]
+    print(comp, "fused_bwd<CUT>:", b[11] - b[12], " ".join(parts))
+    print("    LN1 bwd (from phase start %d): request+hook %d | get %d | math %d | put %d | to barrier %d | barrier + g1 store %d" %
+          (b[16] - b[4], b[17] - b[16], b[18] - b[17], b[19] - b[18], b[20] - b[19], b[21] - b[20], b[5] - b[21]))
+    print("    LN0 bwd (from phase start %d): request+hook %d | get %d | math %d | put (incl. dseg stores) %d | to barrier %d | colsums %d" %
+          (b[22] - b[10], b[23] - b[22], b[24] - b[23], b[25] - b[24], b[26] - b[25], b[27] - b[26], b[11] - b[27]))
