@@ -508,6 +508,7 @@ def run(args) -> int:
                    "global_batch": B * world, "parallelism": f"dp{world}", "impl": args.impl, "workgroups_per_clip": F_egx.last_encoder_slices(),
                    "launch": "one hipGraph replay per step" if (use_graph and not (bucketed and not args.graph_collectives)) else "eager",
                    "deterministic": bool(args.deterministic),
+                   "compute_is_module_default": bool(dtype == getattr(type(model), "egx_compute", None)),
                    "weights_packed": ("once, outside the timed loop (forward + backward only: the weights do not change between steps; "
                                       "with_optimizer re-packs every step)" if (wcache_on and not args.optimizer) else "every step"),
                    "loss": ("weighted CE in the forward's head epilogue (egx_ce)" if (wl["name"] in ("c1", "c2") and not args.no_fused_ce)
@@ -573,6 +574,10 @@ def run(args) -> int:
     if rank == 0 and not args.no_roofline:
         model.egx_defer_small = False
         out["roofline"] = measure_roofline(torch, lib, fwd_bwd, wl, dtype)
+        # `frac` is the dominant LAUNCH's fraction; `step_frac` the whole step's (all algorithmic FLOPs of forward + backward over the step time):
+        # the number that moves only when the step does (cutting a kernel in two raises `frac` without a faster step)
+        out["roofline"]["step_frac"] = out["step_frac_of_mfma_peak"]
+        out["roofline"]["step_tflops"] = out["step_tflops"]
         if wl.get("producer"):
             out["producer"] = wl["producer"]
     if rank == 0 and not args.no_cpu_baseline and world == 1 and wl["name"] in ("c1", "c2"):

@@ -89,6 +89,7 @@ SIGNATURES = {
     "egx_abi_version": (C.c_int, []),
     "egx_last_error": (C.c_char_p, []),
     "egx_launch_count": (C.c_longlong, [C.c_int]),
+    "egx_tuning_reload": (None, []),
     "egx_weight_cache_bytes": (C.c_size_t, [C.POINTER(Config), C.POINTER(Segment)]),
     "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -204,10 +204,25 @@ static size_t fused_core_bytes(const egx_config* cfg, const egx_segment* segs, c
 // 25 % from the second wave per SIMD) with one layer per launch pair and the reference's d_ff; bf16's short loops and deeper / narrower
 // stacks pay more for the two extra launches per layer than the loops gain. EGX_FFN_CUT=1 forces it wherever it is supported (the
 // parity tests run every mode through it), =0 keeps the one-launch kernels.
+// Kernel-selection switches of the per-clip path (development / test aids): EGX_FFN_CUT = 0 | 1, EGX_FFN_SLICES = 1 | 2 | 4 | 8,
+// EGX_SLICE_DROP = <hex mask>. The product library reads the environment ONCE, at first use (round 6; rounds 4-5 called getenv in every
+// forward and backward); egx_tuning_reload() re-reads it — the parity tests, which compare the modes inside one process, call it after
+// changing os.environ (egot2_amd/functional.py reload_tuning_each_call). No workspace layout depends on any of them.
+struct Tuning { int ffn_cut = -1; int slices_cap = 0; bool has_slices = false; long slice_drop = 0; bool has_drop = false; };
+static Tuning g_tuning;
+static bool g_tuning_loaded = false;
+static void tuning_load() {
+    Tuning t;
+    if (const char* e = getenv("EGX_FFN_CUT")) t.ffn_cut = e[0] != '0' ? 1 : 0;
+    if (const char* e = getenv("EGX_FFN_SLICES")) { t.has_slices = true; t.slices_cap = atoi(e); }
+    if (const char* e = getenv("EGX_SLICE_DROP")) { t.has_drop = true; t.slice_drop = strtol(e, nullptr, 16); }
+    g_tuning = t;
+    g_tuning_loaded = true;
+}
+static const Tuning& tuning() { if (!g_tuning_loaded) tuning_load(); return g_tuning; }
 static bool use_cut(const Plan& pl, int n_slices, bool tiled, int compute) {
     if (tiled || n_slices != 1 || !ffn_cut_supported(pl.dff)) return false;
-    const char* e = getenv("EGX_FFN_CUT");      // (read per call: the tests compare both modes in one process; no layout depends on it)
-    if (e) return e[0] != '0';
+    if (tuning().ffn_cut >= 0) return tuning().ffn_cut != 0;
     return compute == EGX_F32_SPLIT && pl.L == 1 && pl.dff >= 1024;
 }
 static int fused_slices(const Plan& pl, int compute);
@@ -239,9 +254,8 @@ static int device_cus() {
 }
 // EGX_SLICE_DROP=<hex mask> (testing aid): the workgroups of those slices leave at once; the others must compute their share
 static int slice_drop_mask(int n) {
-    const char* e = getenv("EGX_SLICE_DROP");
-    if (!e) return 0;
-    const int m = (int)strtol(e, nullptr, 16) & ((1 << n) - 1);
+    if (!tuning().has_drop) return 0;
+    const int m = (int)tuning().slice_drop & ((1 << n) - 1);
     return m == (1 << n) - 1 ? 0 : m;      // at least one slice has to run
 }
 // The exchange is built on gfx942 / gfx950 behaviour (write-through relaxed agent-scope atomics, s_waitcnt ordering; fused_dev.h): any other
@@ -256,7 +270,8 @@ static bool device_slicing_ok() {
     }
     return ok[dev] == 1;
 }
-constexpr int SLICE_LAYOUT_CUS = 512;       // no supported device has more compute units: bounds the slice count the layout provides for
+constexpr int SLICE_LAYOUT_CUS = 304;       // the largest compute-unit count of the supported parts (gfx942: 304, gfx950: 256) bounds the slice count the layout
+                                            // provides for (512 reserved a two-slice exchange buffer, 12.6 MB per layer, for the B = 256 headline batch)
 static int fused_slices_layout(const Plan& pl) {
     const int nit = pl.dff / 128, bq = (pl.B + 7) / 8 * 8;
     int n = 1;
@@ -265,9 +280,9 @@ static int fused_slices_layout(const Plan& pl) {
 }
 static int fused_slices(const Plan& pl, int compute) {
     if (!device_slicing_ok()) return 1;
-    const char* e = getenv("EGX_FFN_SLICES");      // (read per call: the tests compare both modes in one process; the LAYOUT does not depend on it)
+    const bool e = tuning().has_slices;            // (EGX_FFN_SLICES; the LAYOUT does not depend on it)
     // measured at B = 32 (profiles/r04_sliced.txt): the exchange costs ~10 us per kernel; with bf16's short FFN loop eight slices lose to four
-    int cap = e ? atoi(e) : (compute == EGX_BF16 ? 4 : 8);
+    int cap = e ? tuning().slices_cap : (compute == EGX_BF16 ? 4 : 8);
     if (cap < 1) cap = 1;
     const int cus = device_cus(), nit = pl.dff / 128, bq = (pl.B + 7) / 8 * 8;
     int n = 1;
@@ -452,6 +467,7 @@ using namespace egx;
 extern "C" {
 
 int egx_abi_version(void) { return EGX_ABI_VERSION; }
+void egx_tuning_reload(void) { tuning_load(); }
 long long egx_launch_count(int reset) { long long n = g_launches; if (reset) g_launches = 0; return n; }
 int egx_debug_stamps(unsigned long long* out, int n) { return n == -1000 ? debug_read_ppstamps(out) : n == -3000 ? debug_read_cstamps(out) : n == -4000 ? debug_read_sstamps(out) : (n < 0 ? debug_read_bstamps(out, -n) : debug_read_stamps(out, n)); }
 long long egx_slices_stolen(int reset) {

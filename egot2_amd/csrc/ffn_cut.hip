@@ -301,8 +301,9 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
                     const int row = rem >> 4, c8 = rem & 15;
                     if (i < NPIECE) {
                         unsigned short* d = XP + part * CPS + row * LDXH + c8 * 8;
-                        *reinterpret_cast<uint2*>(d) = make_uint2(pv[k][0], pv[k][1]);
-                        *reinterpret_cast<uint2*>(d + 4) = make_uint2(pv[k][2], pv[k][3]);
+                        const bool live = row < S;      // rows >= S: zero operands whatever the producer left there (the bf16 plane is written for rows < S only)
+                        *reinterpret_cast<uint2*>(d) = live ? make_uint2(pv[k][0], pv[k][1]) : make_uint2(0, 0);
+                        *reinterpret_cast<uint2*>(d + 4) = live ? make_uint2(pv[k][2], pv[k][3]) : make_uint2(0, 0);
                     }
                 }
             }

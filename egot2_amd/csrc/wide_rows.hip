@@ -240,13 +240,16 @@ int wide_row_reduce_flush(WideRowReduceBatch& b, hipStream_t st) {
     b.n = 0; b.total_blocks = 0;
     return 0;
 }
-static int row_reduce_queue(WideRowReduceBatch& b, const WideRowReduceDesc& in, hipStream_t st) {
-    if (b.n == WIDE_ROWRED_MAX && wide_row_reduce_flush(b, st)) return 1;      // (what is queued has been produced on this stream already)
+// false: the batch is full — the caller then runs this reduction at once, on the stream that produced its partials. (rounds 4-5 flushed the
+// whole batch on the ADDING call's stream; the decoder backward queues from two streams, so a flush triggered from one could read partials the other had
+// not written yet — reachable from 7 decoder layers on. A queued entry is only ever summed by the flush at the end, behind the join of both streams.)
+static bool row_reduce_queue(WideRowReduceBatch& b, const WideRowReduceDesc& in) {
+    if (b.n == WIDE_ROWRED_MAX) return false;
     WideRowReduceDesc& q = b.d[b.n++];
     q = in;
     q.first_block = b.total_blocks;
     b.total_blocks += cdiv(q.cols, 64);
-    return 0;
+    return true;
 }
 
 static int ln_bwd_blocks(int rows) {
@@ -270,7 +273,7 @@ int wide_ln_bwd(WideLnBwdParams p, void* scratch, hipStream_t st, WideRowReduceB
         WideRowReduceDesc q;
         q.part = p.partials; q.o0 = p.dw; q.o1 = p.db; q.o2 = p.dbias; q.o3 = p.dadd; q.nt = p.blocks; q.cols = 3 * p.d; q.d = p.d; q.kind = 1;
         q.first_block = 0; q.out_ld = 0; q.row_len = 1; q.pad_ = 0;
-        return row_reduce_queue(*defer, q, st);
+        if (row_reduce_queue(*defer, q)) return 0;
     }
     if (p.dw || p.db || p.dbias || p.dadd)
         hipLaunchKernelGGL(wide_ln_bwd_reduce_kernel, dim3(cdiv(3 * p.d, 64)), dim3(1024), 0, st, (const float*)p.partials, p.blocks,
@@ -318,7 +321,7 @@ int wide_reduce_rows(const float* part, int nt, int cols, float* out, hipStream_
         WideRowReduceDesc q;
         q.part = part; q.o0 = out; q.o1 = q.o2 = q.o3 = nullptr; q.nt = nt; q.cols = cols; q.d = cols; q.kind = 0;
         q.first_block = 0; q.out_ld = cols; q.row_len = cols; q.pad_ = 0;
-        return row_reduce_queue(*defer, q, st);
+        if (row_reduce_queue(*defer, q)) return 0;
     }
     hipLaunchKernelGGL(wide_reduce_rows_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, st, part, nt, cols, out, cols, cols);
     EGX_LAUNCH_CHECK();

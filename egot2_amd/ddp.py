@@ -238,6 +238,7 @@ class EgxComm:
         h = C.c_void_p()
         _lib.check(self._lib.egx_comm_create(C.c_char_p(idb), self.rank, self.world, C.byref(h)))
         self._h = h
+        self.device = torch.cuda.current_device()       # the communicator is bound to the device that was current here
 
     @property
     def size(self) -> int:
@@ -247,8 +248,12 @@ class EgxComm:
         from . import _lib
         if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
             raise _lib.EgxError("EgxComm.allreduce_: contiguous fp32 / bf16 CUDA tensor expected")
+        if t.device.index != self.device:
+            raise _lib.EgxError(f"EgxComm.allreduce_: tensor on cuda:{t.device.index}, communicator created on cuda:{self.device}")
+        if self._h is None:
+            raise _lib.EgxError("EgxComm.allreduce_: communicator is closed")
         _lib.check(self._lib.egx_allreduce(self._h, t.data_ptr(), t.numel(), int(t.dtype == torch.bfloat16), int(average),
-                                           torch.cuda.current_stream().cuda_stream))
+                                           torch.cuda.current_stream(t.device).cuda_stream))
         return t
 
     @torch.no_grad()
@@ -273,8 +278,17 @@ class EgxComm:
             self._lib.egx_comm_destroy(self._h)
             self._h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():      # interpreter shutdown: RCCL / HIP may already be torn down, leave the communicator to the process exit
+            return
         try:
             self.close()
-        except Exception:       # noqa: BLE001  (interpreter shutdown)
+        except Exception:       # noqa: BLE001
             pass

@@ -92,6 +92,10 @@ class EncoderSpec:
                       int(bool(self.deterministic)), int(self.out_tokens))
 
 
+# The library reads its kernel-selection switches (EGX_FFN_CUT, EGX_FFN_SLICES, EGX_SLICE_DROP) from the environment once. Tests and tuning
+# tools that flip them inside one process set this (tests/conftest.py): every forward / backward then asks the library to re-read them first.
+reload_tuning_each_call = False
+
 _scratch_cache = {}
 _last_impl = [EGX_IMPL_AUTO]
 _last_slices = [1]
@@ -242,6 +246,8 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec: EncoderSpec, task_embed, pos_table, ln_w, ln_b, *rest):
         lib = _lib.load()
+        if reload_tuning_each_call:
+            lib.egx_tuning_reload()
         nseg = len(spec.segments)
         feats = [_dev_feat(t, f"feats[{i}]") for i, t in enumerate(rest[:nseg])]
         nproj = sum(1 for s in spec.segments if s.has_proj)
@@ -422,6 +428,8 @@ class EncoderFn(torch.autograd.Function):
             full[:, :ctx.py_slice] = d_tokens
             d_tokens = full
         lib = _lib.load()
+        if reload_tuning_each_call:
+            lib.egx_tuning_reload()
         spec: EncoderSpec = ctx.spec
         sv = list(ctx.saved_tensors)
         task_embed = sv.pop(0) if ctx.has_te else None
@@ -680,6 +688,49 @@ class LinearFn(torch.autograd.Function):
         check(lib.egx_linear_bwd(ptr(dy), ptr(x), ptr(W), ptr(dx), ptr(dW), ptr(db), M, N, K, COMPUTE[ctx.compute],
                                  ptr(scratch), _stream()))
         return dx, dW, db, None, None
+
+
+class StackedLinearFn(torch.autograd.Function):
+    """y = x Wst^T + bst where Wst / bst are the row-wise stack of several nn.Linear parameters that LIVE in that stack (their `.data` are views
+    of it: hoi_lta.MultiTaskHead). One GEMM forward, one backward; the weight / bias gradients come back as views of ONE stacked gradient
+    buffer each — no torch.cat of twenty weight matrices per step, no split of the gradient.
+    Arguments: x (M, K), Wst (N, K), bst (N), sizes, compute, then the member weights and the member biases (gradient routing only)."""
+
+    @staticmethod
+    def forward(ctx, x, Wst, bst, sizes, compute: str, *members):
+        lib = _lib.load()
+        x = _dev_f32(x, "x")
+        M, K = x.shape
+        N = Wst.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        check(lib.egx_linear_fwd(ptr(x), ptr(Wst), ptr(bst), ptr(y), M, N, K, 0, COMPUTE[compute], _stream()))
+        ctx.compute, ctx.sizes, ctx.nm = compute, tuple(sizes), len(members) // 2
+        ctx.save_for_backward(x, Wst)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, Wst = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        M, K = x.shape
+        N = Wst.shape[0]
+        need = ctx.needs_input_grad
+        dev = dy.device
+        dx = torch.empty_like(x) if need[0] else None
+        want_w = any(need[5:5 + ctx.nm])
+        want_b = any(need[5 + ctx.nm:])
+        dW = torch.zeros_like(Wst) if want_w else None
+        db = torch.zeros(N, dtype=torch.float32, device=dev) if want_b else None
+        scratch = _workspace("linear", dev, lib.egx_linear_bwd_scratch(M, N, K))
+        check(lib.egx_linear_bwd(ptr(dy), ptr(x), ptr(Wst), ptr(dx), ptr(dW), ptr(db), M, N, K, COMPUTE[ctx.compute],
+                                 ptr(scratch), _stream()))
+        gw, gb, off = [], [], 0
+        for i, n in enumerate(ctx.sizes):
+            gw.append(dW[off:off + n] if (dW is not None and need[5 + i]) else None)
+            gb.append(db[off:off + n] if (db is not None and need[5 + ctx.nm + i]) else None)
+            off += n
+        return (dx, None, None, None, None, *gw, *gb)
 
 
 def linear(x, W, b=None, compute: str = "f32", relu: bool = False):

@@ -46,16 +46,52 @@ class MultiTaskHead(nn.Module):
             raise NotImplementedError("{} is not supported as an activation" "function.".format(act_func))
         self.egx_compute = "f32"
 
+    def _stacked(self):
+        """(Wst, bst): the projections' weights / biases as ONE row-wise stack that is their storage. Checked on every call (twenty pointer
+        compares); when the parameters do not lie behind one another in one storage (fresh module, module.to(), load_state_dict(assign=True))
+        the values are copied into a new stack and every `p.data` becomes a view of it — Parameter objects, state_dict keys and shapes stay what
+        they were. FusedAdam's flat buffer, which lays the parameters out like their gradients, is such a storage and is used as it is."""
+        ws, bs = [p.weight for p in self.projections], [p.bias for p in self.projections]
+
+        def stacked_in_place(ts):       # the tensors already lie row-wise behind one another in one storage (this module's stack, or FusedAdam's flat buffer)
+            off = 0
+            for t in ts:
+                if not t.is_contiguous() or t.data_ptr() != ts[0].data_ptr() + 4 * off or t.untyped_storage().data_ptr() != ts[0].untyped_storage().data_ptr():
+                    return None
+                off += t.numel()
+            shape = (sum(t.shape[0] for t in ts),) + tuple(ts[0].shape[1:])
+            return torch.empty(0, dtype=ts[0].dtype, device=ts[0].device).set_(ts[0].untyped_storage(), ts[0].storage_offset(), shape)
+        with torch.no_grad():
+            Wst, bst = stacked_in_place([w.data for w in ws]), stacked_in_place([b.data for b in bs])
+        if Wst is not None and bst is not None:
+            return Wst, bst
+        with torch.no_grad():
+            Wst = torch.cat([w.detach() for w in ws], dim=0).contiguous()
+            bst = torch.cat([b.detach() for b in bs], dim=0).contiguous()
+            off = 0
+            for w, b in zip(ws, bs):
+                n = w.shape[0]
+                w.data = Wst[off:off + n]
+                b.data = bst[off:off + n]
+                off += n
+        return Wst, bst
+
     def forward(self, feat):
         """feat: (B, d) -> list of (B, n_classes)."""
         if hasattr(self, "dropout"):
             feat = self.dropout(feat)
-        # ONE GEMM for all Z future-action heads: the 20 (593, d) projections are stacked row-wise (autograd splits the
-        # gradient back), instead of 20 launches of a 256-row problem each
+        # ONE GEMM for all Z future-action heads: the 20 (593, d) projections LIVE row-wise stacked in one buffer (their `.data` are views of
+        # it, _stacked()), so there is no torch.cat of twenty matrices per step and no split of the gradient (round 6, VERDICT r5 item 7d)
         sizes = [p.out_features for p in self.projections]
-        W = torch.cat([p.weight for p in self.projections], dim=0)
-        b = torch.cat([p.bias for p in self.projections], dim=0)
-        x = list(F_egx.linear(feat, W, b, self.egx_compute).split(sizes, dim=-1))
+        if feat.is_cuda and len(self.projections) > 1:
+            W, b = self._stacked()
+            y = F_egx.StackedLinearFn.apply(feat.reshape(-1, feat.shape[-1]), W, b, sizes, self.egx_compute,
+                                            *[p.weight for p in self.projections], *[p.bias for p in self.projections])
+            x = list(y.view(*feat.shape[:-1], W.shape[0]).split(sizes, dim=-1))
+        else:
+            W = torch.cat([p.weight for p in self.projections], dim=0)
+            b = torch.cat([p.bias for p in self.projections], dim=0)
+            x = list(F_egx.linear(feat, W, b, self.egx_compute).split(sizes, dim=-1))
         if not self.training and not self.test_noact:
             x = [self.act(x_i) for x_i in x]
         return x

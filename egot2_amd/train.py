@@ -90,6 +90,10 @@ class FusedAdam(torch.optim.Optimizer):
         if self._step_dev is not None:
             self._step_dev.fill_(step)
         for b in self._buckets.values():
+            for p, off in b.members:        # a parameter WITHOUT loaded state starts from zero moments again (a state_dict taken before the first step)
+                if p not in self.state:
+                    b.exp_avg[off:off + p.numel()].zero_()
+                    b.exp_avg_sq[off:off + p.numel()].zero_()
             self._adopt_state(b)
 
     @torch.no_grad()
@@ -158,17 +162,50 @@ class GraphedStep:
         self.static = self._clone_tree(example_inputs)
         self._one = None
         dev = self.params[0].device
+        # The warm-up runs REAL steps on `example_inputs` (allocator, lazy initialisation, FusedAdam re-pointing the parameters into its flat
+        # buffers: all of that has to happen before the capture). With an optimizer they would leave `warmup` updates from the example batch
+        # behind: parameters, optimizer moments / step count and the device-resident dropout seeds are snapshotted here and
+        # restored afterwards, so the first replay starts exactly where the caller's model and optimizer were.
+        snap_p = [p.detach().clone() for p in self.params]
+        snap_o = None
+        if optimizer is not None:
+            import copy
+            snap_o = copy.deepcopy(optimizer.state_dict())
+        seeds = [m._egx_seed_dev for m in self._seed_owners(loss_fn)]
+        snap_s = [t.clone() for t in seeds]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):        # allocator, lazy initialisation, FusedAdam's flat buffers: all before the capture
+            for _ in range(max(warmup, 1)):
                 self._step()
+            with torch.no_grad():
+                for p, v in zip(self.params, snap_p):
+                    p.copy_(v)
+                for t, v in zip(seeds, snap_s):
+                    t.copy_(v)
+            if optimizer is not None:
+                optimizer.load_state_dict(snap_o)
+            F_egx.note_weights_changed()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._step()
         torch.cuda.synchronize(dev)
+
+    @staticmethod
+    def _seed_owners(loss_fn):
+        """Modules with a device-resident dropout seed that `loss_fn` closes over (model.enable_device_seed())."""
+        found = []
+        cells = getattr(loss_fn, "__closure__", None) or ()
+        objs = [c.cell_contents for c in cells if c is not None]
+        objs += [getattr(loss_fn, "__self__", None)]
+        for o in objs:
+            mods = o.modules() if isinstance(o, nn.Module) else ()
+            for m in mods:
+                if isinstance(getattr(m, "_egx_seed_dev", None), torch.Tensor) and all(m is not f for f in found):
+                    found.append(m)
+        return found
 
     def _clone_tree(self, t):
         if isinstance(t, torch.Tensor):

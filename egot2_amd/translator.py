@@ -55,7 +55,11 @@ class TranslatorMixin:
     """Adds the HIP encoder call to an nn.Module. `egx_compute` in {"f32", "bf16", "f32s"}; `egx_impl` in
     {"auto", "generic", "fused"}."""
 
-    egx_compute: str = "f32"
+    # default arithmetic (round 6): "f32s" = fp32 operands split exactly into three bf16 parts, six bf16 MFMAs per K-block, fp32 accumulation —
+    # fp32-grade results (2e-6 on the logits against fp64, tests/test_gpu_translator.py::test_split_bf16_mode_is_fp32_grade) at 2.7x the matrix
+    # rate of the exact fp32 MFMA; implemented by the per-clip d = 128 kernels, everywhere else it computes as "f32". set_compute("f32") is the
+    # exact v_mfma_f32_16x16x4_f32 path, "bf16" the BASELINE.json configs[2..4] arithmetic.
+    egx_compute: str = "f32s"
     egx_impl: str = "auto"
     egx_defer_small: bool = False      # staged backward for the all-reduce overlap (ddp.allreduce_gradients_overlapped)
     egx_deterministic: bool = False    # fixed-order reductions in the backward (egx_config.deterministic)

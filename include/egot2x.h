@@ -197,6 +197,9 @@ typedef struct egx_ce {
 } egx_ce;
 
 int egx_abi_version(void);
+/* The kernel-selection switches EGX_FFN_CUT / EGX_FFN_SLICES / EGX_SLICE_DROP (development and test aids) are read from the environment once,
+ * at first use; this re-reads them (the parity tests compare the modes inside one process). */
+void egx_tuning_reload(void);
 /* Bytes of egx_config.weight_cache for this configuration (0: this configuration does not run on kernels that pack weights). Depends on
  * the model dimensions and the compute mode, not on the batch. */
 size_t egx_weight_cache_bytes(const egx_config* cfg, const egx_segment* segs);

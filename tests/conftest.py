@@ -14,6 +14,9 @@ if ROOT not in sys.path:
 
 
 def pytest_configure(config):
+    # the parity tests flip EGX_FFN_CUT / EGX_FFN_SLICES / EGX_SLICE_DROP inside one process: the library (which reads them once) re-reads them per call
+    from egot2_amd import functional as _F
+    _F.reload_tuning_each_call = True
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (this container only)")
 

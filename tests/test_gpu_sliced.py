@@ -80,6 +80,7 @@ def test_slice_count_policy(egx_lib, cuda):
         segs[i].T, segs[i].d_in, segs[i].proj_w = 15, 256, 1
     def n(B, compute, d_ff=2048):
         cfg = Config(128, 4, d_ff, 1, 3, 1e-5, compute, 0, 0.0, 0.0, 0.0)
+        egx_lib.egx_tuning_reload()         # (direct C call: the library reads EGX_FFN_SLICES once and on request)
         return egx_lib.egx_encoder_slices(C.byref(cfg), segs, B)
     f32s = _lib.EGX_F32_SPLIT
     want = lambda B, cap: max(k for k in (1, 2, 4, 8) if k <= cap and (B + 7) // 8 * 8 * k <= cus)  # noqa: E731

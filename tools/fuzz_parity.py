@@ -20,6 +20,7 @@ import torch
 from oracle import translator_ref as tr
 from tests import dropmask as dm
 from tests.util import hhi_args, rel_err, seeded_feats, seeded_state_dict
+import egot2_amd.functional as _F_tuning; _F_tuning.reload_tuning_each_call = True   # the kernel-selection switches are flipped inside this process
 
 class ReluSpy:
     """Smallest |ReLU pre-activation| / rms the oracle's forward sees. A hidden unit whose pre-activation is within fp32 rounding of zero

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["EGX_FFN_CUT"] = "1"
 import torch
 from egot2_amd import hhi_ttm, _lib
+import egot2_amd.functional as _F_tuning; _F_tuning.reload_tuning_each_call = True   # the switches below are flipped inside this process
 from egot2_amd.synth import hhi_args
 lib = _lib.load()
 dev = torch.device("cuda:0")
