@@ -243,6 +243,17 @@ def run(args) -> int:
     if args.deterministic:
         model.set_deterministic(True)
     ddp.broadcast_parameters(model)
+    egx_comm = None
+    if args.graph_collectives and multi:
+        # Captured collectives run on the C ABI's own RCCL communicator (egx_allreduce on streams this process owns): no ProcessGroupNCCL work
+        # objects and no watchdog thread inside or beside the capture (round 5: hipErrorCapturedEvent once in six runs). The 128-byte id travels
+        # over the torch process group that launched the ranks.
+        def _bcast(idb):
+            box = [idb]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        egx_comm = ddp.EgxComm(rank, world, bcast=_bcast if world > 1 else None)
+        ddp.use_egx_comm(egx_comm)
     one = F_egx.unit_grad(dev)
     loss_fn = wl["loss_fn"]
 
@@ -470,6 +481,9 @@ def run(args) -> int:
     # the exchange on its own (same buffers, same stream order), for the `allreduce_us` field
     allreduce_us = None
     if multi:
+        if not any(p.grad is not None for p in params):     # (a captured step leaves .grad as the capture left it; make sure there is something to exchange)
+            fwd_bwd()
+            F_egx.run_deferred()
         sync()
         t0 = time.perf_counter()
         for _ in range(20):
@@ -521,9 +535,13 @@ def run(args) -> int:
         # what took part: the rank count as a REAL collective sees it (sum of ones over the group), its backend, and how much of the
         # exchange the step actually pays for: the same step timed without any collective (same launches, same graph policy)
         t = torch.ones(1, device=dev, dtype=torch.float32)
-        dist.all_reduce(t)
+        if egx_comm is not None:
+            egx_comm.allreduce_(t, average=False)
+            out["collective_backend"] = "egx_allreduce (RCCL through the C ABI: " + (lib.egx_comm_library() or b"?").decode() + ")"
+        else:
+            dist.all_reduce(t)
+            out["collective_backend"] = dist.get_backend()
         out["rccl_ranks"] = int(round(t.item()))
-        out["collective_backend"] = dist.get_backend()
         model.egx_defer_small = False
         gr0 = capture(fwd_bwd) if use_graph else None
         step_noex = gr0.replay if gr0 is not None else fwd_bwd
@@ -593,6 +611,9 @@ def run(args) -> int:
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+    if egx_comm is not None:
+        ddp.use_egx_comm(None)
+        egx_comm.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,6 +15,64 @@ import torch
 import torch.distributed as dist
 
 
+# ---- which collective runs the exchanges ------------------------------------------------------------------------------------------------
+# Default: torch.distributed (the process group Lightning's DDP would hand over; backend "nccl" = RCCL). use_egx_comm(EgxComm) routes EVERY
+# exchange of this module through egx_allreduce instead: plain RCCL calls on torch streams this module owns, no ProcessGroupNCCL work
+# objects and no watchdog thread. That is what a step captured into a hipGraph needs (round 6, VERDICT r5 item 5: PyTorch's watchdog
+# queried an event of the capturing stream and aborted one profile run in six with hipErrorCapturedEvent; a retry hid it).
+_comm = None
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def use_egx_comm(comm) -> None:
+    """comm: an EgxComm (or None to return to torch.distributed). Every rank must make the same choice."""
+    global _comm
+    _comm = comm
+
+
+def _world(group=None) -> int:
+    if _comm is not None:
+        return _comm.world
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _active(group=None, force: bool = False) -> bool:
+    if _comm is not None:
+        return _comm.world > 1 or force
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+
+
+class _SideWork:
+    """Handle of a collective issued on this module's side stream: wait() makes the current stream wait for it (an event, no host sync;
+    under capture: the join of a parallel branch of the graph)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def wait(self):
+        torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+
+
+def _all_reduce(buf: torch.Tensor, average: bool, group=None, async_op: bool = False):
+    """In-place all-reduce of `buf`; returns (work | None, averaged_by_the_collective)."""
+    if _comm is not None:
+        if not async_op:
+            _comm.allreduce_(buf, average)
+            return None, True
+        dev = buf.device.index
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(device=buf.device)
+        side.wait_stream(torch.cuda.current_stream(buf.device))      # behind the kernels that completed `buf`
+        with torch.cuda.stream(side):
+            _comm.allreduce_(buf, average)
+        return _SideWork(side), True
+    fused_avg = average and dist.get_backend(group) == "nccl"       # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the explicit scale
+    op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
+    work = dist.all_reduce(buf, op=op, group=group, async_op=async_op)
+    return (work if async_op else None), fused_avg
+
+
 def shard_batch(tensors: Iterable[torch.Tensor], rank: int, world: int) -> List[torch.Tensor]:
     """Rank r takes clips [r*B/n, (r+1)*B/n) of every feature tensor (DistributedSampler equivalent,
     HOI/tasks/multitask/video_task.py:631)."""
@@ -53,25 +111,20 @@ def _flat_groups(params: Iterable[torch.nn.Parameter]):
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = True, force: bool = False) -> int:
     """All-reduce every .grad in place; returns the number of collectives issued. `force` issues the collectives even in
     a one-rank group (used to exercise the RCCL path on a single GPU)."""
-    if not dist.is_available() or not dist.is_initialized():
+    if not _active(group, force):
         return 0
-    world = dist.get_world_size(group)
-    if world == 1 and not force:
-        return 0
+    world = _world(group)
     params = [p for p in params if p.grad is not None]
     flats, loose = _flat_groups(params)
     n = 0
-    # RCCL averages inside the collective (ncclAvg); gloo (CPU tests) needs the explicit scale
-    fused_avg = average and dist.get_backend(group) == "nccl"
-    op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
     for buf in flats:
-        dist.all_reduce(buf, op=op, group=group)
+        _, fused_avg = _all_reduce(buf, average, group)
         if average and not fused_avg:
             buf.mul_(1.0 / world)
         n += 1
     if loose:
         flat = torch.cat([g.reshape(-1) for g in loose])
-        dist.all_reduce(flat, op=op, group=group)
+        _, fused_avg = _all_reduce(flat, average, group)
         if average and not fused_avg:
             flat.mul_(1.0 / world)
         off = 0
@@ -107,9 +160,8 @@ def allreduce_gradients_overlapped(finish_backward, params: Iterable[torch.nn.Pa
     from . import functional as F_egx
     lay = F_egx.last_grad_layout
     flat, late = lay.get("flat"), int(lay.get("late_floats", 0))
-    active = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size(group) if active else 1
-    if not active or (world == 1 and not force):
+    world = _world(group)
+    if not _active(group, force):
         finish_backward()
         return 0
     params = [p for p in params if p.grad is not None] if params is not None else None
@@ -124,14 +176,15 @@ def allreduce_gradients_overlapped(finish_backward, params: Iterable[torch.nn.Pa
         if not inside:
             raise RuntimeError("allreduce_gradients_overlapped: the recorded flat gradient buffer does not hold any gradient of "
                                "`params` (another backward ran in between?)")
-    fused_avg = average and dist.get_backend(group) == "nccl"
-    op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
     early_buf, late_buf = flat[late:], flat[:late]
-    work = dist.all_reduce(early_buf, op=op, group=group, async_op=True) if early_buf.numel() else None
+    fused_avg = True
+    work = None
+    if early_buf.numel():
+        work, fused_avg = _all_reduce(early_buf, average, group, async_op=True)
     finish_backward()                       # overlaps the collective
     n = 1 if work is not None else 0
     if late_buf.numel():
-        dist.all_reduce(late_buf, op=op, group=group)
+        _, fused_avg = _all_reduce(late_buf, average, group)
         n += 1
     if work is not None:
         work.wait()
@@ -165,15 +218,14 @@ class BucketedExchange:
         self.params, self.group, self.average, self.force = list(params), group, average, force
         self.collectives = 0
         self._work, self._covered = [], []
-        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
+        self.active = _active(group, force)
 
     def _on_bucket(self, flat: torch.Tensor, lo: int, hi: int):
         if hi <= lo:
             return
         buf = flat[lo:hi]
-        fused_avg = self.average and dist.get_backend(self.group) == "nccl"
-        op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
-        self._work.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf, fused_avg))
+        work, fused_avg = _all_reduce(buf, self.average, self.group, async_op=True)
+        self._work.append((work, buf, fused_avg))
         self._covered.append((flat.untyped_storage().data_ptr(), flat.data_ptr() + 4 * lo, flat.data_ptr() + 4 * hi))
         self.collectives += 1
 
@@ -199,7 +251,7 @@ class BucketedExchange:
         if not self.active:
             return False
         F_egx.bucket_hook = None
-        world = dist.get_world_size(self.group)
+        world = _world(self.group)
         for work, buf, fused_avg in self._work:
             work.wait()
             if self.average and not fused_avg:

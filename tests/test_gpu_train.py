@@ -787,3 +787,79 @@ def test_egx_allreduce_one_rank_communicator(egx_lib, cuda):
     torch.cuda.synchronize()
     assert all(torch.equal(p.grad, before[k]) for k, p in m.named_parameters())
     comm.close()
+
+
+def test_captured_step_with_collectives_on_the_c_abi_communicator_replays_200_times(egx_lib, cuda):
+    """a step WITH its gradient exchange captured as one hipGraph, the collectives on egx_allreduce (ddp.use_egx_comm: RCCL
+    through the C ABI on streams this process owns — no ProcessGroupNCCL work objects, no watchdog thread) instead of torch.distributed, whose
+    watchdog aborted one captured run in six in round 5 (hipErrorCapturedEvent). One-rank communicator (this pool hands out one GPU): the staged
+    exchange of the per-clip path (first collective on the side stream as a parallel branch of the graph, under the grouped small weight
+    gradients; second on the capture stream) and the single exchange, each replayed 200 times; the averaged-over-one-rank gradients must equal
+    the un-exchanged backward's and stay finite throughout."""
+    from egot2_amd import ddp, functional as F_egx
+    from egot2_amd.train import CrossEntropyLoss
+    crit = CrossEntropyLoss(torch.FloatTensor(CE_W)).to(cuda)
+    comm = ddp.EgxComm(0, 1)
+    ddp.use_egx_comm(comm)
+    try:
+        for staged in (True, False):
+            from egot2_amd import hhi_ttm
+            m = hhi_ttm.TaskFusionMFTransformer3Task(hhi_args(dropout=0.3))
+            m.load_state_dict(seeded_state_dict(m, 5))
+            m = m.to(cuda).set_compute("f32s").train().enable_device_seed()
+            m.egx_defer_small = staged
+            params = [p for p in m.parameters() if p.requires_grad]
+            feats = [f.to(cuda) for f in seeded_feats(77, [(40, 15, 256)] * 3)]
+            y = torch.randint(0, 2, (40,), generator=torch.Generator().manual_seed(7)).to(cuda)
+            one = F_egx.unit_grad(cuda)
+            counts = []
+
+            def step():
+                for p in params:
+                    p.grad = None
+                loss = crit(m.forward_features(*feats), y)
+                loss.backward(gradient=one)
+                if staged:
+                    counts.append(ddp.allreduce_gradients_overlapped(F_egx.run_deferred, params, force=True))
+                else:
+                    counts.append(ddp.allreduce_gradients(params, force=True))
+                return loss
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            assert counts[-1] >= (2 if staged else 1)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                loss = step()
+            seen = set()
+            for i in range(200):
+                gr.replay()
+                if i % 50 == 49:
+                    torch.cuda.synchronize()
+                    assert all(torch.isfinite(p.grad).all().item() for p in params)
+                    seen.add(round(loss.item(), 6))
+            torch.cuda.synchronize()
+            assert len(seen) >= 3, seen         # fresh dropout masks replay after replay: the graph is doing real steps
+            # p = 0 in eval-equivalent terms is not available here (dropout recipe); compare one replay with the un-exchanged eager backward from the same seed
+            m._egx_seed_dev.fill_(1234)
+            gr.replay()
+            torch.cuda.synchronize()
+            got = {k: p.grad.clone() for k, p in m.named_parameters()}
+            m._egx_seed_dev.fill_(1234)
+            m.egx_defer_small = False
+            ddp.use_egx_comm(None)
+            for p in params:
+                p.grad = None
+            crit(m.forward_features(*feats), y).backward()
+            torch.cuda.synchronize()
+            ddp.use_egx_comm(comm)
+            for k, p in m.named_parameters():
+                assert (got[k] - p.grad).norm().item() <= 2e-5 * (p.grad.norm().item() + 1e-12), k
+    finally:
+        ddp.use_egx_comm(None)
+        comm.close()

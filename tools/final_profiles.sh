@@ -3,15 +3,15 @@
 # Bench lines, rocprofv3 kernel stats and PMC counters of every BASELINE configuration -> gpurun_out/final/ (copy what is to
 # be kept into profiles/). Every step checks its exit code: a failed bench never leaves a half-written JSON behind.
 set -euo pipefail
-R=${1:-r05}
+R=${1:-r06}
 STAGES=${2:-bench,prof,trace,pmc}      # which parts to run (run pmc first and copy its files into profiles/ when the bench lines are to carry the counters)
 OUT=gpurun_out/final
 mkdir -p $OUT
 bench() {   # bench <name> <bench.py args...>
   local name=$1; shift
-  # one retry: the opt-in --graph-collectives lines can abort in PyTorch's RCCL watchdog thread (hipErrorCapturedEvent: it queries an event
-  # recorded in the capturing stream; seen once in six runs of round 5) — a second failure is a real one
-  if python bench.py "$@" > $OUT/bench_$name.log 2>&1 || { echo "bench $name: first attempt failed, retrying"; python bench.py "$@" > $OUT/bench_$name.log 2>&1; }; then
+  # (no retry: round 5 retried a failed line once because the captured collectives could abort in PyTorch's RCCL watchdog thread; since round 6 the
+  # captured exchange runs on egx_allreduce, which has no such thread — a failure here is a real one)
+  if python bench.py "$@" > $OUT/bench_$name.log 2>&1; then
     tail -1 $OUT/bench_$name.log > $OUT/${R}_bench_$name.json
     python tools/benchline.py $OUT/${R}_bench_$name.json $name
   else
@@ -42,6 +42,7 @@ bench c5hhi --config c5hhi --no-cpu-baseline --steps 5 --warmup 2
 bench c5hhi_enc --config c5hhi --encoder-only --no-cpu-baseline --steps 5 --warmup 2
 bench f32s_deterministic --deterministic --no-cpu-baseline --no-roofline --no-native-line
 bench f32s_forcedist --force-dist --no-cpu-baseline --no-roofline --no-native-line
+bench f32s_graph_forcedist --force-dist --graph-collectives --no-cpu-baseline --no-roofline --no-native-line
 bench c4_forcedist --config c4 --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_forcedist --config c5hoi --force-dist --no-cpu-baseline --no-roofline --steps 5 --warmup 2
 bench c5hoi_eager --config c5hoi --no-graph --no-cpu-baseline --no-roofline --steps 5 --warmup 2
