@@ -250,8 +250,11 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 // PART (round 5, f32s): 0 = both weight gradients in one workgroup (the kernel of rounds 3-4); 1 = dW1 (+ db1) only, 2 = dW2 only. A PART workgroup
 // keeps one accumulator set, stages one operand image (x1 or g: 27 KB of planes) and reads one of the H / dH tile streams: about half the
 // registers and half the LDS, so FOUR workgroups share a CU where two did. ffn_dw_split2_kernel launches both parts as one grid (blockIdx.z).
-template <int CM, int OCC, int PART>
+// NW (round 6, f32s PART workgroups only): 8 = eight waves share the staged operand image (hidden group of 128: the x1 / g planes are fetched
+// once per 128 hidden units instead of once per 64 — 805 -> 510 MB through the CUs' address paths per launch)
+template <int CM, int OCC, int PART, int NW = 4>
 __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
+    static_assert(NW == 4 || ((NW == 8 || NW == 16) && CM == CM_SPLIT && PART != 0), "eight / sixteen waves: the f32s PART workgroups only");
     constexpr bool W1 = PART != 2, W2 = PART != 1;
     constexpr bool BF16 = CM == CM_BF16;
     constexpr bool SPLIT = CM == CM_SPLIT;
@@ -270,7 +273,7 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
         const int nwg = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
         if ((nwg & 7) == 0) { const int t = (id & 7) * (nwg >> 3) + (id >> 3); by = t / gridDim.x; bx = t - by * gridDim.x; }
     }
-    const int htile = bx * 4 + wave, split = by;
+    const int htile = bx * NW + wave, split = by;
     const int nht = p.d_ff / 16;
     const int ntile = p.B * FUSED_TOK_TILES;
     const int nkb_total = (ntile + 1) / 2;
@@ -300,12 +303,27 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
     // 16 B of every (tensor, part) image: no split work here (the 32 workgroups of a token range used to repeat it)
     uint4 prs[SPLIT ? 12 : 1];
     auto gload = [&](int kb) {
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && NW == 16) {
+            // 1024 threads: the image's 3 x 32 x 16 sixteen-byte pieces in two passes (the second half-empty: clamped, not stored)
+            const size_t plane = (size_t)p.B * FUSED_TOK_PAD * FD;
+            const unsigned short* base = reinterpret_cast<const unsigned short*>(W1 ? p.x1 : p.g);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int idx = tid + k * 1024;
+                idx = idx < 1536 ? idx : 1535;
+                const int part = idx >> 9, row = (idx & 511) >> 4, c8 = idx & 15;
+                const int tile = kb * 2 + (row >> 4);
+                const int tc = tile < ntile ? tile : ntile - 1;
+                const uint4 v = *reinterpret_cast<const uint4*>(base + part * plane + ((size_t)tc * 16 + (row & 15)) * FD + c8 * 8);
+                prs[k] = tile < ntile ? v : make_uint4(0, 0, 0, 0);
+            }
+        } else if constexpr (SPLIT) {
             const size_t plane = (size_t)p.B * FUSED_TOK_PAD * FD;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 const int tp = i >> 1, tensor = tp / 3, part = tp - tensor * 3;
                 if ((tensor == 0 && !W1) || (tensor == 1 && !W2)) continue;
+                if (NW == 8 && (i & 1)) continue;       // 512 threads: one pass covers the 32 rows
                 const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
                 int tile = kb * 2 + (row >> 4);
                 const unsigned short* src = reinterpret_cast<const unsigned short*>(tensor ? p.g : p.x1) + part * plane +
@@ -343,10 +361,20 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
         }
     };
     auto lstore = [&](int buf_idx) {
+        if constexpr (SPLIT && NW == 16) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + k * 1024;
+                const int part = idx >> 9, row = (idx & 511) >> 4, c8 = idx & 15;
+                if (idx < 1536) *reinterpret_cast<uint4*>(ldsh + part * TILEH + row * LDB + c8 * 8) = prs[k];
+            }
+            return;
+        }
         if constexpr (SPLIT) {
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
                 if ((i < 6 && !W1) || (i >= 6 && !W2)) continue;
+                if (NW == 8 && (i & 1)) continue;
                 const int row = (tid >> 4) + (i & 1) * 16, c8 = tid & 15;
                 // (a PART workgroup has ONE operand image: it sits where tensor 0's would)
                 *reinterpret_cast<uint4*>(ldsh + ((i >> 1) - (PART == 2 ? 3 : 0)) * TILEH + row * LDB + c8 * 8) = prs[i];
@@ -517,6 +545,14 @@ __global__ __launch_bounds__(256, OCC) void ffn_dw_stored_kernel(FfnDwParams p) 
 __global__ __launch_bounds__(256, 4) void ffn_dw_split2_kernel(FfnDwParams p) {
     if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1>(p);
     else ffn_dw_stored_body<CM_SPLIT, 2, 2>(p);
+}
+__global__ __launch_bounds__(512, 2) void ffn_dw_split2w8_kernel(FfnDwParams p) {
+    if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 8>(p);
+    else ffn_dw_stored_body<CM_SPLIT, 2, 2, 8>(p);
+}
+__global__ __launch_bounds__(1024, 1) void ffn_dw_split2w16_kernel(FfnDwParams p) {
+    if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 16>(p);
+    else ffn_dw_stored_body<CM_SPLIT, 2, 2, 16>(p);
 }
 
 // bf16 stored-operand kernel with everything staged by LDS-DMA. ffn_dw_stored_kernel<CM_BF16> spends a K-block's time on
@@ -797,6 +833,28 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
                 EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
                 attr4_set = true;
             }
+            // Round 6: EIGHT waves per workgroup share one staged operand image (hidden group of 128). With four, the launch moved 805 MB through
+            // the CUs' address paths (24 KB of x1 / g planes + 8 KB of H / dH tiles per K-block and workgroup: ~30 B / clk / CU, the rate a CU pulls
+            // from L2 at best), 590 MB of it the planes that every hidden group of a token range re-reads; with eight 510 MB. 76.5 -> 64.0 us,
+            // step 371 -> 360 us (three same-box pairs, profiles/r06_ab_ffn_dw_w8.txt); sixteen waves (one workgroup per CU) measured the same as
+            // eight. EGX_FFN_DW_W8 = 0 | 16 selects the four- / sixteen-wave grids (tuning aid).
+            static const int w8 = [] { const char* e = getenv("EGX_FFN_DW_W8"); return e ? atoi(e) : 8; }();
+            if (w8 == 16 && p.d_ff % 256 == 0) {
+                static bool attr6_set = false;
+                if (!attr6_set) {
+                    EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2w16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
+                    attr6_set = true;
+                }
+                hipLaunchKernelGGL(ffn_dw_split2w16_kernel, dim3(p.d_ff / 256, grid.y, 2), dim3(1024), lds / 2, st, p);
+            } else
+            if (w8 && p.d_ff % 128 == 0) {
+                static bool attr5_set = false;
+                if (!attr5_set) {
+                    EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
+                    attr5_set = true;
+                }
+                hipLaunchKernelGGL(ffn_dw_split2w8_kernel, dim3(p.d_ff / 128, grid.y, 2), dim3(512), lds / 2, st, p);
+            } else
             hipLaunchKernelGGL(ffn_dw_split2_kernel, dim3(grid.x, grid.y, 2), dim3(256), lds / 2, st, p);
         } else if (occ == 3) hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 3>), grid, dim3(256), lds / 2 + tstage_bytes, st, p);
         else hipLaunchKernelGGL((ffn_dw_stored_kernel<CM, 2>), grid, dim3(256), lds + tstage_bytes, st, p);
