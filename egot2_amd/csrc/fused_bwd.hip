@@ -564,10 +564,15 @@ __global__ __launch_bounds__(1024, 1) void ffn_dw_split2w16_kernel(FfnDwParams p
 // + 4 waves x 4 tiles of 512 B (accumulator layout, read back token-along-K by ds_read_b64_tr_b16 as they lie). 256 threads,
 // two independent workgroups per CU.
 #define EGX_RING_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-__global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p) {
+// NW waves per workgroup share the staged x1 / g images (round 6: the kernel is bound by the bytes a CU pulls from L2 — with four waves 24 KB per
+// K-block for 64 MFMAs; the images are 16 KB of it); D ring stages.
+template <int NW, int D>
+__device__ __forceinline__ void ffn_dw_bf16_ring_body(const FfnDwParams& p) {
     constexpr int CM = CM_BF16;
     // (two stages at three workgroups per CU, with 16 or 24 token splits, run at the same 35 us)
-    constexpr int IMG = 32 * 256, TILES = 4 * 4 * 512, SB = 2 * IMG + TILES, D = 3;
+    constexpr int IMG = 32 * 256, TILES = NW * 4 * 512, SB = 2 * IMG + TILES;
+    constexpr int IMGI = 16 / NW;        // image staging instructions per wave and K-block (two images x 32 rows = 16 wave-loads of 4 rows)
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
         const int nwg = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
         if ((nwg & 7) == 0) { const int t = (id & 7) * (nwg >> 3) + (id >> 3); by = t / gridDim.x; bx = t - by * gridDim.x; }
     }
-    const int htile = bx * 4 + wave, split = by;
+    const int htile = bx * NW + wave, split = by;
     const int nht = p.d_ff / 16;
     const int ntile = p.B * FUSED_TOK_TILES;
     const int nkb_total = (ntile + 1) / 2;
@@ -592,13 +597,13 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
     for (int j = 0; j < 8; ++j) { accW1[j] = f32x4{0, 0, 0, 0}; accW2[j] = f32x4{0, 0, 0, 0}; }
     float accB4[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // staging, six instructions per wave and K-block: j < 4 moves rows 4 * (idx & 7) .. + 3 of image idx >> 3 (idx = 4 w + j);
-    // j = 4 / 5 moves this wave's two H / two dH tiles (lanes 0..31: first token tile, lanes 32..63: second)
-    const unsigned char* srcS[4];
-    int rowS[4];
+    // staging, IMGI + 2 instructions per wave and K-block: j < IMGI moves rows 4 * (idx & 7) .. + 3 of image idx >> 3 (idx = IMGI w + j);
+    // the last two move this wave's two H / two dH tiles (lanes 0..31: first token tile, lanes 32..63: second)
+    const unsigned char* srcS[IMGI];
+    int rowS[IMGI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = wave * 4 + j, img = idx >> 3;
+    for (int j = 0; j < IMGI; ++j) {
+        const int idx = wave * IMGI + j, img = idx >> 3;
         const int row = (idx & 7) * 4 + (lane >> 4), slot = lane & 15;
         rowS[j] = row;
         srcS[j] = reinterpret_cast<const unsigned char*>(img ? p.g : p.x1) + (((slot >> 1) ^ (row & 7)) * 32 + (slot & 1) * 16);
@@ -606,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
     const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(p.hs) + (size_t)htile * 512 + (lane & 31) * 16;
     const unsigned char* dsrc = reinterpret_cast<const unsigned char*>(p.dhs) + (size_t)htile * 512 + (lane & 31) * 16;
     auto stage = [&](int kb, int buf) {
-        unsigned char* dst = ring + buf * SB + wave * 4 * 1024;
+        unsigned char* dst = ring + buf * SB + wave * IMGI * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < IMGI; ++j) {
             int tile = min(kb * 2 + (rowS[j] >> 4), ntile - 1);     // a missing second tile: finite rows, its H / dH operand half is zeroed
             __builtin_amdgcn_global_load_lds((glb_void*)(srcS[j] + ((size_t)tile * 16 + (rowS[j] & 15)) * (FD * 2)), (lds_void*)(dst + j * 1024), 16, 0, 0);
         }
@@ -640,8 +645,11 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
         for (int s = 0; s < D; ++s) {
             const int kb = kb0 + s;
             if (kb >= kb_end) break;
-            // this K-block's six loads have landed; the next K-block's six may stay in flight across the barrier
-            if (kb + 1 < kb_end) EGX_RING_WAIT(6); else EGX_RING_WAIT(0);
+            // this K-block's loads have landed; the next K-block's (IMGI + 2 per wave) may stay in flight across the barrier
+            if (kb + 1 < kb_end) {
+                if constexpr (D >= 3) { if constexpr (IMGI == 4) EGX_RING_WAIT(6); else if constexpr (IMGI == 2) EGX_RING_WAIT(4); else EGX_RING_WAIT(3); }
+                else EGX_RING_WAIT(0);
+            } else EGX_RING_WAIT(0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kb + D - 1 < kb_end) stage(kb + D - 1, (s + D - 1) % D);
             const bool has_b = kb * 2 + 1 < ntile;
@@ -693,6 +701,10 @@ __global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p)
     }
     if (r == 0) *reinterpret_cast<float4*>(p.slab_b1 + (size_t)split * p.d_ff + htile * 16 + 4 * q) = make_float4(accB4[0], accB4[1], accB4[2], accB4[3]);
 }
+__global__ __launch_bounds__(256, 2) void ffn_dw_bf16_ring_kernel(FfnDwParams p) { ffn_dw_bf16_ring_body<4, 3>(p); }
+__global__ __launch_bounds__(512, 1) void ffn_dw_bf16_ring8_kernel(FfnDwParams p) { ffn_dw_bf16_ring_body<8, 3>(p); }
+__global__ __launch_bounds__(512, 2) void ffn_dw_bf16_ring8d2_kernel(FfnDwParams p) { ffn_dw_bf16_ring_body<8, 2>(p); }
+__global__ __launch_bounds__(1024, 1) void ffn_dw_bf16_ring16_kernel(FfnDwParams p) { ffn_dw_bf16_ring_body<16, 3>(p); }
 
 // Three slab reductions in one launch: out_k[i] += sum_z slab_k[z * n_k + i], float4-vectorised. The same launch can
 // carry the reduction of the per-clip partial rows (blocks >= slab_blocks; see reduce_partials_kernel).
@@ -764,9 +776,17 @@ static bool ffn_dw_ring() {
     return v == 1;
 }
 bool ffn_dw_bf16_planes() { return ffn_dw_ring(); }
+// waves per workgroup of the bf16 LDS-ring kernel: 4 (rounds 3-5), 8, 16, or 82 = eight waves with a two-stage ring at two workgroups per CU
+// (EGX_FFN_DW_BF16_NW, tuning aid)
+static int ffn_dw_bf16_waves(int d_ff) {
+    static const int env = [] { const char* e = getenv("EGX_FFN_DW_BF16_NW"); return e ? atoi(e) : 4; }();
+    const int nwv = env == 82 ? 8 : env;
+    if ((nwv == 8 || nwv == 16) && d_ff % (16 * nwv) == 0) return env;
+    return 4;
+}
 // most token splits any variant uses for a hidden width: a narrow FFN (the PNR / OSCC recipe's d_ff = 256: four hidden groups) needs more of them
 // to fill the chip; its slabs are small
-static int ffn_dw_max_splits(int d_ff) { return d_ff <= 512 ? 48 : 24; }
+static int ffn_dw_max_splits(int d_ff) { return d_ff <= 512 ? 48 : 32; }
 // EGX_FFN_DW_SPLIT2=0: the one-workgroup-for-both-gradients kernel of rounds 3-4 in f32s (tuning aid)
 static bool ffn_dw_split2() {
     static int v = -1;
@@ -805,13 +825,22 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
     dim3 grid(p.d_ff / (64 * HT), p.splits);
     timing_begin(TIMER_FFN_DW, st);
     if (p.hs && CM == CM_BF16 && p.xg_planes && ffn_dw_ring()) {
-        const int ring_bytes = 3 * (2 * 32 * 256 + 4 * 4 * 512);
+        const int nw = ffn_dw_bf16_waves(p.d_ff);
+        const int nd = nw == 82 ? 2 : 3, nwv = nw == 82 ? 8 : nw;
+        const int ring_bytes = nd * (2 * 32 * 256 + nwv * 4 * 512);
         static bool attr3_set = false;
         if (!attr3_set) {
-            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes));
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (2 * 32 * 256 + 4 * 4 * 512)));
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (2 * 32 * 256 + 8 * 4 * 512)));
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring8d2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 32 * 256 + 8 * 4 * 512)));
+            EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_bf16_ring16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (2 * 32 * 256 + 16 * 4 * 512)));
             attr3_set = true;
         }
-        hipLaunchKernelGGL(ffn_dw_bf16_ring_kernel, grid, dim3(256), ring_bytes, st, p);
+        const dim3 g2(p.d_ff / (16 * nwv), p.splits);
+        if (nw == 16) hipLaunchKernelGGL(ffn_dw_bf16_ring16_kernel, g2, dim3(1024), ring_bytes, st, p);
+        else if (nw == 82) hipLaunchKernelGGL(ffn_dw_bf16_ring8d2_kernel, g2, dim3(512), ring_bytes, st, p);
+        else if (nw == 8) hipLaunchKernelGGL(ffn_dw_bf16_ring8_kernel, g2, dim3(512), ring_bytes, st, p);
+        else hipLaunchKernelGGL(ffn_dw_bf16_ring_kernel, grid, dim3(256), ring_bytes, st, p);
     } else if (p.hs) {
         EGX_CHECK(!p.xg_planes || CM == CM_SPLIT, "ffn_dw: bf16 operand planes are read by the LDS-ring kernel only (unset EGX_FFN_DW_RING)");
         EGX_CHECK(CM != CM_SPLIT || p.xg_planes, "ffn_dw: the split-mode stored-operand kernel reads pre-split x1 / g planes");
