@@ -23,6 +23,13 @@ def _model(cuda, compute="f32s", p=0.0, tasks=3, layers=1):
     return m
 
 
+def _same(a, b, rtol):
+    """||a - b|| <= rtol ||b|| + a floor for gradients that cancel to nearly zero (a head bias: the sum over the clips of d_logits), whose
+    relative error under another atomic-add order is noise over ~0."""
+    a, b = a.double().cpu(), b.double().cpu()
+    return (a - b).norm().item() <= rtol * b.norm().item() + 2e-7 * (b.numel() ** 0.5)
+
+
 def _grads(m):
     return {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
 
@@ -79,7 +86,7 @@ def test_fused_cross_entropy_equals_separate_launch_and_oracle(egx_lib, cuda, co
     assert abs(loss_a.item() - loss_b.item()) < 2e-6 * max(1.0, abs(loss_a.item()))
     # (atomic accumulation order differs run to run; bf16: d_logits differing in the last bit flips roundings of bf16 operands downstream)
     for k in ga:
-        assert rel_err(gb[k], ga[k]) < (5e-3 if compute == "bf16" else 2e-5), k
+        assert _same(gb[k], ga[k], 5e-3 if compute == "bf16" else 2e-5), k
     ref = torch.nn.functional.cross_entropy(logits_b.double().cpu(), target.cpu(), weight=torch.tensor(CE_W, dtype=torch.float64))
     assert abs(ref.item() - loss_b.item()) < 1e-5
     if with_oracle:
@@ -112,7 +119,7 @@ def test_fused_cross_entropy_upstream_gradients(egx_lib, cuda):
     for fn in (lambda z, l: 3.0 * l, lambda z, l: l + (z * z).sum() * 0.1, lambda z, l: (z * z).sum()):
         a, b = run(False, fn), run(True, fn)
         for k in a:
-            assert rel_err(b[k], a[k]) < 2e-5, k
+            assert _same(b[k], a[k], 2e-5), k
 
 
 def test_fused_cross_entropy_without_valid_label_is_nan_like_torch(egx_lib, cuda):
@@ -144,7 +151,7 @@ def test_fused_cross_entropy_on_other_implementations(egx_lib, cuda):
         gb = _grads(m)
         assert torch.equal(z, z2)
         for k in ga:
-            assert rel_err(gb[k], ga[k]) < 2e-5, k
+            assert _same(gb[k], ga[k], 2e-5), k
     m.set_deterministic(False)
     assert F_egx.last_encoder_impl() == "tiled"
 
@@ -178,7 +185,7 @@ def test_weight_cache_skips_the_packing_launch_and_follows_the_weights(egx_lib, 
     zr, gr = step(ref)
     assert torch.equal(z1, z2) and torch.equal(z1, zr)
     for k in gr:
-        assert rel_err(g2[k], gr[k]) < 2e-5, k
+        assert _same(g2[k], gr[k], 2e-5), k
     # in-place update through torch: version counters move
     with torch.no_grad():
         for mm in (m, ref):
@@ -265,7 +272,7 @@ def test_frozen_cache_graph_step_has_no_launch_in_front_of_the_forward(egx_lib, 
         assert abs(loss_new.item() - l_old.item()) < 1e-5
         g_old, g_new = _grads(old), _grads(new)
         for k in g_old:
-            assert rel_err(g_new[k], g_old[k]) < 2e-5, k
+            assert _same(g_new[k], g_old[k], 2e-5), k
         a = loss_new.item()
         gr.replay()
         torch.cuda.synchronize()

@@ -859,7 +859,8 @@ def test_captured_step_with_collectives_on_the_c_abi_communicator_replays_200_ti
             torch.cuda.synchronize()
             ddp.use_egx_comm(comm)
             for k, p in m.named_parameters():
-                assert (got[k] - p.grad).norm().item() <= 2e-5 * (p.grad.norm().item() + 1e-12), k
+                # (+ a floor for gradients that cancel to ~0, the head bias: their relative error under another atomic-add order is noise)
+                assert (got[k] - p.grad).norm().item() <= 2e-5 * p.grad.norm().item() + 2e-7 * p.grad.numel() ** 0.5, k
     finally:
         ddp.use_egx_comm(None)
         comm.close()
