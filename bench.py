@@ -667,7 +667,8 @@ def counter_fields(cnt, kernel, avg_launch_us):
     ks = (cnt or {}).get("kernels", {})
     k = ks.get(kernel) or {}
     if not k and kernel.endswith("::ffn_dw_kernel"):      # the library's timer name covers the variant that actually ran
-        k = ks.get("egx::ffn_dw_split2_kernel") or ks.get("egx::ffn_dw_stored_kernel") or ks.get("egx::ffn_dw_bf16_ring_kernel") or {}
+        k = (ks.get("egx::ffn_dw_split2w8_kernel") or ks.get("egx::ffn_dw_split2_kernel") or ks.get("egx::ffn_dw_stored_kernel")
+             or ks.get("egx::ffn_dw_bf16_ring_kernel") or {})
     traffic = k.get("traffic_bytes")
     out = {"traffic": traffic,
            "hbm_gbps": (traffic / (avg_launch_us * 1e-6) / 1e9) if traffic and avg_launch_us else None}
