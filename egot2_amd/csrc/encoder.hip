@@ -334,6 +334,7 @@ struct FusedBwdScratch {
     size_t x1[FUSED_MAX_LAYERS], g2[FUSED_MAX_LAYERS], attn_o[FUSED_MAX_LAYERS], g1[FUSED_MAX_LAYERS], dqkv[FUSED_MAX_LAYERS];
     size_t dseg[EGX_MAX_SEGMENTS];
     size_t partials, slabs, slab_bytes, dhid, bytes, dx0;
+    size_t sdw_tiles, sdw_bytes;            // round 6: the tiles small_dw leaves for the fixed-order tail launch (NOT the shared slab area: layer 0's FFN slabs live there)
     size_t dy1, dxin;                       // cut mode: what the FFN-side and the attention-side launches of the backward hand each other
     size_t xchg;                            // sliced mode only
     size_t datt, dres, delta, dtok;         // tiled mode only
@@ -362,6 +363,8 @@ static FusedBwdScratch fused_bwd_scratch(const egx_config* cfg, const egx_segmen
     s.slabs = take(cur, slab);
     s.ffn_slab[0] = s.slabs;
     for (int l = 1; l < pl.L && l < FUSED_MAX_LAYERS; ++l) s.ffn_slab[l] = take(cur, ffn_dw_scratch_bytes((int)pl.N, pl.dff, nullptr));
+    s.sdw_bytes = (size_t)(512 + SMALL_DW_MAX * 16) * 64 * 128 * sizeof(float);
+    s.sdw_tiles = take(cur, s.sdw_bytes);
     s.dhid = take(cur, fused_hid_total(cfg, pl));
     s.dx0 = take(cur, nd);         // d(token-prep output) behind its dropout mask (learned positional table gradient)
     s.dy1 = take(cur, nd); s.dxin = take(cur, nd);
@@ -1073,9 +1076,46 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             for (int l = 0; l < pl.L; ++l) any_small = any_small || layer_grads[l].out_proj_w || layer_grads[l].in_proj_w;
             for (int i = 0; i < pl.nseg && seg_grads; ++i) any_small = any_small || seg_grads[i].proj_w;
             SmallDwTail tail;
-            const bool ride = stage == 0 && !cfg->deterministic && any_small && (red.narr || rp_pending) && reduce_rides();
             // egx_config.advance_seed == 2: the backward advances the device seed behind its last reader (the last launch that can run here)
             uint64_t* adv = (cfg->advance_seed == 2 && cfg->seed_ptr && training && stage != 1) ? const_cast<uint64_t*>(cfg->seed_ptr) : nullptr;
+            // Round 6, one-stage backward: small_dw writes tiles and ONE fixed-order launch sums them, the FFN slabs and the partial rows (tail_reduce,
+            // fused_bwd.hip): no float atomics, bit-reproducible in every mode. EGX_TAIL_REDUCE=0: the round-5 launches (atomics with the reductions
+            // riding in small_dw; the slow three-pass path in deterministic mode) — tuning aid. The staged backward (stage 1 / 2) keeps its own launches.
+            static const bool tail_env = [] { const char* e = getenv("EGX_TAIL_REDUCE"); return !(e && e[0] == '0'); }();
+            if (stage == 0 && tail_env) {
+                TouchList tl;
+                memset(&tl, 0, sizeof(tl));
+                if (touch) {    // the next forward starts with the projections and layer 0's in-projection (one contiguous run of the cache) and out-projection
+                    touch_add(tl, PL.proj[0], (size_t)((const char*)PL.layer[0].in_wt - (const char*)PL.proj[0]));
+                    touch_add(tl, PL.layer[0].out_w, out_pb);
+                }
+                SmallDwParams sp;
+                memset(&sp, 0, sizeof(sp));
+                bool first = true;
+                auto flush = [&]() -> int {
+                    if (sp.n && small_dw(sp, comp, st, (char*)scratch + SC.sdw_tiles, SC.sdw_bytes, nullptr, false)) return 1;
+                    const int rc = (sp.n || first) ? tail_reduce(sp.n ? &sp : nullptr, first ? &red : nullptr, first ? &rp : nullptr, first ? adv : nullptr, first ? &tl : nullptr, st) : 0;
+                    first = false;
+                    memset(&sp, 0, sizeof(sp));
+                    return rc;
+                };
+                auto add = [&](const float* G, int ldg, const float* X, int ldx, float* out, int R, int Cc, int K) -> int {
+                    if (!out) return 0;
+                    if (sp.n == SMALL_DW_MAX && flush()) return 1;
+                    SmallDwProblem& q = sp.pr[sp.n++];
+                    q.G = G; q.X = X; q.out = out; q.R = R; q.C = Cc; q.K = K; q.ldg = ldg; q.ldx = ldx;
+                    return 0;
+                };
+                for (int l = 0; l < pl.L; ++l) {
+                    const egx_layer_grads& gw = layer_grads[l];
+                    if (add(bp.layer[l].g1_out, d, bp.layer[l].attn_o_out, d, gw.out_proj_w, d, d, N)) return 1;
+                    if (add(bp.layer[l].dqkv_out, 3 * d, bp.layer[l].x_in_out, d, gw.in_proj_w, 3 * d, d, N)) return 1;
+                }
+                for (int i = 0; i < pl.nseg; ++i)
+                    if (seg_grads && add(bp.dseg_out[i], d, segs[i].feat, segs[i].d_in, seg_grads[i].proj_w, d, segs[i].d_in, B * segs[i].T)) return 1;
+                return flush();
+            }
+            const bool ride = stage == 0 && !cfg->deterministic && any_small && (red.narr || rp_pending) && reduce_rides();
             if (ride) {
                 small_dw_tail_init(tail, red, rp_pending ? &rp : nullptr);
                 tail.seed_advance = adv; adv = nullptr;

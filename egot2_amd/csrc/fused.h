@@ -246,7 +246,8 @@ struct SmallDwParams {
 struct SmallDwTail;
 // `tail` (optional): the FFN slab reduction and the partial-row reduction, done by this launch's workgroups before their own
 // work (each takes 1 / grid of the units) instead of by a launch of their own
-int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullptr, size_t slab_bytes = 0, const SmallDwTail* tail = nullptr);
+// reduce_here = false (with slabs): the tiles are left for tail_reduce()
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs = nullptr, size_t slab_bytes = 0, const SmallDwTail* tail = nullptr, bool reduce_here = true);
 int seed_advance(uint64_t* seed, hipStream_t st);
 
 struct PartialDst { float* dst; int off, len; };
@@ -259,6 +260,9 @@ struct ReducePartialsParams {
 int reduce_partials(const ReducePartialsParams& rp, hipStream_t st, bool deterministic = false);
 struct SmallDwTail { SlabReduce red; ReducePartialsParams rp; unsigned slab_blocks; int rp_units, chunks; uint64_t* seed_advance; /* optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed == 2) */ TouchList touch; /* the next forward's first weight streams */ };
 void small_dw_tail_init(SmallDwTail& t, const SlabReduce& red, const ReducePartialsParams* rp);
+// Round 6: every cross-workgroup sum of the per-clip backward in ONE fixed-order launch (fused_bwd.hip tail_reduce_kernel): the tiles small_dw(sp, ..., slabs)
+// wrote, the FFN slabs, the per-clip partial rows; also the seed advance and the next forward's weight prefetch. Null / empty parts are skipped.
+int tail_reduce(const SmallDwParams* sp, const SlabReduce* red, const ReducePartialsParams* rp, uint64_t* seed_advance_ptr, const TouchList* touch, hipStream_t st);
 
 // Optional per-kernel device timing (hipEvents on the launch stream) for bench.py's roofline block.
 enum { TIMER_FUSED_FWD = 0, TIMER_FUSED_BWD = 1, TIMER_FFN_DW = 2, TIMER_FFN_FWD = 3, TIMER_FFN_BWD = 4, TIMER_WIDE_GEMM = 5,

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void small_dw_reduce_kernel(SmallDwParams p) {
     }
 }
 
-int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t slab_bytes, const SmallDwTail* tail) {
+int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t slab_bytes, const SmallDwTail* tail, bool reduce_here) {
     int items[SMALL_DW_MAX], nkb[SMALL_DW_MAX], total_items = 0;
     for (int i = 0; i < p.n; ++i) {
         EGX_CHECK(p.pr[i].R % 4 == 0 && p.pr[i].C % 4 == 0 && p.pr[i].ldg % 4 == 0 && p.pr[i].ldx % 4 == 0,
@@ -1231,7 +1231,128 @@ int small_dw(SmallDwParams& p, int compute, hipStream_t st, void* slabs, size_t 
         else if (compute == CM_SPLIT) hipLaunchKernelGGL((small_dw_kernel<CM_SPLIT, false>), dim3(blocks), dim3(256), 0, st, p, none);
         else hipLaunchKernelGGL((small_dw_kernel<CM_F32, false>), dim3(blocks), dim3(256), 0, st, p, none);
     }
-    if (p.slabs) hipLaunchKernelGGL(small_dw_reduce_kernel, dim3(total_items * 8), dim3(256), 0, st, p);
+    if (p.slabs && reduce_here) hipLaunchKernelGGL(small_dw_reduce_kernel, dim3(total_items * 8), dim3(256), 0, st, p);
+    EGX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- round 6: every cross-workgroup sum of the per-clip backward in ONE fixed-order launch -------------------------------------------------
+// Until round 5 the grouped small weight gradients left as 8 192 float atomics per workgroup (16 MB of added bytes per C2 step at the ~1.3 TB/s
+// the memory-side atomic units take: 12 us of the launch) with the FFN slab sums and the per-clip partial rows riding in front of them (10 us);
+// the deterministic mode ran slab tiles and three slow fixed-order passes instead (25 + 16 + 33 us). Now small_dw always writes its tiles and
+// this launch sums, each in a fixed order: (a) the tiles of every (problem, item) over its splits, (b) the FFN weight-gradient slabs, (c) the
+// per-clip partial rows (16 clip lanes per column, LDS tree) — 51 MB read, all of it freshly written; it also carries the step's seed advance and
+// the next forward's weight prefetch. The per-clip backward is bit-reproducible in every mode as a by-product.
+struct TailReduceParams {
+    SmallDwParams sp;           // tile sums (sp.slabs = the tiles small_dw wrote); sp.n == 0: none
+    SlabReduce red;             // FFN slab sums; red.narr == 0: none
+    ReducePartialsParams rp;    // partial rows; rp.n == 0: none
+    unsigned tile_blocks, slab_blocks, part_blocks;
+    uint64_t* seed_advance;
+    TouchList touch;
+};
+__global__ __launch_bounds__(256) void tail_reduce_kernel(TailReduceParams t) {
+    const unsigned b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && t.seed_advance)
+        *t.seed_advance = *t.seed_advance * 6364136223846793005ull + 1442695040888963407ull;
+    if (t.touch.n) touch_sink(touch_lines<256>(t.touch, blockIdx.x, gridDim.x, threadIdx.x));
+    if (b < t.part_blocks) {
+        // (c) partial rows first (chains of dependent loads that then run under the streams): 16 columns x 16 clip lanes per workgroup
+        __shared__ float red[16][17];
+        const ReducePartialsParams& rp = t.rp;
+        const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+        const int j = (int)b * 16 + c;
+        float s = 0.f;
+        if (j < rp.P) {
+            int clip = g;
+            for (; clip + 7 * 16 < rp.B; clip += 8 * 16) {      // eight loads in flight
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = rp.partials[(size_t)(clip + k * 16) * rp.P + j];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[k];
+            }
+            for (; clip < rp.B; clip += 16) s += rp.partials[(size_t)clip * rp.P + j];
+        }
+        red[g][c] = s;
+        __syncthreads();
+        if (g == 0 && j < rp.P) {
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tot += red[k][c];
+            float* dst = nullptr;
+            for (int i = 0; i < rp.n; ++i)
+                if (j >= rp.d[i].off && j < rp.d[i].off + rp.d[i].len) dst = rp.d[i].dst + (j - rp.d[i].off);
+            if (dst) *dst += tot;        // the only adder of this element in this launch
+        }
+        return;
+    }
+    if (b < t.part_blocks + t.tile_blocks) {
+        // (a) tiles of the grouped small weight gradients: (work item, 8 of its 64 rows) per workgroup, splits in order, eight loads in flight
+        const SmallDwParams& p = t.sp;
+        const unsigned u = b - t.part_blocks;
+        const int unit = (int)(u >> 3), part = (int)(u & 7);
+        int pi = 0, base = 0;
+        for (;; ++pi) {
+            const int items = ((p.pr[pi].R + 63) / 64) * ((p.pr[pi].C + 127) / 128);
+            if (unit < base + items || pi + 1 >= p.n) break;
+            base += items;
+        }
+        const SmallDwProblem& pr = p.pr[pi];
+        const int item = unit - base;
+        const int ncol = (pr.C + 127) / 128;
+        const int row0 = (item / ncol) * 64, col0 = (item % ncol) * 128;
+        const int nkb = (pr.K + 31) / 32;
+        const int nsp = min(pr.splits, (nkb + p.per - 1) / p.per);      // workgroups without K-blocks wrote nothing
+        const int r = part * 8 + (threadIdx.x >> 5), c = (threadIdx.x & 31) * 4;
+        const float* tile0 = p.slabs + (size_t)(pr.first_block + item * pr.splits) * (64 * 128) + r * 128 + c;
+        float4 s = make_float4(0, 0, 0, 0);
+        int sp = 0;
+        for (; sp + 8 <= nsp; sp += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(tile0 + (size_t)(sp + k) * (64 * 128));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+        }
+        for (; sp < nsp; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(tile0 + (size_t)sp * (64 * 128));
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        const int row = row0 + r, col = col0 + c;
+        if (row < pr.R && col < pr.C) {                                 // C % 4 == 0
+            float4* dst = reinterpret_cast<float4*>(pr.out + (size_t)row * pr.C + col);
+            const float4 o = *dst;
+            *dst = make_float4(o.x + s.x, o.y + s.y, o.z + s.z, o.w + s.w);
+        }
+        return;
+    }
+    // (b) FFN weight-gradient slabs
+    reduce_slabs_block(t.red, b - t.part_blocks - t.tile_blocks);
+}
+
+// small_dw with tiles (sp must have been through small_dw(sp, ..., slabs)) + the fixed-order tail. Any of the three parts may be empty.
+int tail_reduce(const SmallDwParams* sp, const SlabReduce* red, const ReducePartialsParams* rp, uint64_t* seed_advance_ptr, const TouchList* touch, hipStream_t st) {
+    TailReduceParams t;
+    memset(&t, 0, sizeof(t));
+    if (sp && sp->n && sp->slabs) {
+        t.sp = *sp;
+        int items = 0;
+        for (int i = 0; i < sp->n; ++i) items += cdiv(sp->pr[i].R, 64) * cdiv(sp->pr[i].C, 128);
+        t.tile_blocks = (unsigned)items * 8;
+    }
+    if (red && red->narr) {
+        t.red = *red;
+        size_t total = 0;
+        for (int k = 0; k < red->narr; ++k) total += red->n[k];
+        t.slab_blocks = (unsigned)((total / 4 + 255) / 256);
+    }
+    if (rp && rp->n) { t.rp = *rp; t.part_blocks = (unsigned)cdiv(rp->P, 16); }
+    t.seed_advance = seed_advance_ptr;
+    if (touch) t.touch = *touch;
+    const unsigned blocks = t.tile_blocks + t.slab_blocks + t.part_blocks;
+    if (!blocks) return seed_advance_ptr ? seed_advance(seed_advance_ptr, st) : 0;
+    hipLaunchKernelGGL(tail_reduce_kernel, dim3(blocks), dim3(256), 0, st, t);
     EGX_LAUNCH_CHECK();
     return 0;
 }
