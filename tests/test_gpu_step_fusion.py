@@ -277,3 +277,25 @@ def test_frozen_cache_graph_step_has_no_launch_in_front_of_the_forward(egx_lib, 
         gr.replay()
         torch.cuda.synchronize()
         assert loss_new.item() != a, "a replay must draw fresh dropout masks"
+
+
+@pytest.mark.parametrize("compute,B", [("f32s", 256), ("bf16", 256), ("f32s", 40), ("f32", 130)])
+def test_default_backward_is_bit_reproducible(egx_lib, cuda, compute, B):
+    """Round 6: every cross-workgroup sum of the per-clip backward runs in a fixed order in the DEFAULT mode (small_dw tiles + tail_reduce_kernel
+    instead of float atomics): the same inputs, weights and dropout seed give bit-identical gradients run to run — at the bench batch in cut mode
+    (f32s), with the one-launch kernels (bf16, exact fp32) and in the sliced mode of small batches (B = 40). Until round 5 that took
+    set_deterministic(True) and three slow reduction passes (+8 % on the step)."""
+    m = _model(cuda, compute, p=0.5).enable_device_seed()
+    feats = [f.to(cuda) for f in seeded_feats(55, [(B, 15, 256)] * 3)]
+    target = torch.randint(0, 2, (B,), generator=torch.Generator().manual_seed(9)).to(cuda)
+    w = torch.tensor(CE_W, device=cuda)
+    runs = []
+    for _ in range(3):
+        m._egx_seed_dev.fill_(31337)
+        m.zero_grad()
+        _, loss = m.forward_features(*feats, target=target, class_weight=w)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append(_grads(m))
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
