@@ -526,6 +526,7 @@ def run(args) -> int:
                    "weights_packed": ("once, outside the timed loop (forward + backward only: the weights do not change between steps; "
                                       "with_optimizer re-packs every step)" if (wcache_on and not args.optimizer) else "every step"),
                    "loss": ("weighted CE in the forward's head epilogue (egx_ce)" if (wl["name"] in ("c1", "c2") and not args.no_fused_ce)
+                            else "lossAV in the encoder's launches where the per-clip kernels can (egx_token_ce)" if (wl["name"] == "c3" and not args.no_fused_ce)
                             else "separate launch(es)")},
         "library_launches_per_step": launches_per_step,
         "step_tflops": (fwd_f + bwd_f) / (ms_per_step * 1e-3) / 1e12,

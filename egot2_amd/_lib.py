@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # EGX_LIB (development aid): load a variant build (egot2_amd/_variants/lib_<name>.so, tools/build_variant.py) instead
 LIB_PATH = os.environ.get("EGX_LIB") or os.path.join(_PKG, "libegot2x.so")
 
-EGX_ABI_VERSION = 15
+EGX_ABI_VERSION = 16
 EGX_MAX_SEGMENTS = 8
 EGX_F32, EGX_BF16, EGX_F32_SPLIT = 0, 1, 2
 EGX_IMPL_AUTO, EGX_IMPL_GENERIC, EGX_IMPL_FUSED, EGX_IMPL_WIDE, EGX_IMPL_TILED = 0, 1, 2, 3, 4
@@ -55,12 +55,19 @@ class Config(C.Structure):
                 ("advance_seed", C.c_int), ("zero_buf", _fp), ("zero_bytes", C.c_size_t), ("bwd_stage", C.c_int),
                 ("deterministic", C.c_int), ("out_tokens", C.c_int), ("bucket_cb", C.c_void_p), ("bucket_user", C.c_void_p),
                 # ABI v15: persistent packed-weight cache, upstream gradient of a fused loss, fused weighted cross entropy
-                ("weight_cache", _fp), ("weight_cache_valid", C.c_int), ("d_logits_scale", _fp), ("ce", C.c_void_p)]
+                ("weight_cache", _fp), ("weight_cache_valid", C.c_int), ("d_logits_scale", _fp), ("ce", C.c_void_p),
+                ("token_ce", C.c_void_p)]
 
 
 class Ce(C.Structure):
     """egx_ce: weighted cross entropy on the pooled head's logits, evaluated by the translator forward itself."""
     _fields_ = [("target", _fp), ("class_weight", _fp), ("loss", _fp), ("d_logits", _fp)]
+
+
+class TokenCe(C.Structure):
+    """egx_token_ce: per-token classifier + weighted cross entropy on the tokens the encoder returns (the ASD task's lossAV)."""
+    _fields_ = [("W", _fp), ("b", _fp), ("target", _fp), ("class_weight", _fp), ("C", C.c_int), ("logits", _fp), ("probs", _fp), ("pred", _fp),
+                ("loss", _fp), ("correct", _fp), ("d_logits", _fp), ("d_W", _fp), ("d_b", _fp)]
 
 
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
@@ -94,6 +101,7 @@ SIGNATURES = {
     "egx_encoder_workspace": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int,
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "egx_encoder_uses_fused": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
+    "egx_encoder_token_ce_ok": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_encoder_impl": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_encoder_slices": (C.c_int, [C.POINTER(Config), C.POINTER(Segment), C.c_int]),
     "egx_wide_gemm_scratch": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

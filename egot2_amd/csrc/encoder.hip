@@ -559,6 +559,17 @@ int egx_encoder_workspace(const egx_config* cfg, const egx_segment* segs, int B,
     return 0;
 }
 
+// egx_config.token_ce is evaluated by the per-clip kernels of the one-launch mode only (one workgroup per clip, no cut, no slices, no pooled head),
+// with the arrival counter of the weight cache's control block
+static bool token_ce_ok(const egx_config* cfg, const egx_segment* segs, const Plan& pl) {
+    bool ferr;
+    if (!use_fused(cfg, segs, pl, &ferr)) return false;
+    if (!cfg->weight_cache || cfg->deterministic) return false;
+    if (pl.B > 4095) return false;      // (the arrival word: 12 bits of clips, 20 bits of correct frames)
+    const int ns = fused_slices(pl, cfg->compute);
+    return ns == 1 && !use_cut(pl, ns, false, cfg->compute);
+}
+
 // Bytes of the persistent packed-weight cache (egx_config.weight_cache): the fragment-packed copies of the per-clip / tiled kernels. The layout
 // is a function of the model dimensions and the compute mode only (fused_pack_layout), so one buffer serves every batch size.
 size_t egx_weight_cache_bytes(const egx_config* cfg, const egx_segment* segs) {
@@ -568,7 +579,13 @@ size_t egx_weight_cache_bytes(const egx_config* cfg, const egx_segment* segs) {
     if (pl.d != 128 || pl.nseg > FUSED_MAX_SEG || pl.L > FUSED_MAX_LAYERS || pl.L < 1 || pl.dff % 128 != 0) return 0;
     for (int i = 0; i < pl.nseg; ++i)
         if (!segs[i].proj_w || segs[i].d_in % 128 != 0) return 0;
-    return align_up(fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256);
+    return align_up(fused_pack_layout(cfg, segs, pl, nullptr).bytes, 256) + 256;      // + the control block (FusedFwdParams::ce_ticket / tce_ticket)
+}
+
+int egx_encoder_token_ce_ok(const egx_config* cfg, const egx_segment* segs, int B) {
+    Plan pl;
+    if (!cfg || !segs || make_plan(cfg, segs, B, pl)) return 0;
+    return token_ce_ok(cfg, segs, pl) ? 1 : 0;
 }
 
 int egx_encoder_uses_fused(const egx_config* cfg, const egx_segment* segs, int B) {
@@ -618,6 +635,12 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     EGX_CHECK(!ce || with_head, "egx_config.ce: the fused cross entropy needs the pooled head (egx_translator_fwd)");
     EGX_CHECK(!ce || (ce->target && ce->loss && ce->d_logits), "egx_config.ce: target, loss and d_logits must be set");
     EGX_CHECK(!cfg->weight_cache_valid || cfg->weight_cache, "weight_cache_valid without a weight_cache");
+    const egx_token_ce* tce = cfg->token_ce;
+    if (tce) {
+        EGX_CHECK(!with_head && token_ce_ok(cfg, segs, pl), "egx_config.token_ce: not on this configuration (egx_encoder_token_ce_ok)");
+        EGX_CHECK(tce->W && tce->target && tce->logits && tce->loss && tce->d_logits && tce->C >= 1 && tce->C <= 8,
+                  "egx_config.token_ce: W, target, logits, loss, d_logits and 1 <= C <= 8 must be set");
+    }
     EGX_CHECK(!with_head || (head->ln_w && head->ln_b && head->b && head->n_out >= 1 && head->n_out <= FUSED_HEAD_MAX_OUT),
               "head needs ln_w, ln_b, W, b and 1 <= n_out <= %d", FUSED_HEAD_MAX_OUT);
     // A HOST seed is baked into a captured graph: every replay would draw the SAME dropout masks — training that runs, converges worse and
@@ -723,8 +746,16 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fp.ce_target = ce->target; fp.ce_weight = ce->class_weight; fp.ce_loss = ce->loss; fp.ce_dlogits = ce->d_logits; fp.ce_B = B;
             if (pk.n || pk.seed_advance || pk.zero_words) pk.zero_word2 = ce->loss;
             else if (cut) fp.zero_word = ce->loss;
+            else if (cfg->weight_cache) fp.ce_ticket = (unsigned*)((char*)cfg->weight_cache + align_up(PL.bytes, 256));   // no earlier launch: arrival counter (5 us less than a memset node)
             else EGX_HIP(hipMemsetAsync(ce->loss, 0, sizeof(float), st));
         }
+        if (tce) {
+            fp.tce_W = tce->W; fp.tce_b = tce->b; fp.tce_target = tce->target; fp.tce_cw = tce->class_weight; fp.tce_C = tce->C;
+            fp.tce_logits = tce->logits; fp.tce_probs = tce->probs; fp.tce_pred = tce->pred; fp.tce_loss = tce->loss; fp.tce_correct = tce->correct;
+            fp.tce_dlogits = tce->d_logits;
+            fp.tce_ticket = (unsigned*)((char*)cfg->weight_cache + align_up(PL.bytes, 256)) + 4;      // words 4..6 of the control block
+        }
+        if (cfg->weight_cache && pk.n) pk.zero_ctl = (unsigned*)((char*)cfg->weight_cache + align_up(PL.bytes, 256));     // a launch that fills the cache also resets its control block
         if (pack_weights(pk, st)) return 1;
         // With a persistent weight cache nothing has just written the packed copies: every launch brings the streams its successor reads
         // first into the Infinity Cache (TouchList, fused.h)
@@ -881,7 +912,7 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
     Plan pl;
     if (make_plan(cfg, segs, B, pl)) return 1;
     const bool with_head = head && head->W;
-    EGX_CHECK((with_head ? (const void*)d_logits : (const void*)d_tokens) && saved && scratch && ln_w, "null pointer argument");
+    EGX_CHECK((with_head ? (const void*)d_logits : cfg->token_ce ? (const void*)cfg->token_ce->d_logits : (const void*)d_tokens) && saved && scratch && ln_w, "null pointer argument");
     {
         bool ferr, terr = false;
         const bool fused = use_fused(cfg, segs, pl, &ferr);
@@ -893,7 +924,12 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             Plan vp = pl;
             if (tiled) plan_tiled(vp);
             FusedPackLayout PL = fused_pack_layout(cfg, segs, vp, fused_pack_base(cfg, saved, vp));
-            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, with_head ? head->n_out : 0);
+            const egx_token_ce* tce = cfg->token_ce;
+            if (tce) {
+                EGX_CHECK(!with_head && !tiled && token_ce_ok(cfg, segs, pl), "egx_config.token_ce: not on this configuration (egx_encoder_token_ce_ok)");
+                EGX_CHECK(tce->W && tce->d_logits && tce->C >= 1 && tce->C <= 8, "egx_config.token_ce: W, d_logits and 1 <= C <= 8 must be set");
+            }
+            FusedBwdScratch SC = fused_bwd_scratch(cfg, segs, vp, with_head ? head->n_out : tce ? tce->C : 0);
             FusedBwdParams bp;
             memset(&bp, 0, sizeof(bp));
             const bool touch = cfg->weight_cache != nullptr && !tiled;      // (see the forward)
@@ -940,6 +976,11 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 bp.d_logits_scale = cfg->d_logits_scale;
                 bp.head_off = fused_partial_len(pl.L, pl.nseg);
                 if (tiled) bp.pooled = (const float*)((const char*)saved + tiled_tokens_offset(cfg, segs, vp)) + (size_t)N * d;
+            }
+            if (tce) {
+                bp.tce_W = tce->W; bp.tce_dlogits = tce->d_logits; bp.tce_C = tce->C;
+                bp.d_logits_scale = cfg->d_logits_scale;
+                bp.head_off = fused_partial_len(pl.L, pl.nseg);
             }
             bp.saved_pre = (const float*)saved;
             bp.saved_res = (const float*)saved + (size_t)N * d;
@@ -1059,6 +1100,11 @@ static int encoder_bwd_impl(const egx_config* cfg, const egx_segment* segs, cons
                 add_dst(head_grads->ln_w, oh, 128); add_dst(head_grads->ln_b, oh + 128, 128);
                 add_dst(head_grads->b, oh + 256, head->n_out);
                 add_dst(head_grads->W, oh + 256 + FUSED_HEAD_MAX_OUT, head->n_out * 128);
+            }
+            if (tce) {
+                int oh = fused_partial_len(pl.L, pl.nseg);
+                add_dst(tce->d_b, oh + 256, tce->C);
+                add_dst(tce->d_W, oh + 256 + FUSED_HEAD_MAX_OUT, tce->C * 128);
             }
             // learned positional table (the HOI translators' `pe`): sum d(token-prep output) over the clips, per segment
             if (bp.dx0_out && stage != 2)

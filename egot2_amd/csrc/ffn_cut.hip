@@ -475,7 +475,7 @@ __global__ __launch_bounds__(CT) void ffn_fwd_kernel(FusedFwdParams p, int l) {
     if (p.head.n_out > 0) {
         float* pooled = X1;
         // fused weighted cross entropy (egx_ce): the labels and their class weights are requested here, under the pooling
-        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B};
+        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B, nullptr};
         CeReq rq;
         if (ce.target) { ce_request_labels<CT>(ce, tid, rq); ce_request_weights(ce, p.head.n_out, rq); }
         if (tid < FD) pooled[tid] = colsum_lds(Y, 0, S, tid) * (1.f / (float)S);

@@ -101,6 +101,13 @@ struct FusedFwdParams {
     // ---- fused weighted cross entropy on the pooled head's logits (egx_ce, round 6; fused_dev.h FusedCe): evaluated by the launch that writes the logits
     const int64_t* ce_target; const float* ce_weight; float* ce_loss; float* ce_dlogits; int ce_B;
     float* zero_word;       // optional: one float the FIRST launch of a cut-mode forward zeroes (ce_loss: the FFN launch then adds into it)
+    // per-token classifier + weighted cross entropy on the returned tokens (egx_token_ce): the launch that normalises the last layer's tokens
+    const float* tce_W; const float* tce_b; const int64_t* tce_target; const float* tce_cw; int tce_C;
+    float* tce_logits; float* tce_probs; float* tce_pred; float* tce_loss; float* tce_correct; float* tce_dlogits;
+    unsigned* tce_ticket;   // {arrival counter, loss accumulator, correct-frame accumulator}, zero between launches (see ce_ticket)
+    unsigned* ce_ticket;    // optional: {arrival counter, float accumulator} in the weight cache's control block, both zero between launches:
+                            // the clips add their loss terms into the accumulator, the LAST one moves the sum to *ce_loss and leaves zeros
+                            // (a one-launch forward with a valid weight cache has no earlier launch that could zero *ce_loss)
     TouchList touch;        // weight streams of a later launch to bring into the Infinity Cache (see TouchList)
 };
 enum { FUSED_MODE_FULL = 0, FUSED_MODE_PRE = 1, FUSED_MODE_POST = 2, FUSED_MODE_ATTN = 3 };
@@ -118,6 +125,7 @@ struct PackParams {
     uint64_t* seed_advance;     // optional: *seed = lcg(*seed) by the first thread (egx_config.advance_seed)
     unsigned* zero_words; int n_zero;   // optional: words to zero (the arrival counters of the sliced mode)
     float* zero_word2;                  // optional: one more word to zero (the fused cross entropy's loss accumulator)
+    unsigned* zero_ctl;                 // optional: the weight cache's control block (ce_ticket / tce_ticket below, eight words), zeroed by a launch that packs
 };
 int pack_weights(PackParams& pp, hipStream_t st);
 static inline size_t packed_bytes(int R, int K, int mode) { return (size_t)R * K * (mode == 1 ? 2 : mode == 2 ? 6 : 4); }
@@ -222,6 +230,8 @@ struct FusedBwdParams {
     float* dy1;             // (Ntok, 128) gradient reaching LayerNorm1's output (FFN path + residual path)
     float* dxin;            // (Ntok, 128) gradient w.r.t. the input of layer cut_layer (= LayerNorm2 output of the layer below)
     const float* d_logits_scale;    // optional device scalar multiplied into d_logits (egx_config.d_logits_scale)
+    // egx_token_ce: d tokens = g * d_logits W rebuilt per clip, the clip's partial d W / d b rows in the head section of the partial row (head_off)
+    const float* tce_W; const float* tce_dlogits; int tce_C;
     TouchList touch;        // weight streams of a later launch to bring into the Infinity Cache (see TouchList)
 };
 int fused_backward(const FusedBwdParams& p, int compute, hipStream_t st);

@@ -22,6 +22,17 @@
 #include <type_traits>
 #include <vector>
 
+// bf16 FFN loop of the clip kernels software-pipelined across hidden blocks (see fused_fwd_kernel); 0 = the block-after-block loop of rounds 2-5
+#ifndef EGX_FFN_PIPE
+#define EGX_FFN_PIPE 1
+#endif
+#ifndef EGX_FFN_PIPE_RING
+#define EGX_FFN_PIPE_RING 8
+#endif
+#ifndef EGX_FFN_PIPE_VALU
+#define EGX_FFN_PIPE_VALU 6
+#endif
+
 namespace egx {
 
 __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
@@ -31,6 +42,7 @@ __global__ __launch_bounds__(64) void pack_weights_kernel(PackParams pp) {
     if (pp.zero_words)
         for (int i = blk * 64 + threadIdx.x; i < pp.n_zero; i += gridDim.x * 64) pp.zero_words[i] = 0u;
     if (pp.zero_word2 && blk == 0 && threadIdx.x == 0) *pp.zero_word2 = 0.f;
+    if (pp.zero_ctl && blk == 0 && threadIdx.x < 8) pp.zero_ctl[threadIdx.x] = 0u;     // (words 0-1: ce_ticket, 4-6: tce_ticket)
     if (pp.n == 0) return;      // nothing to pack (weight cache valid): the launch only carries the side jobs above
     int di = 0;
     while (di + 1 < pp.n && blk >= pp.d[di + 1].first_block) ++di;
@@ -191,6 +203,33 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
     } else {
         if (tid < FUSED_MAX_SEG) segtab[tid] = p.seg[tid];
     }
+    // egx_token_ce: the normaliser sum_i w[y_i] over every label of the batch and this thread's row label are fetched HERE, under the kernel's first
+    // loads — at the tail, where the classifier runs, each would be a bare memory round trip at the end of the launch (13 us per launch, measured)
+    float tce_sw = 0.f;         // (the wave's partial sum, in every lane)
+    int64_t tce_y = -1;
+    int64_t tce_lab[16];
+    if constexpr (!TILED && !SLICED && !CUT) if (p.tce_W) {
+        const int M = p.B * p.out_T;
+        float cw[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cw[c] = c < p.tce_C ? (p.tce_cw ? p.tce_cw[c] : 1.f) : 0.f;
+        tce_y = p.tce_target[(size_t)clip * p.out_T + min(tid >> 2, p.out_T - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tce_lab[u] = tid + u * 256 < M ? p.tce_target[tid + u * 256] : -1;     // (requested now, summed behind the staging below)
+        for (int i0 = tid + 256 * 16; i0 < M; i0 += 256 * 16) {       // batches beyond 4096 token rows: plain passes
+            int64_t y[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) y[u] = i0 + u * 256 < M ? p.tce_target[i0 + u * 256] : -1;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (c < p.tce_C) tce_sw += y[u] == c ? cw[c] : 0.f;
+        }
+        // the classifier itself into LDS (rows 12.. of the staged parameters: C weight rows, then [bias (8) | class weights (8)])
+        float* TW = PS + 12 * FD;
+        if (tid < p.tce_C * 32) *reinterpret_cast<f32x4*>(TW + tid * 4) = *reinterpret_cast<const f32x4*>(p.tce_W + tid * 4);
+        if (tid < 8) { TW[8 * FD + tid] = (tid < p.tce_C && p.tce_b) ? p.tce_b[tid] : 0.f; TW[8 * FD + 8 + tid] = tid < p.tce_C ? (p.tce_cw ? p.tce_cw[tid] : 1.f) : 0.f; }
+    }
     const int ps_g = tid >> 5, ps_c = (tid & 31) << 2;      // staging: thread (row group, 4 columns)
     {   // shared LayerNorm + task-embedding rows (a missing one repeats ln_w: never read)
         const int sg_i = ps_g - 2;
@@ -198,6 +237,16 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         const float* src = ps_g == 1 ? p.ln_b : (av && sg_i < p.nseg) ? av : p.ln_w;
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + ps_c);
         if (ps_g < 6) *reinterpret_cast<f32x4*>(PS + ps_g * FD + ps_c) = v;
+    }
+    if constexpr (!TILED && !SLICED && !CUT) if (p.tce_W) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < p.tce_C) {      // class weight by compare chain: no load that depends on the label
+                const float cwc = p.tce_cw ? p.tce_cw[c] : 1.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tce_sw += tce_lab[u] == c ? cwc : 0.f;
+            }
+        tce_sw = wsum(tce_sw);
     }
     __syncthreads();
     const int nseg_t = TILED ? *nseg_slot : p.nseg;
@@ -795,6 +844,163 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
                 for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hb0, lane);
             }
             LSTAMP_INIT();
+            // (training with dropout only: the epilogue without the mask is half as long, and a second instantiation of the pipelined loop costs ~60
+            // registers of hoisted loop invariants; the sliced instantiation has no registers left for the second set either: 37 spills)
+            bool ffn_done = false;
+            if constexpr (CM == CM_BF16 && EGX_FFN_PIPE && !SLICED) if (w.ffn_thresh) {
+                ffn_done = true;
+                // bf16 (round 6): ONE wave per SIMD and 16 cycles of matrix pipe per MFMA against ~280 VALU instructions of epilogue per hidden
+                // block: run block after block as [W1 x1 | epilogue | W2 H] and the matrix pipe idles through every epilogue (stamps: GEMM1 11.5k +
+                // epilogue 21.8k + GEMM2 10.6k of the 49k-cycle loop; 26 % busy). The three are independent ACROSS blocks, so the loop is
+                // software-pipelined: the epilogue of block `it` is issued together with GEMM1 of block it + 1 (into a second accumulator set)
+                // and GEMM2 of block it - 1 (from the operand fragments the previous epilogue left), one MFMA per ~6 VALU instructions
+                // (sched_group_barrier). The first GEMM2 meets zero fragments and the last GEMM1 is discarded: +2 / 16 of the MFMAs, all hidden.
+                {
+                    const uint32_t rowbase = TILED ? (uint32_t)tokbase : (uint32_t)(clip * 64);
+                    f32x4 hc[2][NT];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) hc[i][t] = f32x4{0, 0, 0, 0};
+                    {
+                        const int hb1 = hb_of(1 < nit ? 1 : 0);
+#pragma unroll
+                        for (int kb = 0; kb < FD / 32; ++kb)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                pin(w1r[i][kb]);
+                                Frag<CM> a = w_frag<CM>(w1r[i][kb]);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) mma<CM>(hc[i][t], a, xb[kb][t]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                w1r[i][kb] = load_w<CM>(w.lin1_wp, hb1 * 2 + i, FD / 32, kb, lane);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                    }
+                    // two register sets that swap roles from block to block (no copies): (pre-activations, operand fragments) of this block / the next
+                    f32x4 hc2[2][NT];
+                    Frag<CM> hqA[NT], hqB[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) hqA[t].v = __builtin_bit_cast(bf16x8, (u32x4){0u, 0u, 0u, 0u});
+                    auto step = [&](int it, f32x4 (&hc)[2][NT], f32x4 (&hn)[2][NT], const Frag<CM> (&hq_prev)[NT], Frag<CM> (&hq)[NT]) {
+                        const int hb = hb_of(it);
+                        const int hbn = hb_of(it + 1 < nit ? it + 1 : it);
+                        const int hb2 = hb_of(it + 2 < nit ? it + 2 : nit - 1);
+                        const int hbp = hb_of(it > 0 ? it - 1 : 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        LSTAMP(0);
+                        float bv[2][4];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            bv[i][0] = b1r[i].x * bscale; bv[i][1] = b1r[i].y * bscale; bv[i][2] = b1r[i].z * bscale; bv[i][3] = b1r[i].w * bscale;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) b1r[i] = *reinterpret_cast<const float4*>(w.lin1_b + hbn * 32 + i * 16 + 4 * q);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // 16 steps: one weight fragment's MFMAs (steps 0-7: GEMM1 of the NEXT block -> hn, the last iteration's is discarded; 8-15:
+                        // GEMM2 of the PREVIOUS block) + one slice of this block's epilogue. ONE ring of eight fragment slots (w1r) serves both
+                        // streams: a slot's fragment is requested eight steps (~1k cycles) before its MFMAs — a second set of eight costs 32 registers
+                        // the kernel does not have (the two accumulator / operand sets already take it to 512)
+                        // (2 NT slices bias + dropout of one 16 x 16 tile, NT slices alive bits + ReLU of eight units, NT slices operand fragment +
+                        // H tile of a token tile)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) hn[i][t] = f32x4{0, 0, 0, 0};
+                        uint32_t dead = 0;
+                        static_assert(4 * NT <= 16, "epilogue slices");
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            if (k < 8) {
+                                const int kb = k >> 1, i = k & 1;
+                                pin(w1r[i][kb]);
+                                Frag<CM> a = w_frag<CM>(w1r[i][kb]);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) mma<CM>(hn[i][t], a, xb[kb][t]);
+#if EGX_FFN_PIPE_RING == 16
+                                w1r[i][kb] = load_w<CM>(w.lin1_wp, hb2 * 2 + i, FD / 32, kb, lane);
+#else
+                                w1r[i][kb] = load_w<CM>(w.lin2_wp, k, nhb, hbp, lane);             // slot k: W2 fragment k, needed eight steps on
+#endif
+                            } else {
+                                const int j = k - 8, i = j & 1, kb = j >> 1;
+#if EGX_FFN_PIPE_RING == 16
+                                pin(w2r[j]);
+                                Frag<CM> a = w_frag<CM>(w2r[j]);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) mma<CM>(y[j][t], a, hq_prev[t]);
+                                w2r[j] = load_w<CM>(w.lin2_wp, j, nhb, hb, lane);
+#else
+                                pin(w1r[i][kb]);
+                                Frag<CM> a = w_frag<CM>(w1r[i][kb]);
+#pragma unroll
+                                for (int t = 0; t < NT; ++t) mma<CM>(y[j][t], a, hq_prev[t]);
+                                w1r[i][kb] = load_w<CM>(w.lin1_wp, hb2 * 2 + i, FD / 32, kb, lane);   // slot j: W1 fragment j of the block after next
+#endif
+                            }
+                            if (k < 2 * NT) {
+                                const int i = k / NT, t = k % NT;
+                                if constexpr (true) {
+                                    const uint32_t cq = (uint32_t)(hb * 32 + i * 16 + 4 * q) >> 2;
+                                    const uint2 h = rand_quad(k_ffn, rowbase + (uint32_t)(t * 16 + r), cq);
+                                    // dropped units become negative: the ReLU zeroes them and their sign bit marks them dead
+                                    hc[i][t][0] = keep_lo(h.x, w.ffn_thresh) ? hc[i][t][0] + bv[i][0] : -1.f;
+                                    hc[i][t][1] = keep_hi(h.x, w.ffn_thresh) ? hc[i][t][1] + bv[i][1] : -1.f;
+                                    hc[i][t][2] = keep_lo(h.y, w.ffn_thresh) ? hc[i][t][2] + bv[i][2] : -1.f;
+                                    hc[i][t][3] = keep_hi(h.y, w.ffn_thresh) ? hc[i][t][3] + bv[i][3] : -1.f;
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) hc[i][t][e] += bv[i][e];
+                                }
+                            } else if (k < 3 * NT) {
+                                const int j = k - 2 * NT;       // units 8 (NT - j) - 1 .. 8 (NT - 1 - j): the word's bit order is the loop's below
+#pragma unroll
+                                for (int kk = 8 * (NT - j) - 1; kk >= 8 * (NT - 1 - j); --kk) {
+                                    const int i = kk / (NT * 4), t = (kk / 4) % NT, e = kk & 3;
+                                    dead = __builtin_amdgcn_alignbit(dead, __float_as_uint(hc[i][t][e]), 31);
+                                    hc[i][t][e] = __int_as_float(max(__float_as_int(hc[i][t][e]), 0));
+                                }
+                                if (k == 3 * NT - 1) p.relu_bits[bits_base + (size_t)hb * 64] = ~dead & ((1u << (2 * NT * 4)) - 1u);
+                            } else if (k < 4 * NT) {
+                                const int t = k - 3 * NT;
+                                hq[t] = chain_frag<CM>(hc[0][t], hc[1][t]);
+                                const u32x4 u = __builtin_bit_cast(u32x4, hq[t].v);
+                                store_hid_tile_bf16(hid_base + (size_t)hb * 2 * (HTILE_ELEMS * ESZ) + (size_t)t * nht * (HTILE_ELEMS * ESZ), u, lane, S - t * 16);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        LSTAMP(3);
+                    };
+                    auto last_gemm2 = [&](const Frag<CM> (&hq_last)[NT]) {      // (its W2 columns are requested here: one exposed round trip per layer)
+#if EGX_FFN_PIPE_RING != 16
+                        const int hbl = hb_of(nit - 1);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) w2r[i] = load_w<CM>(w.lin2_wp, i, nhb, hbl, lane);
+#endif
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            Frag<CM> a = w_frag<CM>(w2r[i]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mma<CM>(y[i][t], a, hq_last[t]);
+                        }
+                    };
+                    int it = 0;
+                    for (; it + 1 < nit; it += 2) {
+                        step(it, hc, hc2, hqA, hqB);
+                        step(it + 1, hc2, hc, hqB, hqA);
+                    }
+                    if (it < nit) {     // odd block count (narrow FFNs, deep slicing)
+                        step(it, hc, hc2, hqA, hqB);
+                        last_gemm2(hqB);
+                    } else {
+                        last_gemm2(hqA);
+                    }
+                    LSTAMP(4);
+                }
+            }
+            if (!ffn_done)
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
                 const int hbn = hb_of(it + 1 < nit ? it + 1 : it);     // the last block refills itself (never used)
@@ -993,7 +1199,7 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
             bool last = (l + 1 == p.n_layers);
             ln_rows_lds(X1, S, PS + 9 * FD, PS + 10 * FD, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
                 if (last && p.tokens_out && (TILED || row < p.out_T)) store32(p.tokens_out + (TILED ? tokbase + row : (size_t)clip * p.out_T + row) * FD + c0, y);
-                if (!last || p.head.n_out > 0) store32(Xs + row * LDX + c0, y);
+                if (!last || p.head.n_out > 0 || p.tce_W) store32(Xs + row * LDX + c0, y);
             }, [&] { store_block(sv_res2, X1, S); });        // (the LayerNorm leaves X1 alone)
         }
         __syncthreads();
@@ -1004,11 +1210,101 @@ __global__ __launch_bounds__(256, 1) void fused_fwd_kernel(FusedFwdParams p) {
         }
     }
 
+    // ---- optional per-token classifier + weighted cross entropy on the returned tokens (egx_token_ce; the arithmetic of linear_ce_fwd_kernel,
+    // train.hip): four lanes per token row, the clip's loss / correct-frame terms through the arrival counter (no launch in front that could zero them)
+    if constexpr (!TILED && !SLICED && !CUT) if (p.tce_W) {
+        constexpr int MAXC = 8;
+        float* red = X1;                        // scratch (X1 is dead)
+        const int C = p.tce_C;
+        const float* TW = PS + 12 * FD;         // classifier rows, bias, class weights: staged at kernel entry
+        float cw[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) cw[c] = TW[8 * FD + 8 + c];
+        auto wof = [&](int64_t y) {             // class weight by compare chain: no load that depends on the label
+            float wv = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) wv = y == c ? cw[c] : wv;
+            return wv;
+        };
+        STAMP(11);
+        if (lane == 0) red[wave] = tce_sw;      // the normaliser: every workgroup sums it itself, in the same order (at kernel entry)
+        const int row = tid >> 2, part = tid & 3;
+        const bool live = row < p.out_T;
+        const size_t grow = (size_t)clip * p.out_T + (live ? row : 0);
+        const int64_t yrow = tce_y;
+        float acc[MAXC];
+        {
+            float x[32];
+            load32(Xs + (live ? row : 0) * LDX + part * 32, x);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                acc[c] = 0.f;
+                if (c < C) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 wv = *reinterpret_cast<const float4*>(TW + c * FD + part * 32 + 4 * j);
+                        a += (x[4 * j] * wv.x + x[4 * j + 1] * wv.y) + (x[4 * j + 2] * wv.z + x[4 * j + 3] * wv.w);
+                    }
+                    acc[c] = quad_sum4(a) + TW[8 * FD + c];
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(12);
+        const float wtot = (red[0] + red[1]) + (red[2] + red[3]);
+        const float inv = 1.f / wtot;
+        float lterm = 0.f, cterm = 0.f;
+        if (live && part == 0) {
+            float m = acc[0];
+#pragma unroll
+            for (int c = 1; c < MAXC; ++c) if (c < C) m = fmaxf(m, acc[c]);
+            float e[MAXC], ssum = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) { e[c] = c < C ? __expf(acc[c] - m) : 0.f; ssum += e[c]; }
+            const float rs = 1.f / ssum;
+            const bool ok = yrow >= 0 && yrow < C;
+            const float wy = ok ? wof(yrow) : 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    p.tce_logits[grow * C + c] = acc[c];
+                    if (p.tce_probs) p.tce_probs[grow * C + c] = e[c] * rs;
+                    p.tce_dlogits[grow * C + c] = ok ? wy * inv * (e[c] * rs - (c == (int)yrow ? 1.f : 0.f)) : 0.f;
+                    if (ok && c == (int)yrow) lterm += wy * (m + __logf(ssum) - acc[c]);
+                }
+            const float pl = C > 1 ? rintf(e[1] * rs) : 0.f;
+            if (p.tce_pred) p.tce_pred[grow] = pl;
+            if (C > 1 && pl == (float)yrow) cterm += 1.f;
+        }
+        lterm = wsum(lterm); cterm = wsum(cterm);
+        if (lane == 0) { red[4 + wave] = lterm; red[8 + wave] = cterm; }
+        __syncthreads();
+        STAMP(13);
+        if (tid == 0) {
+            const float l = ((red[4] + red[5]) + (red[6] + red[7])) * inv, cn = (red[8] + red[9]) + (red[10] + red[11]);
+            // ONE returning atomic per clip: the arrival word counts clips in its low 12 bits and correct frames above them (every atomic on
+            // this line waits for the other clips' — 256 of them finish together: three per clip cost 8 us at the end of the launch, measured)
+            float* tacc = reinterpret_cast<float*>(p.tce_ticket + 1);
+            atomicAdd(tacc, l);
+            __threadfence();
+            const unsigned mine = 1u + ((unsigned)cn << 12);
+            const unsigned old = atomicAdd(p.tce_ticket, mine);
+            if ((old & 4095u) == (unsigned)p.B - 1u) {      // last clip of the launch: publish, leave zeros
+                __threadfence();
+                *p.tce_loss = atomicExch(tacc, 0.f);
+                if (p.tce_correct) *p.tce_correct = (float)((old + mine) >> 12);
+                atomicExch(p.tce_ticket, 0u);
+            }
+        }
+        STAMP(14);
+    }
+
     // ---- optional pooled head: logits = Linear(LN(mean_s tokens)); tokens of the last layer are in Xs
     if (!TILED && p.head.n_out > 0) {
         float* pooled = X1;                      // 128 floats of scratch (X1 is dead)
         // fused weighted cross entropy (egx_ce): the labels and their class weights are requested here, under the pooling
-        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B};
+        const FusedCe ce{p.ce_target, p.ce_weight, p.ce_loss, p.ce_dlogits, p.ce_B, p.ce_ticket};
         CeReq rq;
         if (ce.target) { ce_request_labels<256>(ce, tid, rq); ce_request_weights(ce, p.head.n_out, rq); }
         if (tid < FD) pooled[tid] = colsum_lds(Xs, 0, S, tid) * (1.f / (float)S);
@@ -1078,7 +1374,7 @@ int timing_read(int which, double* total_ms, int* count) {
 
 size_t fused_lds_bytes(int NT) {
     int SP = NT * 16;
-    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16 + 12 * FD * sizeof(float);     // + the staged parameter rows
+    return (size_t)(4 * SP * LDX + FD * LDV) * sizeof(float) + FUSED_MAX_SEG * sizeof(FusedSeg) + 16 + 21 * FD * sizeof(float);     // + the staged parameter rows (12) and the token classifier (8 + 1)
 }
 
 bool fused_supported(int d_model, int n_heads, int d_ff, int S, int nseg, const int* d_in, const int* T, const bool* has_proj) {

@@ -252,9 +252,15 @@ __global__ __launch_bounds__(256, HT == 1 ? 2 : 1) void ffn_dw_kernel(FfnDwParam
 // registers and half the LDS, so FOUR workgroups share a CU where two did. ffn_dw_split2_kernel launches both parts as one grid (blockIdx.z).
 // NW (round 6, f32s PART workgroups only): 8 = eight waves share the staged operand image (hidden group of 128: the x1 / g planes are fetched
 // once per 128 hidden units instead of once per 64 — 805 -> 510 MB through the CUs' address paths per launch)
-template <int CM, int OCC, int PART, int NW = 4>
+// NH (round 6, f32s PART workgroups only; tuning aid EGX_FFN_DW_W8=42 | 82): hidden tiles per wave. A wave's 8 token-along-K fragments of the x1 / g
+// image (48 transposing LDS reads of 512 B per K-block) meet NH H / dH fragments: at NH = 1 the kernel issues ONE LDS read per MFMA (SQ counters,
+// profiles/r06_pmc_c2_f32s.json: 5.0 M LDS instructions for 4.7 M MFMAs, 49 % MFMA busy), NH = 2 halves that without splitting any H / dH tile twice.
+// Measured SLOWER: c2 f32s step 351 / 357 us (NH = 1, eight waves) vs 362 / 365 (NH = 2, four waves, three workgroups per CU) vs 371 / 372 (NH = 2, eight
+// waves, one per CU): the kernel wants four independent waves per SIMD more than it wants fewer LDS reads. Default unchanged.
+template <int CM, int OCC, int PART, int NW = 4, int NH = 1>
 __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
     static_assert(NW == 4 || ((NW == 8 || NW == 16) && CM == CM_SPLIT && PART != 0), "eight / sixteen waves: the f32s PART workgroups only");
+    static_assert(NH == 1 || (CM == CM_SPLIT && PART != 0), "several hidden tiles per wave: the f32s PART workgroups only");
     constexpr bool W1 = PART != 2, W2 = PART != 1;
     constexpr bool BF16 = CM == CM_BF16;
     constexpr bool SPLIT = CM == CM_SPLIT;
@@ -273,17 +279,21 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
         const int nwg = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
         if ((nwg & 7) == 0) { const int t = (id & 7) * (nwg >> 3) + (id >> 3); by = t / gridDim.x; bx = t - by * gridDim.x; }
     }
-    const int htile = bx * NW + wave, split = by;
+    const int htile = (bx * NW + wave) * NH, split = by;      // (first of the wave's NH hidden tiles)
     const int nht = p.d_ff / 16;
     const int ntile = p.B * FUSED_TOK_TILES;
     const int nkb_total = (ntile + 1) / 2;
     const int kb_beg = split * p.kb_per_split;
     const int kb_end = min(nkb_total, kb_beg + p.kb_per_split);
 
-    f32x4 accW1[8], accW2[8];
+    f32x4 accW1[W1 ? NH : 1][8], accW2[W2 ? NH : 1][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { accW1[j] = f32x4{0, 0, 0, 0}; accW2[j] = f32x4{0, 0, 0, 0}; }
-    float accB1 = 0.f;
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if constexpr (W1) accW1[h][j] = f32x4{0, 0, 0, 0}; if constexpr (W2) accW2[h][j] = f32x4{0, 0, 0, 0}; }
+    float accB1[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) accB1[h] = 0.f;
     float accB4[4] = {0.f, 0.f, 0.f, 0.f};      // CM_BF16: db1 partials of hidden units 4q..4q+3 over this lane's token
 
     constexpr int LDB = 144;
@@ -298,7 +308,7 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
     // into operands after the prefetch has landed)
     struct HidRaw { float4 a, b; };
     struct HidRawB { uint2 a, b; };
-    typename std::conditional<BF16, HidRawB, HidRaw>::type nH, nD;
+    typename std::conditional<BF16, HidRawB, HidRaw>::type nH[NH], nD[NH];
     // CM_SPLIT: x1 / g arrive as three bf16 planes ([part][N][128], written by the clip-parallel kernels); a thread moves two rows x
     // 16 B of every (tensor, part) image: no split work here (the 32 workgroups of a token range used to repeat it)
     uint4 prs[SPLIT ? 12 : 1];
@@ -345,18 +355,22 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
         int ta = kb * 2, tb = min(kb * 2 + 1, ntile - 1);     // a missing second tile meets zero x1 / g rows
         size_t oa = ((size_t)ta * nht + htile) * (HTILE_ELEMS * ESZ), ob = ((size_t)tb * nht + htile) * (HTILE_ELEMS * ESZ);
         if constexpr (BF16) {
-            nH.a = reinterpret_cast<const uint2*>((const char*)p.hs + oa)[lane];
-            nH.b = reinterpret_cast<const uint2*>((const char*)p.hs + ob)[lane];
-            nD.a = reinterpret_cast<const uint2*>((const char*)p.dhs + oa)[lane];
-            nD.b = reinterpret_cast<const uint2*>((const char*)p.dhs + ob)[lane];
+            nH[0].a = reinterpret_cast<const uint2*>((const char*)p.hs + oa)[lane];
+            nH[0].b = reinterpret_cast<const uint2*>((const char*)p.hs + ob)[lane];
+            nD[0].a = reinterpret_cast<const uint2*>((const char*)p.dhs + oa)[lane];
+            nD[0].b = reinterpret_cast<const uint2*>((const char*)p.dhs + ob)[lane];
         } else {
-            if constexpr (W2) {
-                nH.a = reinterpret_cast<const float4*>((const char*)p.hs + oa)[lane];
-                nH.b = reinterpret_cast<const float4*>((const char*)p.hs + ob)[lane];
-            }
-            if constexpr (W1) {
-                nD.a = reinterpret_cast<const float4*>((const char*)p.dhs + oa)[lane];
-                nD.b = reinterpret_cast<const float4*>((const char*)p.dhs + ob)[lane];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {      // (consecutive hidden tiles of a token tile are consecutive in memory)
+                const size_t oh = (size_t)h * (HTILE_ELEMS * ESZ);
+                if constexpr (W2) {
+                    nH[h].a = reinterpret_cast<const float4*>((const char*)p.hs + oa + oh)[lane];
+                    nH[h].b = reinterpret_cast<const float4*>((const char*)p.hs + ob + oh)[lane];
+                }
+                if constexpr (W1) {
+                    nD[h].a = reinterpret_cast<const float4*>((const char*)p.dhs + oa + oh)[lane];
+                    nD[h].b = reinterpret_cast<const float4*>((const char*)p.dhs + ob + oh)[lane];
+                }
             }
         }
     };
@@ -443,14 +457,17 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
         }
         lstore(cur);
         const bool has_b = kb * 2 + 1 < ntile;      // odd tile count: the last block's second half is a duplicate
-        Frag<CM> aH, aD;
+        Frag<CM> aH[NH], aD[NH];
         if constexpr (!BF16) {
-            if constexpr (W1) {
-                float s0 = (nD.a.x + nD.a.y) + (nD.a.z + nD.a.w), s1 = (nD.b.x + nD.b.y) + (nD.b.z + nD.b.w);
-                accB1 += s0 + (has_b ? s1 : 0.f);
-                aD = make_frag<CM>(nD.a, nD.b);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                if constexpr (W1) {
+                    float s0 = (nD[h].a.x + nD[h].a.y) + (nD[h].a.z + nD[h].a.w), s1 = (nD[h].b.x + nD[h].b.y) + (nD[h].b.z + nD[h].b.w);
+                    accB1[h] += s0 + (has_b ? s1 : 0.f);
+                    aD[h] = make_frag<CM>(nD[h].a, nD[h].b);
+                }
+                if constexpr (W2) aH[h] = make_frag<CM>(nH[h].a, nH[h].b);
             }
-            if constexpr (W2) aH = make_frag<CM>(nH.a, nH.b);
         } else {
             // CM_BF16: tiles arrive in accumulator layout (lane = token r, 4 hidden units 4q..4q+3). Stage this wave's two
             // K-blocks ([32 tokens][16 hidden] bf16, unpadded 32-byte rows: writes and transposed reads are conflict-free) and
@@ -472,15 +489,15 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
                     *reinterpret_cast<uint2*>(d + 1024) = make_uint2(l0, l1);
                 }
             };
-            put(0, 0, nH.a); put(0, 1, nH.b); put(1, 0, nD.a); put(1, 1, nD.b);
+            put(0, 0, nH[0].a); put(0, 1, nH[0].b); put(1, 0, nD[0].a); put(1, 1, nD[0].b);
             if constexpr (BF16) {
-                accB4[0] += __uint_as_float(nD.a.x << 16) + (has_b ? __uint_as_float(nD.b.x << 16) : 0.f);
-                accB4[1] += __uint_as_float(nD.a.x & 0xffff0000u) + (has_b ? __uint_as_float(nD.b.x & 0xffff0000u) : 0.f);
-                accB4[2] += __uint_as_float(nD.a.y << 16) + (has_b ? __uint_as_float(nD.b.y << 16) : 0.f);
-                accB4[3] += __uint_as_float(nD.a.y & 0xffff0000u) + (has_b ? __uint_as_float(nD.b.y & 0xffff0000u) : 0.f);
+                accB4[0] += __uint_as_float(nD[0].a.x << 16) + (has_b ? __uint_as_float(nD[0].b.x << 16) : 0.f);
+                accB4[1] += __uint_as_float(nD[0].a.x & 0xffff0000u) + (has_b ? __uint_as_float(nD[0].b.x & 0xffff0000u) : 0.f);
+                accB4[2] += __uint_as_float(nD[0].a.y << 16) + (has_b ? __uint_as_float(nD[0].b.y << 16) : 0.f);
+                accB4[3] += __uint_as_float(nD[0].a.y & 0xffff0000u) + (has_b ? __uint_as_float(nD[0].b.y & 0xffff0000u) : 0.f);
             } else {
-                accB4[0] += nD.a.x + (has_b ? nD.b.x : 0.f); accB4[1] += nD.a.y + (has_b ? nD.b.y : 0.f);
-                accB4[2] += nD.a.z + (has_b ? nD.b.z : 0.f); accB4[3] += nD.a.w + (has_b ? nD.b.w : 0.f);
+                accB4[0] += nD[0].a.x + (has_b ? nD[0].b.x : 0.f); accB4[1] += nD[0].a.y + (has_b ? nD[0].b.y : 0.f);
+                accB4[2] += nD[0].a.z + (has_b ? nD[0].b.z : 0.f); accB4[3] += nD[0].a.w + (has_b ? nD[0].b.w : 0.f);
             }
             auto get = [&](int tensor) {
                 const int i = lane & 15;
@@ -495,38 +512,52 @@ __device__ __forceinline__ void ffn_dw_stored_body(const FfnDwParams& p) {
                 }
                 return f;
             };
-            aH = get(0);
-            aD = get(1);
+            aH[0] = get(0);
+            aD[0] = get(1);
         }
         __syncthreads();
         if ((PF || PF1) && kb + 1 < kb_end) gload(kb + 1);
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            if constexpr (W1) { Frag<CM> bx = tok_frag(cur, 0, jt); mma<CM>(accW1[jt], aD, bx); }
-            if constexpr (W2) { Frag<CM> bg = tok_frag(cur, 1, jt); mma<CM>(accW2[jt], aH, bg); }
+            if constexpr (W1) {
+                Frag<CM> bx = tok_frag(cur, 0, jt);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) mma<CM>(accW1[h][jt], aD[h], bx);
+            }
+            if constexpr (W2) {
+                Frag<CM> bg = tok_frag(cur, 1, jt);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) mma<CM>(accW2[h][jt], aH[h], bg);
+            }
         }
         if constexpr (PF) cur ^= 1;
     }
 
     float* sw1 = p.slab_w1 + (size_t)split * p.d_ff * FD;
     float* sw2 = p.slab_w2t + (size_t)split * p.d_ff * FD;
-    const int hrow = htile * 16 + 4 * q;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt) {
-        if constexpr (W1) {
+    for (int h = 0; h < NH; ++h) {
+        const int hrow = (htile + h) * 16 + 4 * q;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[jt][e];
+        for (int jt = 0; jt < 8; ++jt) {
+            if constexpr (W1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sw1[(size_t)(hrow + e) * FD + jt * 16 + r] = accW1[h][jt][e];
+            }
+            if constexpr (W2)
+                *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
+                    make_float4(accW2[h][jt][0], accW2[h][jt][1], accW2[h][jt][2], accW2[h][jt][3]);
         }
-        if constexpr (W2)
-            *reinterpret_cast<float4*>(sw2 + (size_t)(jt * 16 + r) * p.d_ff + hrow) =
-                make_float4(accW2[jt][0], accW2[jt][1], accW2[jt][2], accW2[jt][3]);
     }
     if constexpr (!BF16) {
         if constexpr (W1) {
-            float bs = accB1;
-            bs += __shfl_xor(bs, 16, 64);
-            bs += __shfl_xor(bs, 32, 64);
-            if (q == 0) p.slab_b1[(size_t)split * p.d_ff + htile * 16 + r] = bs;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float bs = accB1[h];
+                bs += __shfl_xor(bs, 16, 64);
+                bs += __shfl_xor(bs, 32, 64);
+                if (q == 0) p.slab_b1[(size_t)split * p.d_ff + (htile + h) * 16 + r] = bs;
+            }
         }
     } else {
 #pragma unroll
@@ -550,6 +581,16 @@ __global__ __launch_bounds__(512, 2) void ffn_dw_split2w8_kernel(FfnDwParams p) 
     if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 8>(p);
     else ffn_dw_stored_body<CM_SPLIT, 2, 2, 8>(p);
 }
+// two hidden tiles per wave (NH = 2): four waves per workgroup = a hidden group of 128 like the eight-wave grid, three workgroups per CU (<= 168 registers)
+__global__ __launch_bounds__(256, 3) void ffn_dw_split2h2_kernel(FfnDwParams p) {
+    if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 4, 2>(p);
+    else ffn_dw_stored_body<CM_SPLIT, 2, 2, 4, 2>(p);
+}
+// ... and eight waves: a hidden group of 256
+__global__ __launch_bounds__(512, 1) void ffn_dw_split2w8h2_kernel(FfnDwParams p) {
+    if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 8, 2>(p);
+    else ffn_dw_stored_body<CM_SPLIT, 2, 2, 8, 2>(p);
+}
 __global__ __launch_bounds__(1024, 1) void ffn_dw_split2w16_kernel(FfnDwParams p) {
     if (blockIdx.z == 0) ffn_dw_stored_body<CM_SPLIT, 2, 1, 16>(p);
     else ffn_dw_stored_body<CM_SPLIT, 2, 2, 16>(p);
@@ -564,8 +605,8 @@ __global__ __launch_bounds__(1024, 1) void ffn_dw_split2w16_kernel(FfnDwParams p
 // + 4 waves x 4 tiles of 512 B (accumulator layout, read back token-along-K by ds_read_b64_tr_b16 as they lie). 256 threads,
 // two independent workgroups per CU.
 #define EGX_RING_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-// NW waves per workgroup share the staged x1 / g images (round 6: the kernel is bound by the bytes a CU pulls from L2 — with four waves 24 KB per
-// K-block for 64 MFMAs; the images are 16 KB of it); D ring stages.
+// NW waves per workgroup share the staged x1 / g images (round 6: with four waves 24 KB per K-block for 64 MFMAs, the images 16 KB of it; eight and
+// sixteen waves measured SLOWER, 201 -> 205-219 us on the c2 bf16 step: the default stays four); D ring stages.
 template <int NW, int D>
 __device__ __forceinline__ void ffn_dw_bf16_ring_body(const FfnDwParams& p) {
     constexpr int CM = CM_BF16;
@@ -863,11 +904,21 @@ static int launch_ffn_dw(FfnDwParams p, hipStream_t st) {
                 attr4_set = true;
             }
             // Round 6: EIGHT waves per workgroup share one staged operand image (hidden group of 128). With four, the launch moved 805 MB through
-            // the CUs' address paths (24 KB of x1 / g planes + 8 KB of H / dH tiles per K-block and workgroup: ~30 B / clk / CU, the rate a CU pulls
-            // from L2 at best), 590 MB of it the planes that every hidden group of a token range re-reads; with eight 510 MB. 76.5 -> 64.0 us,
+            // the CUs' address paths (24 KB of x1 / g planes + 8 KB of H / dH tiles per K-block and workgroup), 590 MB of it the planes that every
+            // hidden group of a token range re-reads; with eight 510 MB and half the staging instructions per MFMA. 76.5 -> 64.0 us,
             // step 371 -> 360 us (three same-box pairs, profiles/r06_ab_ffn_dw_w8.txt); sixteen waves (one workgroup per CU) measured the same as
             // eight. EGX_FFN_DW_W8 = 0 | 16 selects the four- / sixteen-wave grids (tuning aid).
             static const int w8 = [] { const char* e = getenv("EGX_FFN_DW_W8"); return e ? atoi(e) : 8; }();
+            if ((w8 == 42 || w8 == 82) && p.d_ff % 256 == 0) {      // NH = 2 variants (42: four waves, 82: eight)
+                static bool attr7_set = false;
+                if (!attr7_set) {
+                    EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
+                    EGX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_dw_split2w8h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds / 2)));
+                    attr7_set = true;
+                }
+                if (w8 == 42) hipLaunchKernelGGL(ffn_dw_split2h2_kernel, dim3(p.d_ff / 128, grid.y, 2), dim3(256), lds / 2, st, p);
+                else hipLaunchKernelGGL(ffn_dw_split2w8h2_kernel, dim3(p.d_ff / 256, grid.y, 2), dim3(512), lds / 2, st, p);
+            } else
             if (w8 == 16 && p.d_ff % 256 == 0) {
                 static bool attr6_set = false;
                 if (!attr6_set) {
@@ -1609,7 +1660,7 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
     }
     // res2 -> B1 (LayerNorm2 backward; with the fused head also -> Gs, normalised in place below), res1 -> B5 (P3 / P5)
     if constexpr (!TILED && !CUT) {
-    blk_store(pf_a, B1, p.head.n_out > 0 ? Gs : nullptr);
+    blk_store(pf_a, B1, (p.head.n_out > 0 || p.tce_W) ? Gs : nullptr);
     blk_store(pf_b, B5, nullptr);
     touch_sink(tch);
     if (p.head.n_out > 0) {
@@ -1656,6 +1707,48 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
         for (int i = tid; i < S * (FD / 4); i += 256) {
             int row = i >> 5, c = (i & 31) << 2;
             *reinterpret_cast<float4*>(Gs + row * LDX + c) = *reinterpret_cast<const float4*>(pooled + 128 + c);
+        }
+        __syncthreads();
+    } else if (p.tce_W) {
+        // egx_token_ce: the forward left d loss / d logits of the clip's out_T token rows. Rebuild the tokens y = LN2(res2) (for d W), leave the clip's
+        // partial d b / d W rows in the head section of its partial row, then d tokens = g * d_logits W into Gs (rows >= out_T: no upstream gradient)
+        const FusedBwdLayer& wl = p.layer[p.n_layers - 1];
+        float* hp = part + p.head_off;
+        const int C = p.tce_C;
+        __syncthreads();
+        ln_rows(Gs, S, wl.norm2_w, wl.norm2_b, p.eps, [&](int row, int c0, float (&x)[32], float (&y)[32]) {
+            store32(Gs + row * LDX + c0, y);
+        });
+        float* gos = B2;           // [row][8]: g * d_logits
+        const float g = p.d_logits_scale ? *p.d_logits_scale : 1.f;
+        for (int i = tid; i < p.out_T * 8; i += 256) {
+            const int row = i >> 3, o = i & 7;
+            gos[i] = o < C ? p.tce_dlogits[((size_t)clip * p.out_T + row) * C + o] * g : 0.f;
+        }
+        __syncthreads();
+        if (tid < FD) {
+            for (int o = 0; o < C; ++o) {
+                float a = 0.f;
+                for (int row = 0; row < p.out_T; ++row) a += gos[row * 8 + o] * Gs[row * LDX + tid];
+                hp[256 + FUSED_HEAD_MAX_OUT + o * FD + tid] = a;
+            }
+        } else if (tid < FD + C) {
+            const int o = tid - FD;
+            float a = 0.f;
+            for (int row = 0; row < p.out_T; ++row) a += gos[row * 8 + o];
+            hp[256 + o] = a;
+        }
+        __syncthreads();        // the token rows are consumed
+        for (int i = tid; i < S * (FD / 4); i += 256) {
+            const int row = i >> 5, c = (i & 31) << 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.out_T)
+                for (int o = 0; o < C; ++o) {
+                    const float go = gos[row * 8 + o];
+                    const float4 wv = *reinterpret_cast<const float4*>(p.tce_W + (size_t)o * FD + c);
+                    v.x += go * wv.x; v.y += go * wv.y; v.z += go * wv.z; v.w += go * wv.w;
+                }
+            *reinterpret_cast<float4*>(Gs + row * LDX + c) = v;
         }
         __syncthreads();
     } else {        // rows >= out_T carry no upstream gradient (LDS is zero there)

@@ -367,6 +367,7 @@ struct FusedCe {
     float* loss;                // scalar: zero when the launch starts, every clip adds its term
     float* d_logits;            // (B, n_out)
     int B;                      // clips of the BATCH (the normaliser's range)
+    unsigned* ticket;           // null, or {arrival counter, accumulator}: see FusedFwdParams::ce_ticket
 };
 // all NTHREADS threads: per-wave partial sums of the normaliser -> red[wave]; the caller puts a barrier behind it. `y` / `wy` are requested by
 // ce_request() ahead of a phase that hides the two dependent round trips (label, then its class weight).
@@ -418,7 +419,17 @@ __device__ __forceinline__ void ce_clip(const FusedCe& ce, int n_out, int clip, 
     if (lane == 0 && add_loss) {
         float term = valid ? k * (m + __logf(s) - zy) : 0.f;
         if (wtot == 0.f && clip == 0) term = __builtin_nanf("");    // no valid label in the batch: 0 / 0 like the reference
-        atomicAdd(ce.loss, term);
+        if (!ce.ticket) {
+            atomicAdd(ce.loss, term);
+        } else {
+            float* acc = reinterpret_cast<float*>(ce.ticket + 1);
+            atomicAdd(acc, term);
+            __threadfence();
+            if (atomicInc(ce.ticket, (unsigned)ce.B - 1u) == (unsigned)ce.B - 1u) {     // last clip of the launch (the counter wraps to zero)
+                __threadfence();
+                *ce.loss = atomicExch(acc, 0.f);
+            }
+        }
     }
 }
 

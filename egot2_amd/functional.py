@@ -82,6 +82,8 @@ class EncoderSpec:
     deterministic: bool = False  # backward: fixed-order reductions instead of fp32 atomics (bit-identical gradients run to run)
     out_tokens: int = 0          # > 0: return (and take the gradient of) only the first `out_tokens` tokens of every clip
     wcache: Optional[WeightCache] = None     # persistent packed-weight cache (None: packed into `saved` every forward)
+    token_ce: int = 0            # > 0 (classes): the forward also evaluates a per-token classifier + weighted cross entropy on the returned tokens
+                                 # (egx_token_ce, the ASD task's lossAV); use encoder_token_ce(), which falls back where the kernels do not fuse it
     ce: bool = False             # with head_n_out: the forward also evaluates the weighted cross entropy of the logits (egx_ce); EncoderFn then
                                  # takes (target, class_weight | None) behind the head parameters and returns (logits, loss)
 
@@ -253,6 +255,11 @@ class EncoderFn(torch.autograd.Function):
         nproj = sum(1 for s in spec.segments if s.has_proj)
         proj = [_dev_f32(t, "projection weight") for t in rest[nseg:nseg + 2 * nproj]]
         nhead = 4 if spec.head_n_out else 0
+        tce_in = None
+        if spec.token_ce:
+            if nhead or spec.ce:
+                raise _lib.EgxError("EncoderSpec.token_ce cannot be combined with the pooled head")
+            tce_in, rest = rest[-4:], rest[:-4]         # classifier weight, bias | None, target, class weight | None
         ce_target = ce_weight = None
         if spec.ce:
             if not nhead:
@@ -352,7 +359,7 @@ class EncoderFn(torch.autograd.Function):
                 keep = (1.0 / (1.0 - spec.p_drop)) if (spec.training and 0.0 < spec.p_drop < 1.0) else 1.0
                 wc_sig = (spec.compute, keep, _weights_epoch[0], nbytes) + tuple((t.data_ptr(), t._version) for t in packed)
                 if wc.buf is None or wc.buf.numel() < nbytes or wc.buf.device != device:
-                    wc.buf, wc.sig = torch.empty(nbytes, dtype=torch.uint8, device=device), None
+                    wc.buf, wc.sig = torch.zeros(nbytes, dtype=torch.uint8, device=device), None
                 capturing = torch.cuda.is_current_stream_capturing()
                 valid = wc.sig == wc_sig and (wc.frozen or not capturing)
                 cfg.weight_cache, cfg.weight_cache_valid = wc.buf.data_ptr(), int(valid)
@@ -374,6 +381,31 @@ class EncoderFn(torch.autograd.Function):
             ce_struct = Ce(ptr(tgt), ptr(cw), ptr(loss), ptr(dl))
             cfg.ce = C.cast(C.pointer(ce_struct), C.c_void_p)
             ce_keep = (tgt, cw, ce_struct)
+        tce_keep = tce_out = None
+        if spec.token_ce:
+            Cn, Mrows = int(spec.token_ce), B * (spec.out_tokens or S)
+            if wc is None or py_slice:
+                raise _lib.EgxError("EncoderSpec.token_ce: this configuration does not evaluate the token classifier in its kernels "
+                                    "(use functional.encoder_token_ce, which falls back to linear_cross_entropy)")
+            tw = _dev_f32(tce_in[0], "classifier weight")
+            tb = _dev_f32(tce_in[1], "classifier bias") if tce_in[1] is not None else None
+            ttgt, tcw = tce_in[2], (None if tce_in[3] is None else _dev_f32(tce_in[3], "class weight"))
+            if tuple(tw.shape) != (Cn, d) or ttgt.dtype != torch.int64 or tuple(ttgt.shape) != (Mrows,) or ttgt.device != device:
+                raise ValueError(f"token classifier: weight must be ({Cn}, {d}) and target an int64 tensor of shape ({Mrows},) on the features' device")
+            ttgt = ttgt.contiguous()
+            t_logits = torch.empty((Mrows, Cn), dtype=torch.float32, device=device)
+            t_probs, t_dl = torch.empty_like(t_logits), torch.empty_like(t_logits)
+            t_pred = torch.empty((Mrows,), dtype=torch.float32, device=device)
+            t_loss = torch.empty((), dtype=torch.float32, device=device)
+            t_correct = torch.empty((), dtype=torch.float32, device=device)
+            tce_struct = _lib.TokenCe(ptr(tw), ptr(tb), ptr(ttgt), ptr(tcw), Cn, ptr(t_logits), ptr(t_probs), ptr(t_pred), ptr(t_loss),
+                                      ptr(t_correct), ptr(t_dl), None, None)
+            cfg.token_ce = C.cast(C.pointer(tce_struct), C.c_void_p)
+            if not lib.egx_encoder_token_ce_ok(C.byref(cfg), segs, B):
+                raise _lib.EgxError("EncoderSpec.token_ce: this configuration does not evaluate the token classifier in its kernels "
+                                    "(use functional.encoder_token_ce, which falls back to linear_cross_entropy)")
+            tce_keep = (tw, tb, ttgt, tcw, tce_struct)
+            tce_out = (t_loss, t_logits, t_probs, t_pred, t_correct)
         if nhead:
             head = Head(ptr(head_t[0]), ptr(head_t[1]), ptr(head_t[2]), ptr(head_t[3]), spec.head_n_out)
             tokens = torch.empty((B, spec.head_n_out), dtype=torch.float32, device=device)   # logits
@@ -386,6 +418,7 @@ class EncoderFn(torch.autograd.Function):
                                       ptr(scratch), int(spec.training), seed, _stream()))
             if py_slice:
                 tokens = tokens[:, :py_slice].contiguous()
+            del tce_keep
         if wc is not None:
             wc.sig = wc_sig
         ctx.wcache_buf = wc.buf if wc is not None else None     # the backward reads the packed copies from the same buffer
@@ -401,7 +434,13 @@ class EncoderFn(torch.autograd.Function):
         ctx.scratch_bytes = sc.value
         ctx.has_te = task_embed is not None
         ctx.has_pos = pos_table is not None
-        ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t + head_t))
+        ctx.save_for_backward(*([t for t in (task_embed, pos_table) if t is not None] + [ln_w, ln_b] + feats + proj + layer_t + head_t
+                                + ([tw] + ([tb] if tb is not None else []) if spec.token_ce else [])))
+        if spec.token_ce:
+            ctx.tce_dl, ctx.tce_has_b = t_dl, tb is not None
+            ctx.mark_non_differentiable(*tce_out[1:])
+            ctx.set_materialize_grads(False)
+            return (tokens,) + tce_out
         if spec.ce:
             ctx.ce_dl = dl
             ctx.set_materialize_grads(False)
@@ -409,9 +448,18 @@ class EncoderFn(torch.autograd.Function):
         return tokens
 
     @staticmethod
-    def backward(ctx, d_tokens, d_loss=None):
+    def backward(ctx, d_tokens, d_loss=None, *_aux):
         spec0: EncoderSpec = ctx.spec
         dl_scale = None
+        if spec0.token_ce:
+            # (tokens, loss, ...) outputs: the loss's d_logits was left by the forward; the backward's first launch rebuilds d tokens from it
+            if d_tokens is not None:
+                raise _lib.EgxError("EncoderSpec.token_ce: a gradient through the returned tokens as well as through the fused loss is not supported "
+                                    "(compose encoder() and linear_cross_entropy() instead)")
+            if d_loss is None:
+                return (None,) * len(ctx.needs_input_grad)
+            dl_scale = d_loss if (d_loss.dtype == torch.float32 and d_loss.is_contiguous()) else d_loss.float().contiguous()
+            d_tokens = ctx.tce_dl       # (only its device is read below)
         if spec0.ce:
             # (logits, loss) outputs: the loss's d_logits was left by the forward; its upstream gradient (loss.backward()'s ones, a loss
             # scale) goes to the kernels as a device scalar. A gradient reaching the logits directly as well is the rare case: torch ops.
@@ -432,6 +480,8 @@ class EncoderFn(torch.autograd.Function):
             lib.egx_tuning_reload()
         spec: EncoderSpec = ctx.spec
         sv = list(ctx.saved_tensors)
+        tce_b = sv.pop() if (spec.token_ce and ctx.tce_has_b) else None
+        tce_w = sv.pop() if spec.token_ce else None
         task_embed = sv.pop(0) if ctx.has_te else None
         pos_table = sv.pop(0) if ctx.has_pos else None
         ln_w, ln_b = sv[0], sv[1]
@@ -465,6 +515,9 @@ class EncoderFn(torch.autograd.Function):
         rest_rank = n_l if hook is not None else 0
         i_layer = [pk.add(t, need[5 + nseg + 2 * nproj + i], late=(i % 12 in (0, 2)) and hook is None, rank=lrank(i)) for i, t in enumerate(layer_t)]
         i_head = [pk.add(t, need[5 + nseg + 2 * nproj + len(layer_t) + i], rank=rest_rank) for i, t in enumerate(head_t)]
+        # the token classifier's gradients (egx_token_ce) live in the flat buffer too: zero-filled, reduced and all-reduced with the rest
+        i_tw = pk.add(tce_w, bool(spec.token_ce) and need[-4], rank=rest_rank)
+        i_tb = pk.add(tce_b, bool(spec.token_ce) and need[-3], rank=rest_rank)
         grads = pk.materialise(device, zero=False)      # zero-filled by the library's backward (saves a fill launch)
 
         def g(i):
@@ -506,6 +559,12 @@ class EncoderFn(torch.autograd.Function):
             cfg.weight_cache = ctx.wcache_buf.data_ptr()
         if dl_scale is not None:
             cfg.d_logits_scale = dl_scale.data_ptr()
+        tce_keep = tce_grads = None
+        if spec.token_ce:
+            tce_struct = _lib.TokenCe(ptr(tce_w), None, None, None, int(spec.token_ce), None, None, None, None, None, ptr(ctx.tce_dl),
+                                      ptr(g(i_tw)), ptr(g(i_tb)))
+            cfg.token_ce = C.cast(C.pointer(tce_struct), C.c_void_p)
+            tce_keep, tce_grads = tce_struct, (g(i_tw), g(i_tb))
         announced = set()
         cb_keep = None
         if hook is not None and ctx.impl == EGX_IMPL_WIDE:
@@ -544,10 +603,13 @@ class EncoderFn(torch.autograd.Function):
                                              C.byref(hg), int(spec.training), seed, _stream()))
         else:
             # the generic backward overwrites d_tokens (needs a private copy); the fused and wide kernels only read it
-            dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
-            dtok = dtok.contiguous()
-            if dtok.data_ptr() == d_tokens.data_ptr() and ctx.impl == EGX_IMPL_GENERIC:
-                dtok = dtok.clone()
+            if spec.token_ce:
+                dtok = None
+            else:
+                dtok = d_tokens if d_tokens.dtype == torch.float32 else d_tokens.float()
+                dtok = dtok.contiguous()
+                if dtok.data_ptr() == d_tokens.data_ptr() and ctx.impl == EGX_IMPL_GENERIC:
+                    dtok = dtok.clone()
 
             def launch(c):
                 check(lib.egx_encoder_bwd(C.byref(c), segs, ptr(ln_w), ptr(ln_b), layers, B, ptr(dtok), ptr(saved_buf),
@@ -581,6 +643,10 @@ class EncoderFn(torch.autograd.Function):
         out += feat_grads + [g(i) for i in i_proj] + [g(i) for i in i_layer] + [g(i) for i in i_head]
         if spec.ce:
             out += [None, None]     # target, class weight
+        if spec.token_ce:
+            nig = ctx.needs_input_grad
+            out += [tce_grads[0], tce_grads[1], None, None]
+            del tce_keep
         return tuple(out)
 
 
@@ -592,6 +658,45 @@ def encoder(spec: EncoderSpec, feats: Sequence[torch.Tensor], task_embed, pos_ta
     if spec.ce:
         return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, *head_params, ce[0], ce[1])
     return EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, *head_params)
+
+
+def _token_ce_fused(spec: EncoderSpec, feats, proj) -> bool:
+    """Does this configuration evaluate EncoderSpec.token_ce in its kernels (egx_encoder_token_ce_ok)? Probed with the real feature / projection
+    tensors; the weight cache only has to exist."""
+    if spec.wcache is None or spec.deterministic or not spec.out_tokens:
+        return False
+    lib = _lib.load()
+    nseg = len(spec.segments)
+    segs = (Segment * nseg)()
+    pi = 0
+    for i, (ss, f) in enumerate(zip(spec.segments, feats)):
+        if not (f.is_cuda and f.dim() == 3):
+            return False
+        segs[i].feat, segs[i].T, segs[i].d_in = ptr(f), ss.T, ss.d_in
+        segs[i].feat_bf16, segs[i].pool = int(f.dtype == torch.bfloat16), int(ss.pool)
+        if ss.has_proj:
+            segs[i].proj_w, segs[i].proj_b = ptr(proj[2 * pi]), ptr(proj[2 * pi + 1])
+            pi += 1
+    cfg = spec.config()
+    if lib.egx_encoder_impl(C.byref(cfg), segs, feats[0].shape[0]) != EGX_IMPL_FUSED:
+        return False
+    cfg.weight_cache = 1        # (any non-null value: the query does not touch it)
+    return bool(lib.egx_encoder_token_ce_ok(C.byref(cfg), segs, feats[0].shape[0]))
+
+
+def encoder_token_ce(spec: EncoderSpec, feats: Sequence[torch.Tensor], task_embed, pos_table, ln_w, ln_b,
+                     proj: Sequence[torch.Tensor], layer_params: Sequence[torch.Tensor], fc_w, fc_b, target, class_weight=None):
+    """(loss, logits, probs, pred, correct) of Linear(d -> C) + weighted cross entropy on the first spec.out_tokens tokens of every clip (rows in
+    clip-major order, as encoder(...).reshape(B * out_tokens, d) has them): the ASD task's lossAV on the translator's per-frame output
+    (HHI/tasks/asd/video_task_taskspecific.py:24,33). Where the per-clip kernels can, the encoder launches evaluate it themselves
+    (egx_token_ce: two launches less per step); elsewhere encoder() + linear_cross_entropy()."""
+    import dataclasses
+    if _token_ce_fused(spec, feats, proj):
+        spec = dataclasses.replace(spec, token_ce=int(fc_w.shape[0]))
+        out = EncoderFn.apply(spec, task_embed, pos_table, ln_w, ln_b, *feats, *proj, *layer_params, fc_w, fc_b, target, class_weight)
+        return out[1:]
+    tokens = encoder(spec, feats, task_embed, pos_table, ln_w, ln_b, proj, layer_params)
+    return linear_cross_entropy(tokens.reshape(-1, tokens.shape[-1]), fc_w, fc_b, target, class_weight)
 
 
 class PoolHeadFn(torch.autograd.Function):

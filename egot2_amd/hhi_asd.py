@@ -63,15 +63,21 @@ class TaskFusionMFTransformer3Task(TaskFusion3Task, TranslatorMixin):
         )
         self.output_dim = self.dim
 
-    def forward_features(self, ttm_out, lam_out, asd_out):
-        """(B, T, 256) features -> (B*T, d): tokens asd | ttm | lam, first T tokens returned."""
+    def forward_features(self, ttm_out, lam_out, asd_out, lossav=None, labels=None):
+        """(B, T, 256) features -> (B*T, d): tokens asd | ttm | lam, first T tokens returned.
+        lossav (the task's lossAV module) + labels (B*T,): return lossAV.forward(tokens, labels) = (nloss, predScore, predLabel, correctNum)
+        instead (HHI/tasks/asd/video_task_taskspecific.py:24,33), evaluated by the encoder's own launches where the per-clip kernels can."""
         feats = [asd_out, ttm_out, lam_out]
         segs = [SegmentSpec(T=f.shape[1], d_in=f.shape[2], has_proj=True, add_row=k, pos_row0=0)
                 for f, k in zip(feats, (2, 0, 1))]
         tokens = self._egx_encode(feats, segs, encoder=self.transformer_encoder, ln=self.ln,
                                   projs=[self.proj_asd, self.proj_ttm, self.proj_lam], task_embed=self.task_embed,
                                   pos_table=self.pos_embed.pe, p_drop=self.dp_rate, p_pos=self.pos_embed.dropout.p,
-                                  out_tokens=asd_out.shape[1])     # x[0:D] of model_taskspecific.py:156-158, without the copy
+                                  out_tokens=asd_out.shape[1],     # x[0:D] of model_taskspecific.py:156-158, without the copy
+                                  token_ce=None if lossav is None else (lossav.FC.weight, lossav.FC.bias, labels, lossav.criterion.weight))
+        if lossav is not None:
+            nloss, _, predScore, predLabel, correctNum = tokens
+            return nloss, predScore, predLabel, correctNum
         N, D = asd_out.shape[0], asd_out.shape[1]
         return tokens.reshape(N * D, -1)
 

@@ -100,11 +100,14 @@ def make_workload(name: str, device, *, batch: int = 256, frames: int = 15, laye
         # the classifier lives outside the model: lossAV = Linear(dim, 2) + CE(weight [1, 4]) + scores, HHI/tasks/asd/loss.py:11-30
         # (video_task_taskspecific.py:24,33: nloss, _, _, prec = self.lossAV.forward(outsAV, labels))
         head = hhi_asd.lossAV(128).to(device)
-        loss_fn = lambda: head(model.forward_features(*feats), target)[0]   # noqa: E731
+        if fused_ce:    # lossAV evaluated by the encoder's own launches where the per-clip kernels can (egx_token_ce; elsewhere the same two launches)
+            loss_fn = lambda: model.forward_features(*feats, lossav=head, labels=target)[0]   # noqa: E731
+        else:
+            loss_fn = lambda: head(model.forward_features(*feats), target)[0]   # noqa: E731
         segs = [(T, 256, True)] * 3
         fl = encoder_flops(B, segs, 128, 2048, L)
         desc = (f"configs[2]: ASD 3-task translator, {L} layers d=128 h=4 d_ff=2048, B={B}/GPU T={T} S={3 * T}, per-frame "
-                f"output (B*T, d) + lossAV (FC + weighted CE + scores, one launch each way), dropout={p}")
+                f"output (B*T, d) + lossAV (FC + weighted CE + scores" + (", evaluated by the encoder launches" if fused_ce else ", one launch each way") + f"), dropout={p}")
         d, S = 128, 3 * T
         model.extra_params = list(head.FC.parameters())
     elif name == "pnr":

@@ -113,11 +113,13 @@ class TranslatorMixin:
     def _egx_encode(self, feats: Sequence[torch.Tensor], segments: List[SegmentSpec], *, encoder: nn.TransformerEncoder,
                     ln: nn.LayerNorm, projs: Sequence[Optional[nn.Linear]], task_embed: Optional[torch.Tensor],
                     pos_table: Optional[torch.Tensor], p_drop: float, p_pos: float = 0.0, p_feat: float = 0.0,
-                    head=None, out_tokens: int = 0, ce=None) -> torch.Tensor:
+                    head=None, out_tokens: int = 0, ce=None, token_ce=None) -> torch.Tensor:
         """head = (nn.LayerNorm, nn.Linear): evaluate the pooled head with the encoder and return logits (B, n_out).
         out_tokens = T > 0: return only the first T tokens of every clip, (B, T, d) (in-kernel on the fused path).
         ce = (target, class_weight | None) with a head: also evaluate nn.CrossEntropyLoss(weight)(logits, target) inside the forward
-        (egx_ce) and return (logits, loss)."""
+        (egx_ce) and return (logits, loss).
+        token_ce = (fc_weight, fc_bias | None, target, class_weight | None) with out_tokens: return (loss, logits, probs, pred, correct) of the
+        per-token classifier + weighted cross entropy on the returned tokens instead of the tokens (functional.encoder_token_ce)."""
         layer0 = encoder.layers[0]
         d = ln.normalized_shape[0]
         seed_dev = getattr(self, "_egx_seed_dev", None)
@@ -143,5 +145,10 @@ class TranslatorMixin:
         head_t = (head[0].weight, head[0].bias, head[1].weight, head[1].bias) if head is not None else ()
         if ce is not None and head is None:
             raise ValueError("the fused cross entropy needs the pooled head")
+        if token_ce is not None:
+            if head is not None or not out_tokens:
+                raise ValueError("the token classifier works on the first out_tokens tokens of every clip, without the pooled head")
+            return F_egx.encoder_token_ce(spec, list(feats), task_embed, pos_table, ln.weight, ln.bias, proj_t,
+                                          encoder_layer_tensors(encoder), *token_ce)
         return F_egx.encoder(spec, list(feats), task_embed, pos_table, ln.weight, ln.bias, proj_t,
                              encoder_layer_tensors(encoder), head_t, ce=ce)

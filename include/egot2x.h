@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define EGX_ABI_VERSION 15
+#define EGX_ABI_VERSION 16
 #define EGX_MAX_SEGMENTS 8
 
 enum { EGX_F32 = 0, EGX_BF16 = 1, EGX_F32_SPLIT = 2 };
@@ -119,6 +119,7 @@ typedef struct egx_layer_grads {
 } egx_layer_grads;
 
 struct egx_ce;
+struct egx_token_ce;
 typedef struct egx_config {
     int d_model;
     int n_heads;
@@ -172,7 +173,10 @@ typedef struct egx_config {
     void* weight_cache;       /* optional PERSISTENT device buffer of egx_weight_cache_bytes() bytes (per-clip / tiled kernels): the
                                  MFMA-fragment-packed copies of the weights live there instead of in `saved`, so that a forward whose
                                  weights did not change since the forward that filled it can skip the packing launch
-                                 (weight_cache_valid). The backward must be given the same buffer. NULL: packed into `saved` every forward. */
+                                 (weight_cache_valid). The backward must be given the same buffer. NULL: packed into `saved` every forward.
+                                 Its last 256 bytes are a control block of the library (arrival counter + accumulator of the fused
+                                 cross entropy); a forward that packs resets it, so the buffer needs no initialisation. One cache
+                                 serves one stream at a time. */
     int weight_cache_valid;   /* forward, with weight_cache: != 0 = the cache holds the packed copies of EXACTLY these weights in this
                                  compute mode with this FFN keep-scale (training, p_drop): nothing is packed. The caller owns that
                                  promise (egot2_amd/translator.py keys it on the parameters' storage and version counters). */
@@ -180,6 +184,9 @@ typedef struct egx_config {
                                  gradient of a loss the forward computed itself, egx_ce; lets loss.backward() hand its ones / loss-scale
                                  tensor over without a launch). Per-clip kernels only; NULL = 1. */
     const struct egx_ce* ce;  /* forward, optional (egx_translator_fwd with a head): weighted cross entropy on the logits, see egx_ce */
+    /* ---- ABI v16 (round 6) ---- */
+    const struct egx_token_ce* token_ce;  /* forward + backward, optional (egx_encoder_fwd / _bwd with out_tokens): per-token classifier + weighted
+                                 cross entropy on the returned tokens, see egx_token_ce. Only where egx_encoder_token_ce_ok() says so. */
 } egx_config;
 
 /* Weighted cross entropy ON the pooled head's logits, evaluated by the translator forward itself
@@ -196,7 +203,34 @@ typedef struct egx_ce {
     float* d_logits;            /* (B, n_out), written */
 } egx_ce;
 
+/* Per-token classifier + weighted cross entropy ON the tokens the encoder returns, evaluated by the encoder launches themselves: the ASD task's
+ * lossAV on the translator's per-frame output (HHI/tasks/asd/video_task_taskspecific.py:24,33 -> HHI/tasks/asd/loss.py:11-30: x = FC(x);
+ * nloss = CrossEntropyLoss(weight=[1, 4])(x, labels); softmax scores, rounded labels, number of correct frames). The arithmetic of
+ * egx_linear_ce_fwd / _bwd; as two launches of their own they are 27 us of the 0.41 ms ASD step. Forward: the launch that normalises the last layer's
+ * tokens also writes logits / probs / pred / d_logits of the clip's out_tokens rows and adds the clip's loss and correct-frame terms (the
+ * normaliser sum_i w[y_i] depends on the labels only: every workgroup sums it itself). Backward (egx_encoder_bwd with d_tokens = NULL): the first
+ * launch rebuilds d tokens = g * d_logits W per clip and leaves the clip's partial d W / d b rows to the step's fixed-order reduction; g =
+ * *egx_config.d_logits_scale (NULL = 1). The tokens themselves are still written (tokens_out). */
+typedef struct egx_token_ce {
+    const float* W;             /* (C, d) classifier weight */
+    const float* b;             /* (C) or NULL */
+    const int64_t* target;      /* (B * out_tokens) class indices; outside [0, C): no loss, no weight, no gradient */
+    const float* class_weight;  /* (C) or NULL (= 1) */
+    int C;                      /* 1 <= C <= 8 */
+    float* logits;              /* (B * out_tokens, C), written by the forward */
+    float* probs;               /* same shape, optional: softmax(logits) */
+    float* pred;                /* (B * out_tokens), optional: round(probs[:, 1]) */
+    float* loss;                /* scalar, written by the forward */
+    float* correct;             /* scalar, optional: rows with pred == target */
+    float* d_logits;            /* (B * out_tokens, C): written by the forward, read by the backward */
+    float* d_W; float* d_b;     /* backward: (C, d) and (C), each optional: the gradients are ADDED (as every parameter gradient of
+                                   egx_encoder_bwd: into the caller's zero_buf-covered flat buffer, or pre-zeroed memory) */
+} egx_token_ce;
+
 int egx_abi_version(void);
+/* != 0: this configuration and batch run on kernels that evaluate egx_config.token_ce themselves (one clip per workgroup, one launch per
+ * direction, a persistent weight cache, no pooled head). Elsewhere the caller composes egx_linear_ce_fwd / _bwd with the encoder calls. */
+int egx_encoder_token_ce_ok(const egx_config* cfg, const egx_segment* segs, int B);
 /* The kernel-selection switches EGX_FFN_CUT / EGX_FFN_SLICES / EGX_SLICE_DROP (development and test aids) are read from the environment once,
  * at first use; this re-reads them (the parity tests compare the modes inside one process). */
 void egx_tuning_reload(void);

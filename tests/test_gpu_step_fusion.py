@@ -299,3 +299,133 @@ def test_default_backward_is_bit_reproducible(egx_lib, cuda, compute, B):
         runs.append(_grads(m))
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]) and torch.equal(runs[0][k], runs[2][k]), k
+
+
+# ---- egx_token_ce: the ASD task's lossAV evaluated by the encoder's own launches ------------------------------------------------------------------
+def _asd(cuda, compute, p=0.0, layers=2, cache=True):
+    from egot2_amd import hhi_asd
+    m = hhi_asd.TaskFusionMFTransformer3Task(hhi_args(dropout=p, num_layers=layers))
+    m.load_state_dict(seeded_state_dict(m, 31))
+    m = m.to(cuda).set_compute(compute).train()
+    if p == 0.0:
+        m.pos_embed.dropout.p = 0.0
+    if cache:
+        m.enable_weight_cache()
+    head = hhi_asd.lossAV(128)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        head.FC.weight.copy_(torch.randn(2, 128, generator=g) * 0.2)
+        head.FC.bias.copy_(torch.randn(2, generator=g) * 0.1)
+    return m, head.to(cuda)
+
+
+@pytest.mark.parametrize("compute,B,T", [("bf16", 256, 15), ("bf16", 130, 9), ("f32s", 200, 15), ("f32", 140, 16)])
+def test_fused_lossav_equals_the_two_launch_head(egx_lib, cuda, compute, B, T):
+    """model.forward_features(..., lossav=head, labels=y) (egx_token_ce: classifier + weighted CE + scores in the launch that normalises the last
+    layer's tokens; d tokens and the classifier's gradients rebuilt by the backward's first launch) against head(model.forward_features(...), y)
+    (egx_linear_ce_fwd / _bwd on the returned tokens): same scores, labels and counts, loss within 1e-6, every gradient of the translator and of
+    the classifier within rounding of the other summation order; with a loss scale as the upstream gradient."""
+    from egot2_amd import functional as F_egx
+    feats = [f.to(cuda) for f in seeded_feats(77, [(B, T, 256)] * 3)]
+    y = torch.randint(0, 2, (B * T,), generator=torch.Generator().manual_seed(3)).to(cuda)
+    y[5] = -100     # ignored frame: no loss, no weight, no gradient
+    out = {}
+    for fused in (True, False):
+        m, head = _asd(cuda, compute)
+        if fused:
+            nloss, score, label, correct = m.forward_features(*feats, lossav=head, labels=y)
+            assert F_egx.last_encoder_impl() == "fused"
+        else:
+            nloss, score, label, correct = head(m.forward_features(*feats), y)
+        (nloss * 3.0).backward()
+        torch.cuda.synchronize()
+        out[fused] = (nloss.detach(), score.detach(), label.detach(), correct.detach(), _grads(m), _grads(head))
+    a, b = out[True], out[False]
+    assert abs(a[0].item() - b[0].item()) <= 1e-6 * max(1.0, abs(b[0].item()))
+    assert max_err(a[1], b[1]) < 1e-6 and torch.equal(a[2], b[2]) and a[3].item() == b[3].item()
+    tol = 5e-3 if compute == "bf16" else 2e-5
+    assert set(a[4]) == set(b[4]) and set(a[5]) == set(b[5]) == {"FC.weight", "FC.bias"}
+    bad = {k: rel_err(a[4][k], b[4][k]) for k in b[4] if not _same(a[4][k], b[4][k], tol)}
+    bad.update({k: rel_err(a[5][k], b[5][k]) for k in b[5] if not _same(a[5][k], b[5][k], 2e-5)})
+    assert not bad, bad
+
+
+def test_fused_lossav_against_the_oracle(egx_lib, cuda):
+    """The fused lossAV of the ASD translator (two layers, f32s) against the fp64 oracle: model_taskspecific.py:139-158 + tasks/asd/loss.py:11-30."""
+    from oracle import translator_ref as tr
+    B, T = 140, 15
+    m, head = _asd(cuda, "f32s")
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    feats = seeded_feats(78, [(B, T, 256)] * 3)
+    y = torch.randint(0, 2, (B * T,), generator=torch.Generator().manual_seed(4))
+    nloss, score, label, correct = m.forward_features(*[f.to(cuda) for f in feats], lossav=head, labels=y.to(cuda))
+    nloss.backward()
+    torch.cuda.synchronize()
+    sd64 = {k: v.double().requires_grad_(v.is_floating_point() and not k.endswith(".pe")) for k, v in sd.items()}
+    W64 = head.FC.weight.detach().cpu().double().requires_grad_(True)
+    b64 = head.FC.bias.detach().cpu().double().requires_grad_(True)
+    x = tr.asd_forward(sd64, 4, *[f.double() for f in feats])
+    z = x @ W64.t() + b64
+    ref = tr.weighted_ce(z, y, [1.0, 4.0])
+    ref.backward()
+    assert abs(nloss.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    pr = torch.softmax(z.detach(), dim=-1)
+    assert max_err(score, pr) < 1e-4
+    assert correct.item() == float((torch.round(pr)[:, 1] == y.double()).sum().item())
+    assert rel_err(head.FC.weight.grad, W64.grad) < 1e-3 and rel_err(head.FC.bias.grad, b64.grad) < 1e-3
+    named = dict(m.named_parameters())
+    errs = {k: rel_err(named[k].grad, v.grad) for k, v in sd64.items() if v.grad is not None and k in named and named[k].grad is not None and v.grad.norm() > 0}
+    assert len(errs) > 20 and max(errs.values()) < 1e-3, {k: e for k, e in errs.items() if e >= 1e-3}
+
+
+def test_fused_lossav_falls_back_where_the_kernels_do_not_fuse_it(egx_lib, cuda):
+    """Without a weight cache, in deterministic mode, on a sliced small batch or a long (tiled) clip the same call composes the encoder with
+    egx_linear_ce_fwd / _bwd: same values as the explicit two-step form."""
+    for kind in ("nocache", "small", "long"):
+        B, T = (6, 15) if kind == "small" else (3, 60) if kind == "long" else (140, 15)
+        feats = [f.to(cuda) for f in seeded_feats(79, [(B, T, 256)] * 3)]
+        y = torch.randint(0, 2, (B * T,), generator=torch.Generator().manual_seed(6)).to(cuda)
+        res = []
+        for fused_call in (True, False):
+            m, head = _asd(cuda, "f32s", cache=kind != "nocache")
+            if fused_call:
+                nloss, score, label, correct = m.forward_features(*feats, lossav=head, labels=y)
+            else:
+                nloss, score, label, correct = head(m.forward_features(*feats), y)
+            nloss.backward()
+            torch.cuda.synchronize()
+            res.append((nloss.detach(), score.detach(), _grads(m), _grads(head)))
+        assert abs(res[0][0].item() - res[1][0].item()) <= 1e-6 and max_err(res[0][1], res[1][1]) < 1e-6, kind
+        assert all(_same(res[0][2][k], res[1][2][k], 2e-5) for k in res[1][2]), kind
+        assert all(_same(res[0][3][k], res[1][3][k], 2e-5) for k in res[1][3]), kind
+
+
+def test_fused_lossav_step_replays_in_a_graph(egx_lib, cuda):
+    """The C3 bench step (fused lossAV, frozen weight cache, device seed) captured once and replayed: the loss of every replay equals the eager
+    step's on the same seed state, and the arrival counter leaves the control block clean (a second model sharing nothing still gets its loss)."""
+    from egot2_amd import synth
+    wl = synth.make_workload("c3", cuda, batch=160, frames=15, dtype="bf16", dropout=0.0)
+    model = wl["model"]
+    model.pos_embed.dropout.p = 0.0
+    model.enable_weight_cache(frozen=True)
+    params = [p for p in model.parameters() if p.requires_grad] + list(getattr(model, "extra_params", []))
+    def step():
+        for p in params:
+            p.grad = None
+        loss = wl["loss_fn"]()
+        loss.backward()
+        return loss
+    eager = [step().item() for _ in range(3)]
+    assert abs(eager[0] - eager[2]) < 1e-6
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+        with torch.cuda.graph(g, stream=s):
+            out = step()
+    torch.cuda.current_stream().wait_stream(s)
+    for _ in range(5):
+        g.replay()
+        torch.cuda.synchronize()
+        assert abs(out.item() - eager[0]) < 1e-6
