@@ -15,6 +15,17 @@
 #include "common.h"
 #include "kernels.h"
 #include "fused.h"
+// bf16 FFN input-gradient loop of the clip kernels software-pipelined across hidden blocks like the forward's (fused_bwd_kernel P4); 0 = block after
+// block. OFF: measured no faster — stamps of the phase 38.0k -> 40.5k cycles (16-slot ring) with the LayerNorm1 backward behind it 10.9k -> 17.6k,
+// c2 bf16 / C3 steps within the box noise of the plain loop (201.7 vs 201.1, 400.0 vs 390.5, 208.4 vs 217.3 us). Unlike the forward's, this loop's
+// epilogue is short (110 VALU per block: masks from the saved alive bits, pack, dH tiles): there is little to hide.
+#ifndef EGX_FFN_PIPE_BWD
+#define EGX_FFN_PIPE_BWD 0
+#endif
+#ifndef EGX_FFN_PIPE_BWD_RING
+#define EGX_FFN_PIPE_BWD_RING 16      // fragment slots of the pipelined loop: 16 = a ring per weight stream (the backward has the registers), 8 = one shared ring
+#endif
+
 #ifdef EGX_STAMPS
 namespace egx { extern __device__ unsigned long long g_bstamps[32]; }
 #define LNB_STAMP(base, k) do { if ((base) >= 0 && blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); egx::g_bstamps[(base) + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -1888,6 +1899,124 @@ __global__ __launch_bounds__(256, 1) void fused_bwd_kernel(FusedBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hb0, lane);
             }
+            bool ffn_done = false;
+            if constexpr (CM == CM_BF16 && EGX_FFN_PIPE_BWD && !SLICED) {
+                // bf16: the loop software-pipelined across hidden blocks as in the forward (fused.hip): the mask / pack / dH-tile work of block `it` is
+                // issued in slices behind the MFMAs of one weight fragment each — GEMM1 of block it + 1 (into a second accumulator set) and GEMM2 of
+                // block it - 1 (from the operand fragments the previous block left). One ring of eight fragment slots (w2r) serves both weight streams.
+                ffn_done = true;
+                f32x4 dc[2][NT], dc2[2][NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dc[i][t] = f32x4{0, 0, 0, 0};
+                {
+                    const int hb1 = hb_of(1 < nit ? 1 : 0);
+#pragma unroll
+                    for (int kb = 0; kb < FD / 32; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            pin(w2r[i][kb]);
+                            Frag<CM> a2 = w_frag<CM>(w2r[i][kb]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mma<CM>(dc[i][t], a2, gb[kb][t]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb1 * 2 + i, FD / 32, kb, lane);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+                Frag<CM> dqA[NT], dqB[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dqA[t] = chain_frag<CM>(f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0});
+                auto step = [&](int it, f32x4 (&dcur)[2][NT], f32x4 (&dnext)[2][NT], const Frag<CM> (&dq_prev)[NT], Frag<CM> (&dq)[NT]) {
+                    const int hb = hb_of(it);
+                    const int hbn = hb_of(it + 1 < nit ? it + 1 : it);
+                    const int hb2 = hb_of(it + 2 < nit ? it + 2 : nit - 1);
+                    const int hbp = hb_of(it > 0 ? it - 1 : 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t bits = relu_word;
+                    __builtin_amdgcn_sched_barrier(0);
+                    relu_word = relu_bits[(size_t)hbn * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) dnext[i][t] = f32x4{0, 0, 0, 0};
+                    static_assert(3 * NT <= 16, "epilogue slices");
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        if (k < 8) {
+                            const int kb = k >> 1, i = k & 1;
+                            pin(w2r[i][kb]);
+                            Frag<CM> a2 = w_frag<CM>(w2r[i][kb]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mma<CM>(dnext[i][t], a2, gb[kb][t]);
+#if EGX_FFN_PIPE_BWD_RING == 16
+                            w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb2 * 2 + i, FD / 32, kb, lane);
+#else
+                            w2r[i][kb] = load_w<CM>(w.lin1_wtp, k, nhb, hbp, lane);             // slot k: W1^T fragment k of the previous block, needed eight steps on
+#endif
+                        } else {
+                            const int j = k - 8, i = j & 1, kb = j >> 1;
+#if EGX_FFN_PIPE_BWD_RING == 16
+                            pin(w3r[j]);
+                            Frag<CM> a = w_frag<CM>(w3r[j]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mma<CM>(dxa[j][t], a, dq_prev[t]);
+                            w3r[j] = load_w<CM>(w.lin1_wtp, j, nhb, hb, lane);      // this block's W1^T rows: GEMM2 of the next iteration
+#else
+                            pin(w2r[i][kb]);
+                            Frag<CM> a = w_frag<CM>(w2r[i][kb]);
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mma<CM>(dxa[j][t], a, dq_prev[t]);
+                            w2r[i][kb] = load_w<CM>(w.lin2_wtp, hb2 * 2 + i, FD / 32, kb, lane);  // slot j: W2^T fragment j of the block after next
+#endif
+                        }
+                        if (k < 2 * NT) {           // alive bits -> masks of one 16 x 16 tile (see the loop below)
+                            const int i = k / NT, t = k % NT;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int kk = (i * NT + t) * 4 + e;
+                                const int32_t m = ((int32_t)(bits << (31 - kk))) >> 31;
+                                dcur[i][t][e] = __uint_as_float(__float_as_uint(dcur[i][t][e]) & (uint32_t)m);
+                            }
+                        } else if (k < 3 * NT) {    // operand fragment + dH tile of a token tile
+                            const int t = k - 2 * NT;
+                            dq[t] = chain_frag<CM>(dcur[0][t], dcur[1][t]);
+                            if constexpr (CM == CM_BF16) {
+                                const u32x4 u = __builtin_bit_cast(u32x4, dq[t].v);
+                                store_hid_tile_bf16(dhid_base + (size_t)hb * 2 * (HTILE_ELEMS * ESZ) + (size_t)t * nht * (HTILE_ELEMS * ESZ), u, lane, S - t * 16);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                auto last_gemm2 = [&](const Frag<CM> (&dq_last)[NT]) {      // (its W1^T rows are requested here: one exposed round trip per layer)
+#if EGX_FFN_PIPE_BWD_RING != 16
+                    const int hbl = hb_of(nit - 1);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) w3r[i] = load_w<CM>(w.lin1_wtp, i, nhb, hbl, lane);
+#endif
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        Frag<CM> a = w_frag<CM>(w3r[i]);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) mma<CM>(dxa[i][t], a, dq_last[t]);
+                    }
+                };
+                int it = 0;
+                for (; it + 1 < nit; it += 2) {
+                    step(it, dc, dc2, dqA, dqB);
+                    step(it + 1, dc2, dc, dqB, dqA);
+                }
+                if (it < nit) {
+                    step(it, dc, dc2, dqA, dqB);
+                    last_gemm2(dqB);
+                } else {
+                    last_gemm2(dqA);
+                }
+            }
+            if (!ffn_done)
             for (int it = 0; it < nit; ++it) {
                 const int hb = hb_of(it);
                 const int hbn = hb_of(it + 1 < nit ? it + 1 : it);     // the last block refills itself (never used)

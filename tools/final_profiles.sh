@@ -28,6 +28,7 @@ bench f32s
 bench f32 --dtype f32 --no-cpu-baseline
 bench bf16 --dtype bf16 --no-cpu-baseline
 bench c3 --config c3 --no-cpu-baseline
+bench c3_unfused --config c3 --no-fused-ce --no-cpu-baseline --no-roofline      # lossAV as its own two launches (egx_linear_ce_*)
 bench c4 --config c4 --no-cpu-baseline --steps 5 --warmup 2
 bench c4_sink --config c4 --feat-source sink --feat-dtype bf16 --no-cpu-baseline --steps 5 --warmup 2
 bench pnr --config pnr --no-cpu-baseline --no-native-line
