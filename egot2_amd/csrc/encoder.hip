@@ -12,6 +12,11 @@
 #include "wide.h"
 #include "wide_host.h"
 
+// 1: with a valid weight cache the one-launch forward publishes the fused loss through an arrival counter; 0: a 4-byte memset node in front of it (A/B switch)
+#ifndef EGX_CE_TICKET
+#define EGX_CE_TICKET 1
+#endif
+
 namespace egx {
 
 static thread_local char g_err[1024] = "";
@@ -746,7 +751,7 @@ static int encoder_fwd_impl(const egx_config* cfg, const egx_segment* segs, cons
             fp.ce_target = ce->target; fp.ce_weight = ce->class_weight; fp.ce_loss = ce->loss; fp.ce_dlogits = ce->d_logits; fp.ce_B = B;
             if (pk.n || pk.seed_advance || pk.zero_words) pk.zero_word2 = ce->loss;
             else if (cut) fp.zero_word = ce->loss;
-            else if (cfg->weight_cache) fp.ce_ticket = (unsigned*)((char*)cfg->weight_cache + align_up(PL.bytes, 256));   // no earlier launch: arrival counter (5 us less than a memset node)
+            else if (cfg->weight_cache && EGX_CE_TICKET) fp.ce_ticket = (unsigned*)((char*)cfg->weight_cache + align_up(PL.bytes, 256));   // no earlier launch: arrival counter instead of a memset node
             else EGX_HIP(hipMemsetAsync(ce->loss, 0, sizeof(float), st));
         }
         if (tce) {

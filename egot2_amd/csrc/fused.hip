@@ -22,9 +22,11 @@
 #include <type_traits>
 #include <vector>
 
-// bf16 FFN loop of the clip kernels software-pipelined across hidden blocks (see fused_fwd_kernel); 0 = the block-after-block loop of rounds 2-5
+// bf16 FFN loop of the clip kernels software-pipelined across hidden blocks (see fused_fwd_kernel); 0 = the block-after-block loop of rounds 2-5.
+// OFF: the stamps of workgroup 0 show the phase at 49.3k -> 45.7k cycles, but four interleaved same-box pairs of the whole step do not
+// (profiles/r06_ab_second_half.txt): c2 bf16 +4.3 us (+2 %) with it, C3 -1.8 us (-0.4 %). Kept as a build switch with the measurements.
 #ifndef EGX_FFN_PIPE
-#define EGX_FFN_PIPE 1
+#define EGX_FFN_PIPE 0
 #endif
 #ifndef EGX_FFN_PIPE_RING
 #define EGX_FFN_PIPE_RING 8
