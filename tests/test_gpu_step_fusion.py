@@ -319,19 +319,21 @@ def _asd(cuda, compute, p=0.0, layers=2, cache=True):
     return m, head.to(cuda)
 
 
-@pytest.mark.parametrize("compute,B,T", [("bf16", 256, 15), ("bf16", 130, 9), ("f32s", 200, 15), ("f32", 140, 16)])
-def test_fused_lossav_equals_the_two_launch_head(egx_lib, cuda, compute, B, T):
+@pytest.mark.parametrize("compute,B,T,p", [("bf16", 256, 15, 0.0), ("bf16", 130, 9, 0.0), ("f32s", 200, 15, 0.0), ("f32", 140, 16, 0.0), ("f32s", 256, 15, 0.3),
+                                           ("bf16", 160, 15, 0.1)])
+def test_fused_lossav_equals_the_two_launch_head(egx_lib, cuda, compute, B, T, p):
     """model.forward_features(..., lossav=head, labels=y) (egx_token_ce: classifier + weighted CE + scores in the launch that normalises the last
     layer's tokens; d tokens and the classifier's gradients rebuilt by the backward's first launch) against head(model.forward_features(...), y)
     (egx_linear_ce_fwd / _bwd on the returned tokens): same scores, labels and counts, loss within 1e-6, every gradient of the translator and of
-    the classifier within rounding of the other summation order; with a loss scale as the upstream gradient."""
+    the classifier within rounding of the other summation order; with a loss scale as the upstream gradient; with dropout under the same seed."""
     from egot2_amd import functional as F_egx
     feats = [f.to(cuda) for f in seeded_feats(77, [(B, T, 256)] * 3)]
     y = torch.randint(0, 2, (B * T,), generator=torch.Generator().manual_seed(3)).to(cuda)
     y[5] = -100     # ignored frame: no loss, no weight, no gradient
     out = {}
     for fused in (True, False):
-        m, head = _asd(cuda, compute)
+        m, head = _asd(cuda, compute, p=p)
+        m._egx_seed = lambda: 0x5EED77       # (p > 0: both forms draw the same masks)
         if fused:
             nloss, score, label, correct = m.forward_features(*feats, lossav=head, labels=y)
             assert F_egx.last_encoder_impl() == "fused"
